@@ -1,0 +1,170 @@
+"""Checkpoint layout of the generator and seeded synthetic weights / inputs.
+
+``state_dict_spec(cfg)`` derives, from the constructor kwargs alone, the exact key set and
+shapes that ``generator.load_state_dict(checkpoint['generator'])`` expects in the reference
+(reference demo.py:91; key set listed in SURVEY.md section 8b): conv weights are OIHW, every
+``norm`` carries ``weight, bias, running_mean, running_var, num_batches_tracked`` and the
+dense-motion network owns the ``down.weight`` anti-alias buffer.
+
+No pretrained checkpoint ships with the reference (README.md:21 is a download link), so parity is
+pinned with synthetic weights produced by a frozen ``numpy.random.RandomState`` stream: He-scaled
+convolutions and non-trivial BatchNorm statistics (PyTorch's default init makes the prediction
+almost constant, which would let a broken kernel pass).  The same generator is used in the
+container (to drive the imported reference) and on the GPU box, so 182 MB of weights never have to
+be committed.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+# ----------------------------------------------------------------------------------------------
+# layout
+# ----------------------------------------------------------------------------------------------
+def _block(prefix, cin, cout, k, spec, gain):
+    spec.append((prefix + ".conv.weight", (cout, cin, k, k), "conv_w", gain))
+    spec.append((prefix + ".conv.bias", (cout,), "conv_b", None))
+    _norm(prefix + ".norm", cout, spec)
+
+
+def _norm(prefix, c, spec):
+    spec.append((prefix + ".weight", (c,), "bn_w", None))
+    spec.append((prefix + ".bias", (c,), "bn_b", None))
+    spec.append((prefix + ".running_mean", (c,), "bn_mean", None))
+    spec.append((prefix + ".running_var", (c,), "bn_var", None))
+    spec.append((prefix + ".num_batches_tracked", (), "nbt", None))
+
+
+def hourglass_channels(block_expansion, in_features, num_blocks, max_features):
+    """(encoder [(cin, cout)], decoder [(cin, cout)], out_filters) -- reference util.py:941-987."""
+    enc = []
+    for i in range(num_blocks):
+        cin = in_features if i == 0 else min(max_features, block_expansion * (2 ** i))
+        cout = min(max_features, block_expansion * (2 ** (i + 1)))
+        enc.append((cin, cout))
+    dec = []
+    for i in reversed(range(num_blocks)):
+        mult = 1 if i == num_blocks - 1 else 2
+        cin = mult * min(max_features, block_expansion * (2 ** (i + 1)))
+        cout = min(max_features, block_expansion * (2 ** i))
+        dec.append((cin, cout))
+    return enc, dec, block_expansion + in_features
+
+
+def generator_channels(cfg):
+    """Encoder / decoder channel plan of the generator (reference generator.py:25-46)."""
+    be, mf, nd = cfg["block_expansion"], cfg["max_features"], cfg["num_down_blocks"]
+    down = [(min(mf, be * 2 ** i), min(mf, be * 2 ** (i + 1))) for i in range(nd)]
+    up = [(min(mf, be * 2 ** (nd - i)), min(mf, be * 2 ** (nd - i - 1))) for i in range(nd)]
+    return down, up, min(mf, be * 2 ** nd)
+
+
+def state_dict_spec(cfg):
+    """Ordered [(key, shape, kind, gain)] in the reference's registration order."""
+    spec = []
+    nc, nk = cfg["num_channels"], cfg["num_kp"]
+    dm = cfg.get("dense_motion_params")
+    if dm is not None:
+        enc, dec, out_filters = hourglass_channels(
+            dm["block_expansion"], (nk + 1) * (nc + 1), dm["num_blocks"], dm["max_features"])
+        p = "dense_motion_network."
+        for i, (ci, co) in enumerate(enc):
+            _block(f"{p}hourglass.encoder.down_blocks.{i}", ci, co, 3, spec, 2.0)
+        for i, (ci, co) in enumerate(dec):
+            _block(f"{p}hourglass.decoder.up_blocks.{i}", ci, co, 3, spec, 2.0)
+        spec.append((p + "mask.weight", (nk + 1, out_filters, 7, 7), "conv_w", 4.0))
+        spec.append((p + "mask.bias", (nk + 1,), "conv_b", None))
+        if cfg.get("estimate_occlusion_map", False):
+            spec.append((p + "occlusion.weight", (1, out_filters, 7, 7), "conv_w", 4.0))
+            spec.append((p + "occlusion.bias", (1,), "conv_b", None))
+        if dm.get("scale_factor", 1) != 1:
+            spec.append((p + "down.weight", (nc, 1, 13, 13), "aa", None))
+    down, up, bott = generator_channels(cfg)
+    _block("first", nc, cfg["block_expansion"], 7, spec, 2.0)
+    for i, (ci, co) in enumerate(down):
+        _block(f"down_blocks.{i}", ci, co, 3, spec, 2.0)
+    for i, (ci, co) in enumerate(up):
+        _block(f"up_blocks.{i}", ci, co, 3, spec, 2.0)
+    for i in range(cfg["num_bottleneck_blocks"]):
+        r = f"bottleneck.r{i}"
+        spec.append((r + ".conv1.weight", (bott, bott, 3, 3), "conv_w", 1.0))
+        spec.append((r + ".conv1.bias", (bott,), "conv_b", None))
+        spec.append((r + ".conv2.weight", (bott, bott, 3, 3), "conv_w", 1.0))
+        spec.append((r + ".conv2.bias", (bott,), "conv_b", None))
+        _norm(r + ".norm1", bott, spec)
+        _norm(r + ".norm2", bott, spec)
+    spec.append(("final.weight", (nc, cfg["block_expansion"], 7, 7), "conv_w", 1.0))
+    spec.append(("final.bias", (nc,), "conv_b", None))
+    return spec
+
+
+def antialias_kernel(channels: int, sigma: float = 1.5) -> torch.Tensor:
+    """The fixed 13x13 Gaussian buffer of the anti-alias down-sampler.
+
+    Reference util.py:1009-1035: sigma is hard-coded to 1.5 regardless of the scale, the window is
+    2*round(4*sigma)+1 = 13 taps, normalised to sum 1, replicated per channel as a depthwise weight.
+    """
+    size = 2 * round(sigma * 4) + 1
+    ax = torch.arange(size, dtype=torch.float32)
+    mean = (size - 1) / 2
+    g = torch.exp(-(ax - mean) ** 2 / (2 * sigma ** 2))
+    k2 = g[:, None] * g[None, :]
+    k2 = k2 / torch.sum(k2)
+    return k2.view(1, 1, size, size).repeat(channels, 1, 1, 1).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded synthetic weights and inputs (frozen RandomState stream)
+# ----------------------------------------------------------------------------------------------
+def synthetic_state_dict(cfg, seed: int = 1234) -> "OrderedDict[str, torch.Tensor]":
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for key, shape, kind, gain in state_dict_spec(cfg):
+        if kind == "conv_w":
+            fan_in = shape[1] * shape[2] * shape[3]
+            v = rs.standard_normal(shape) * math.sqrt(gain / fan_in)
+        elif kind == "conv_b":
+            v = 0.1 * rs.standard_normal(shape)
+        elif kind == "bn_w":
+            v = rs.uniform(0.75, 1.25, shape)
+        elif kind in ("bn_b", "bn_mean"):
+            v = 0.1 * rs.standard_normal(shape)
+        elif kind == "bn_var":
+            v = rs.uniform(0.75, 1.25, shape)
+        elif kind == "nbt":
+            sd[key] = torch.tensor(1000, dtype=torch.int64)
+            continue
+        elif kind == "aa":
+            sd[key] = antialias_kernel(shape[0])
+            continue
+        else:  # pragma: no cover
+            raise ValueError(kind)
+        sd[key] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return sd
+
+
+def synthetic_source(size: int, seed: int = 1, batch: int = 1) -> torch.Tensor:
+    """uniform[0,1) RGB source, float32 [batch,3,size,size]."""
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy(rs.uniform(0.0, 1.0, (batch, 3, size, size)).astype(np.float32))
+
+
+def synthetic_keypoints(n: int, num_kp: int = 10, seed: int = 0, jacobian: bool = True) -> dict:
+    """n keypoint sets: value ~ U[-0.8, 0.8], jacobian = I + 0.1 N(0,1) (well conditioned).
+
+    Frame t of a clip uses seed 2+t, the source keypoints seed 0; each
+    frame draws from its own stream so that a shard of a clip is reproducible in isolation.
+    """
+    vals, jacs = [], []
+    for i in range(n):
+        rs = np.random.RandomState(seed + i)
+        vals.append(rs.uniform(-0.8, 0.8, (num_kp, 2)))
+        jacs.append(np.eye(2)[None] + 0.1 * rs.standard_normal((num_kp, 2, 2)))
+    kp = {"value": torch.from_numpy(np.stack(vals).astype(np.float32))}
+    if jacobian:
+        kp["jacobian"] = torch.from_numpy(np.stack(jacs).astype(np.float32))
+    return kp

@@ -1,0 +1,203 @@
+"""CPU oracle for the dense-motion + OcclusionAwareGenerator forward path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain PyTorch-CPU restatement of the reference's
+algorithm for the one hot path this repository accelerates.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it; the product
+path (``eamm_amd``) never does and fails loudly when its HIP library is missing.
+
+Parity pin: the reference ships no tests, golden vectors or checkpoints for this path (SURVEY.md
+section 4), so the oracle is pinned against the reference ITSELF: ``oracle/make_golden.py`` imports
+``/root/reference`` (possible only in the build container), drives it with the seeded weights and
+inputs of ``eamm_amd.weights`` and (a) asserts this restatement reproduces every output key, (b)
+writes the reference's outputs as fixtures under ``tests/golden/``.  ``tests/test_oracle_golden.py``
+re-checks the oracle against those fixtures wherever the tests run.
+
+The restatement is functional (a state_dict in, tensors out) rather than a module tree; every
+function cites the reference lines it follows.  dtype follows the inputs, so the same code gives
+the fp64 noise floor of the algorithm.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5  # reference sync_batchnorm/batchnorm.py:39
+
+
+# ----------------------------------------------------------------------------------------------
+# small pieces
+# ----------------------------------------------------------------------------------------------
+def coordinate_grid(h: int, w: int, dtype, device="cpu") -> torch.Tensor:
+    """[h,w,2] grid, last dim (x, y), x = 2*j/(w-1)-1 -- reference util.py:839-855."""
+    xs = 2 * (torch.arange(w, device=device).to(dtype) / (w - 1)) - 1
+    ys = 2 * (torch.arange(h, device=device).to(dtype) / (h - 1)) - 1
+    return torch.stack([xs[None, :].expand(h, w), ys[:, None].expand(h, w)], dim=2)
+
+
+def gaussian_heatmaps(kp_value: torch.Tensor, h: int, w: int, variance: float) -> torch.Tensor:
+    """[B,K,h,w] exp(-0.5*|z-kp|^2/var) -- reference util.py:815-836."""
+    grid = coordinate_grid(h, w, kp_value.dtype, kp_value.device)          # [h,w,2]
+    diff = grid[None, None] - kp_value[:, :, None, None, :]                # [B,K,h,w,2]
+    return torch.exp(-0.5 * (diff ** 2).sum(-1) / variance)
+
+
+def batch_norm_eval(x, sd, prefix):
+    """Eval-mode BatchNorm with running statistics -- sync_batchnorm/batchnorm.py:48-53."""
+    return F.batch_norm(x, sd[prefix + ".running_mean"].to(x.dtype), sd[prefix + ".running_var"].to(x.dtype),
+                        sd[prefix + ".weight"].to(x.dtype), sd[prefix + ".bias"].to(x.dtype),
+                        False, 0.0, BN_EPS)
+
+
+def _conv(x, sd, prefix, pad):
+    return F.conv2d(x, sd[prefix + ".weight"].to(x.dtype), sd[prefix + ".bias"].to(x.dtype), padding=pad)
+
+
+def same_block(x, sd, prefix, pad):
+    """conv -> BN -> ReLU -- reference util.py:934-938."""
+    return F.relu(batch_norm_eval(_conv(x, sd, prefix + ".conv", pad), sd, prefix + ".norm"))
+
+
+def down_block(x, sd, prefix):
+    """conv3x3 -> BN -> ReLU -> avgpool 2x2 -- reference util.py:915-920."""
+    return F.avg_pool2d(same_block(x, sd, prefix, 1), kernel_size=(2, 2))
+
+
+def up_block(x, sd, prefix):
+    """nearest x2 -> conv3x3 -> BN -> ReLU -- reference util.py:895-900."""
+    return same_block(F.interpolate(x, scale_factor=2), sd, prefix, 1)
+
+
+def res_block(x, sd, prefix):
+    """x + conv2(relu(bn2(conv1(relu(bn1(x)))))) -- reference util.py:872-880."""
+    y = _conv(F.relu(batch_norm_eval(x, sd, prefix + ".norm1")), sd, prefix + ".conv1", 1)
+    y = _conv(F.relu(batch_norm_eval(y, sd, prefix + ".norm2")), sd, prefix + ".conv2", 1)
+    return y + x
+
+
+def hourglass(x, sd, prefix, num_blocks):
+    """U-Net: encoder keeps every scale, decoder concatenates [up, skip] -- util.py:956-987."""
+    skips = [x]
+    for i in range(num_blocks):
+        skips.append(down_block(skips[-1], sd, f"{prefix}.encoder.down_blocks.{i}"))
+    out = skips.pop()
+    for i in range(num_blocks):
+        out = up_block(out, sd, f"{prefix}.decoder.up_blocks.{i}")
+        out = torch.cat([out, skips.pop()], dim=1)
+    return out
+
+
+def antialias_down(x, sd, scale):
+    """zero-pad 6, depthwise 13x13 Gaussian, keep every (1/scale)-th row/col -- util.py:1044-1052."""
+    if scale == 1:
+        return x
+    wgt = sd["dense_motion_network.down.weight"].to(x.dtype)
+    ka = wgt.shape[-1] // 2
+    y = F.conv2d(F.pad(x, (ka, ka, ka, ka)), wgt, groups=x.shape[1])
+    step = int(1 / scale)
+    return y[:, :, ::step, ::step]
+
+
+# ----------------------------------------------------------------------------------------------
+# dense motion -- reference dense_motion.py:32-113
+# ----------------------------------------------------------------------------------------------
+def sparse_motions(kp_driving, kp_source, h, w):
+    """[B,K+1,h,w,2]: T_0 = identity grid, T_k = J_s J_d^-1 (z - kp_d) + kp_s -- dense_motion.py:47-67."""
+    vd, vs = kp_driving["value"], kp_source["value"]
+    b, k = vd.shape[:2]
+    grid = coordinate_grid(h, w, vs.dtype, vs.device)
+    rel = grid[None, None] - vd[:, :, None, None, :]                          # [B,K,h,w,2]
+    if "jacobian" in kp_driving:
+        jac = torch.matmul(kp_source["jacobian"], torch.inverse(kp_driving["jacobian"]))  # [B,K,2,2]
+        rel = torch.einsum("bkij,bkhwj->bkhwi", jac, rel)
+    moved = rel + vs[:, :, None, None, :]
+    ident = grid[None, None].expand(b, 1, h, w, 2)
+    return torch.cat([ident, moved], dim=1)
+
+
+def dense_motion(sd, cfg, source_image, kp_driving, kp_source):
+    dm = cfg["dense_motion_params"]
+    nk = cfg["num_kp"]
+    var = dm.get("kp_variance", 0.01)
+    src = antialias_down(source_image, sd, dm.get("scale_factor", 1))
+    b, c, h, w = src.shape
+    # heat-maps: [0, G(driving) - G(source)]                                 dense_motion.py:32-45
+    heat = gaussian_heatmaps(kp_driving["value"], h, w, var) - gaussian_heatmaps(kp_source["value"], h, w, var)
+    heat = torch.cat([torch.zeros_like(heat[:, :1]), heat], dim=1)[:, :, None]   # [B,K+1,1,h,w]
+    motions = sparse_motions(kp_driving, kp_source, h, w)                       # [B,K+1,h,w,2]
+    # K+1 backward warps of the small source                                dense_motion.py:69-79
+    rep = src[:, None].expand(b, nk + 1, c, h, w).reshape(b * (nk + 1), c, h, w)
+    warped = F.grid_sample(rep, motions.reshape(b * (nk + 1), h, w, 2), mode="bilinear",
+                           padding_mode="zeros", align_corners=False)
+    warped = warped.view(b, nk + 1, c, h, w)
+    hg_in = torch.cat([heat, warped], dim=2).view(b, (nk + 1) * (c + 1), h, w)  # dense_motion.py:93-94
+    feat = hourglass(hg_in, sd, "dense_motion_network.hourglass", dm["num_blocks"])
+    mask = F.softmax(_conv(feat, sd, "dense_motion_network.mask", 3), dim=1)    # dense_motion.py:98-99
+    deformation = (motions * mask[..., None]).sum(dim=1)                        # [B,h,w,2]  :101-104
+    out = {"sparse_deformed": warped, "mask": mask, "deformation": deformation}
+    if cfg.get("estimate_occlusion_map", False):
+        out["occlusion_map"] = torch.sigmoid(_conv(feat, sd, "dense_motion_network.occlusion", 3))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# generator -- reference generator.py:50-97
+# ----------------------------------------------------------------------------------------------
+def warp_by_flow(inp, deformation):
+    """deform_input: resize the flow bilinearly if needed, then grid_sample -- generator.py:50-57."""
+    h, w = inp.shape[2:]
+    if deformation.shape[1] != h or deformation.shape[2] != w:
+        deformation = F.interpolate(deformation.permute(0, 3, 1, 2), size=(h, w), mode="bilinear",
+                                    align_corners=False).permute(0, 2, 3, 1)
+    return F.grid_sample(inp, deformation, mode="bilinear", padding_mode="zeros", align_corners=False)
+
+
+def encode_source(sd, cfg, source_image):
+    """Frame-invariant encoder: first 7x7 block + down blocks -- generator.py:61-63."""
+    out = same_block(source_image, sd, "first", 3)
+    for i in range(cfg["num_down_blocks"]):
+        out = down_block(out, sd, f"down_blocks.{i}")
+    return out
+
+
+def decode(sd, cfg, feat):
+    """bottleneck res-blocks, up blocks, final 7x7 conv, sigmoid -- generator.py:89-93."""
+    out = feat
+    for i in range(cfg["num_bottleneck_blocks"]):
+        out = res_block(out, sd, f"bottleneck.r{i}")
+    for i in range(cfg["num_down_blocks"]):
+        out = up_block(out, sd, f"up_blocks.{i}")
+    return torch.sigmoid(_conv(out, sd, "final", 3))
+
+
+def generator_forward(sd, cfg, source_image, kp_driving, kp_source):
+    """Same contract as OcclusionAwareGenerator.forward (generator.py:59-97): dict of outputs."""
+    feat = encode_source(sd, cfg, source_image)
+    outputs = {}
+    if cfg.get("dense_motion_params") is not None:
+        dmo = dense_motion(sd, cfg, source_image, kp_driving, kp_source)
+        outputs["mask"] = dmo["mask"]
+        outputs["sparse_deformed"] = dmo["sparse_deformed"]
+        outputs["deformation"] = dmo["deformation"]  # not returned by the reference; kept for tests
+        feat = warp_by_flow(feat, dmo["deformation"])
+        if "occlusion_map" in dmo:
+            occ = dmo["occlusion_map"]
+            outputs["occlusion_map"] = occ
+            if occ.shape[2:] != feat.shape[2:]:
+                occ = F.interpolate(occ, size=feat.shape[2:], mode="bilinear", align_corners=False)
+            feat = feat * occ
+        outputs["deformed"] = warp_by_flow(source_image, dmo["deformation"])
+    outputs["prediction"] = decode(sd, cfg, feat)
+    return outputs
+
+
+def animate_clip(sd, cfg, source_image, kp_source, kp_driving_seq):
+    """Counterpart of the per-frame loop in demo.py:251-281: one generator call per driving frame,
+    prediction returned as float32 [H,W,3] arrays (np.transpose(pred, [0,2,3,1])[0])."""
+    frames = []
+    n = kp_driving_seq["value"].shape[0]
+    with torch.no_grad():
+        for t in range(n):
+            kp_d = {k: v[t:t + 1] for k, v in kp_driving_seq.items()}
+            out = generator_forward(sd, cfg, source_image, kp_d, kp_source)
+            frames.append(out["prediction"][0].permute(1, 2, 0).contiguous().numpy())
+    return frames

@@ -1,0 +1,133 @@
+"""Pin the oracle against the reference itself and write tests/golden/*.npz.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to the GPU box):
+
+    python oracle/make_golden.py
+
+What it does
+  1. imports the reference's OcclusionAwareGenerator read-only (an empty ``cv2`` stub module is put
+     on sys.path because modules/util.py:6 imports cv2 for an unrelated helper);
+  2. loads the seeded synthetic weights of ``eamm_amd.weights`` into it with a STRICT
+     ``load_state_dict`` (the reference's checkpoint contract, demo.py:91);
+  3. runs it on seeded inputs, asserts that ``oracle/eamm_oracle.py`` reproduces every output key,
+     and records the fp32-vs-fp64 noise floor of the reference algorithm;
+  4. stores the REFERENCE outputs (data only: inputs + expected outputs, full tensors for the tiny
+     config, strided samples + statistics for the full-size ones) under tests/golden/.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from eamm_amd.config import hot_path_config, tiny_config  # noqa: E402
+from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict  # noqa: E402
+from oracle import eamm_oracle as orc  # noqa: E402
+
+REFERENCE = "/root/reference"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+KEYS = ("prediction", "mask", "sparse_deformed", "occlusion_map", "deformed", "deformation")
+
+
+def import_reference():
+    stub = tempfile.mkdtemp(prefix="cv2stub_")
+    open(os.path.join(stub, "cv2.py"), "w").close()
+    sys.path[:0] = [stub, REFERENCE]
+    from modules.generator import OcclusionAwareGenerator  # type: ignore
+    return OcclusionAwareGenerator
+
+
+def run_reference(gen, source, kp_d, kp_s):
+    with torch.no_grad():
+        out = gen(source, kp_source=kp_s, kp_driving=kp_d)
+        # 'deformation' is internal to the reference (dense_motion.py:106); fetch it from the
+        # sub-module so the flow itself is pinned too.
+        out["deformation"] = gen.dense_motion_network(source_image=source, kp_driving=kp_d,
+                                                      kp_source=kp_s)["deformation"]
+    return {k: out[k] for k in KEYS}
+
+
+def stats(t):
+    t = t.double()
+    return [float(t.mean()), float(t.std()), float(t.min()), float(t.max())]
+
+
+def case(OAG, name, cfg, size, n_frames, seed_w, stride, with_jacobian=True, per_frame_source=False):
+    sd = synthetic_state_dict(cfg, seed=seed_w)
+    gen = OAG(**cfg).eval()
+    gen.load_state_dict(sd, strict=True)
+    nsrc = n_frames if per_frame_source else 1
+    source = synthetic_source(size, seed=1, batch=nsrc)
+    kp_s = synthetic_keypoints(nsrc, cfg["num_kp"], seed=0)
+    kp_d = synthetic_keypoints(n_frames, cfg["num_kp"], seed=2, jacobian=with_jacobian)
+    if per_frame_source:      # the module contract: batch of independent (source, kp) pairs
+        src_b, kp_s_b = source, kp_s
+    else:                      # clip: one source, n_frames driving poses (demo.py:251-281)
+        src_b = source.expand(n_frames, -1, -1, -1).contiguous()
+        kp_s_b = {k: v.expand(n_frames, *v.shape[1:]).contiguous() for k, v in kp_s.items()}
+    ref = run_reference(gen, src_b, kp_d, kp_s_b)
+    with torch.no_grad():
+        mine = orc.generator_forward(sd, cfg, src_b, kp_d, kp_s_b)
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        ref64 = orc.generator_forward(sd64, cfg, src_b.double(), {k: v.double() for k, v in kp_d.items()},
+                                      {k: v.double() for k, v in kp_s_b.items()})
+    report = {}
+    for k in KEYS:
+        d = float((mine[k] - ref[k]).abs().max())
+        floor = float((ref[k].double() - ref64[k]).abs().max())
+        report[k] = {"oracle_vs_reference": d, "fp32_vs_fp64_floor": floor, "stats": stats(ref[k])}
+        # the restatement calls the same ATen kernels in the same order: it must agree with the
+        # reference to well inside the fp32 noise floor of the algorithm.
+        assert d <= max(2e-6, 2 * floor), (name, k, d, floor)
+    blob = {
+        "source_seed": np.int64(1), "weight_seed": np.int64(seed_w), "size": np.int64(size),
+        "stride": np.int64(stride), "per_frame_source": np.int64(per_frame_source),
+        "kp_source_value": kp_s["value"].numpy(), "kp_source_jacobian": kp_s["jacobian"].numpy(),
+        "kp_driving_value": kp_d["value"].numpy(),
+    }
+    if with_jacobian:
+        blob["kp_driving_jacobian"] = kp_d["jacobian"].numpy()
+    for k in KEYS:
+        t = ref[k]
+        s = stride if k in ("prediction", "deformed") else (max(1, stride // 4) if k == "sparse_deformed" else 1)
+        if k == "deformation":
+            blob[k] = t[:, ::s, ::s].contiguous().numpy()
+        else:
+            blob[k] = t[..., ::s, ::s].contiguous().numpy()
+        blob[k + "_stats"] = np.asarray(report[k]["stats"], dtype=np.float64)
+        blob[k + "_stride"] = np.int64(s)
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **blob)
+    return report
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    os.makedirs(GOLDEN, exist_ok=True)
+    OAG = import_reference()
+    full, tiny = hot_path_config(), tiny_config()
+    summary = {}
+    summary["tiny64_clip3"] = case(OAG, "tiny64_clip3", tiny, 64, 3, 1234, 1)
+    summary["tiny64_batch2"] = case(OAG, "tiny64_batch2", tiny, 64, 2, 1234, 1, per_frame_source=True)
+    summary["tiny64_nojac"] = case(OAG, "tiny64_nojac", tiny, 64, 2, 1234, 1, with_jacobian=False)
+    summary["full256_clip2"] = case(OAG, "full256_clip2", full, 256, 2, 1234, 4)
+    summary["full512_clip1"] = case(OAG, "full512_clip1", full, 512, 1, 1234, 8)
+    with open(os.path.join(GOLDEN, "summary.json"), "w") as f:
+        json.dump({"torch": torch.__version__, "cases": summary}, f, indent=1, sort_keys=True)
+    for name, rep in summary.items():
+        print(name)
+        for k, r in rep.items():
+            print(f"   {k:16s} oracle-vs-ref {r['oracle_vs_reference']:.2e}  fp64 floor {r['fp32_vs_fp64_floor']:.2e}"
+                  f"  mean/std/min/max {r['stats'][0]:.3f} {r['stats'][1]:.3f} {r['stats'][2]:.3f} {r['stats'][3]:.3f}")
+
+
+if __name__ == "__main__":
+    main()
