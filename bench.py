@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- 256x256 frames/sec of the dense-motion + generator forward path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (eamm_forward_frames: key points -> dense motion -> warp ->
+decoder) over one batch of 16 synthetic driving frames of a 256x256 clip on each GPU, with the source
+already encoded (the frame-invariant encoder runs once per clip; with N > 1 rank 0 encodes and the
+cached source tensors are broadcast once over RCCL/xGMI before the timed region).  Inputs (key
+points) are resident in HBM before the timed region; outputs stay on the device.  Frames of a clip
+are independent, so the path shards by frames with no data-path collective: weak scaling, value =
+all ranks' frames / max-over-ranks time.
+
+Prints ONE JSON line with the contract keys plus
+  roofline     -- the dominant kernel (the 3x3 fp32-MFMA implicit-GEMM convolution of the bottleneck:
+                  12 launches per step, 67 % of the FLOPs), algorithmic FLOPs / its average launch
+                  duration measured with HIP events on the launch stream inside the timed steps;
+  cpu_baseline -- the CPU oracle (PyTorch-CPU restatement of the reference, reference loop structure:
+                  one frame per call, source encoder re-run every frame) timed on this box's host
+                  cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from eamm_amd import OcclusionAwareGenerator, hot_path_config  # noqa: E402
+from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(cfg, sd, size, frames):
+    """Reference-equivalent CPU loop (demo.py:251-281) on the oracle: B=1, encoder per frame."""
+    from oracle import eamm_oracle as orc  # checker / baseline only; never on the product path
+    src = synthetic_source(size, seed=1)
+    kp_s = synthetic_keypoints(1, cfg["num_kp"], seed=0)
+    kp_d = synthetic_keypoints(frames + 1, cfg["num_kp"], seed=2)
+    # pick the thread count that serves the CPU path best on this box (all logical CPUs oversubscribe
+    # oneDNN on a B=1 256x256 frame); one timed frame per candidate, after a warm-up frame each
+    ncpu = os.cpu_count() or 1
+    best, best_t = 1, float("inf")
+    with torch.no_grad():
+        for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
+            torch.set_num_threads(nt)
+            one = {k: v[:1] for k, v in kp_d.items()}
+            orc.generator_forward(sd, cfg, src, one, kp_s)
+            t0 = time.perf_counter()
+            orc.generator_forward(sd, cfg, src, one, kp_s)
+            t = time.perf_counter() - t0
+            if t < best_t:
+                best, best_t = nt, t
+            if t > 5.0:   # already pathological; larger counts only get worse
+                break
+    torch.set_num_threads(best)
+    frames = max(4, min(frames, int(20.0 / max(best_t, 1e-3))))   # bound the sample to ~20 s
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        for t in range(1, frames + 1):
+            out = orc.generator_forward(sd, cfg, src, {k: v[t:t + 1] for k, v in kp_d.items()}, kp_s)
+            out["prediction"].numpy()
+        dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{frames} frames 256x256, one generator call per frame incl. source encoder "
+                      f"(reference loop demo.py:251-281), PyTorch-CPU fp32 oracle, best of 8..128 threads on "
+                      f"{ncpu} logical CPUs, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = hot_path_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    gen = OcclusionAwareGenerator(**cfg, max_frames=args.batch)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(dev).eval()
+    B, S = args.batch, args.size
+    eng = gen._ensure_engine(S, S, B, 1)
+
+    # once per clip: rank 0 encodes the source, the cached tensors are broadcast (the only collective)
+    t_bcast_ms = None
+    if rank == 0:
+        eng.encode_source(synthetic_source(S, seed=1).to(dev))
+    if world > 1:
+        blob = eng.export_source_cache(1) if rank == 0 else torch.empty(eng.source_cache_numel(1), device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(blob, src=0)
+        torch.cuda.synchronize()
+        t_bcast_ms = (time.perf_counter() - t0) * 1e3
+        if rank != 0:
+            eng.import_source_cache(blob, 1)
+    kp_s = {k: v.to(dev) for k, v in synthetic_keypoints(1, cfg["num_kp"], seed=0).items()}
+    # this rank's frames of the clip: contiguous shard, seeds 2 + global frame index
+    kp_d = {k: v.to(dev) for k, v in synthetic_keypoints(B, cfg["num_kp"], seed=2 + rank * B).items()}
+
+    def step():
+        return eng.forward_frames(kp_d, kp_s, outputs=("prediction",))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.profile(True)
+    eng.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read(reset=True)
+    eng.profile(False)
+    eng.check_numeric()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        frames = args.steps * B * world
+        fps = frames / dt
+        # dominant kernel: conv_mfma<3x3, 128x128 tile> in the bottleneck, 2*num_bottleneck_blocks launches/step
+        hf = S >> cfg["num_down_blocks"]
+        cb = min(cfg["max_features"], cfg["block_expansion"] << cfg["num_down_blocks"])
+        launches = 2 * cfg["num_bottleneck_blocks"] * max(1, prof["calls"])
+        flop_per_launch = 2.0 * (B * hf * hf) * cb * (9 * cb)
+        ms_per_launch = prof["ms"]["bottleneck"] / launches if prof["calls"] else float("nan")
+        achieved = flop_per_launch / (ms_per_launch * 1e-3) / 1e12
+        total_ms = sum(prof["ms"].values())
+        line = {
+            "metric": "256x256 frames/sec (dense-motion + generator forward)" if S == 256 else f"{S}x{S} frames/sec",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{S}x{S}, 10 keypoints, batch={B} synthetic frames per GPU per step, source "
+                                   f"encoded once per clip (BASELINE.json configs[2])",
+                       "frames_per_step_per_gpu": B, "parallelism": f"frame-sharded x{world}",
+                       "flops_per_frame": round(eng.flops_per_frame / 1e9, 3)},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<3,2,2,2,2> (3x3 256->256 @64x64, bottleneck)",
+                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(ms_per_launch, 4),
+                         "whole_path_tflops": round(fps / world * eng.flops_per_frame / 1e12, 2),
+                         "whole_path_frac": round(fps / world * eng.flops_per_frame / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
+            "stage_ms_per_step": {k: round(v / max(1, prof["calls"]), 4) for k, v in prof["ms"].items()},
+            "stage_sum_ms": round(total_ms / max(1, prof["calls"]), 4),
+        }
+        if t_bcast_ms is not None:
+            line["source_broadcast_ms"] = round(t_bcast_ms, 3)
+        if world == 1 and args.cpu_frames > 0:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, S, args.cpu_frames)
+            line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,12 @@
+"""eamm_amd -- MI355X (gfx950) implementation of EAMM's dense-motion + OcclusionAwareGenerator path.
+
+Python host code (this package) mirrors the reference's module interface for the path and drives
+libeamm_hip.so, a C-ABI library of hand-written HIP kernels (include/eamm_hip.h).  See DESIGN.md.
+"""
+from .config import hot_path_config, tiny_config  # noqa: F401
+from .generator import OcclusionAwareGenerator  # noqa: F401
+from .engine import Engine  # noqa: F401
+from .clip import EngineBackend, animate_clip, shard_bounds  # noqa: F401
+
+__all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "shard_bounds",
+           "hot_path_config", "tiny_config"]

@@ -1,0 +1,126 @@
+"""Clip pipeline: the counterpart of the per-frame loop in reference demo.py:251-281.
+
+Reference: for each of T driving frames call ``generator(source, kp_source, kp_driving[t])`` (which
+re-runs the source encoder every time) and copy ``out['prediction']`` to the host (one sync per
+frame).  Here: the source is encoded ONCE, frames are processed ``batch`` at a time, results stay on
+the device (optionally as uint8 HWC frames, the format demo.py:507 writes), and -- because the
+generator has no cross-frame dependence -- a clip shards across the GPUs of a node by contiguous
+frame ranges.  The only collective on the data path is one broadcast of the cached source tensors
+(encoder feature map + down-sampled source + full-resolution source, ~5 MB at 256x256) from rank 0
+over RCCL/xGMI, plus the (tiny) key-point tensors; outputs are gathered only if asked for.
+
+``torch.distributed`` is used as plumbing: backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the
+CPU tests, which drive this file with a stand-in backend object (tests/test_clip_sharding.py).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_frames: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced frame range [start, stop) of `rank` (first n%world ranks get one more)."""
+    base, rem = divmod(n_frames, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class EngineBackend:
+    """Runs the two halves of the path on one GPU through the HIP library."""
+
+    def __init__(self, generator, batch: int = 16):
+        self.generator = generator
+        self.batch = int(batch)
+        self.device = next(generator.parameters()).device
+        self.engine = None
+
+    def prepare(self, height: int, width: int):
+        self.engine = self.generator._ensure_engine(height, width, self.batch, 1)
+
+    def encode(self, source_image: torch.Tensor) -> torch.Tensor:
+        self.engine.encode_source(source_image.to(self.device))
+        return self.engine.export_source_cache(1)
+
+    def blob_like(self) -> torch.Tensor:
+        return torch.empty(self.engine.source_cache_numel(1), dtype=torch.float32, device=self.device)
+
+    def install(self, blob: torch.Tensor):
+        self.engine.import_source_cache(blob, 1)
+
+    def run(self, kp_driving: Dict[str, torch.Tensor], kp_source: Dict[str, torch.Tensor], uint8: bool):
+        out = self.engine.forward_frames(kp_driving, kp_source, outputs=("prediction",), uint8_frames=uint8)
+        return out["frames_u8"] if uint8 else out["prediction"]
+
+    def finish(self):
+        self.engine.check_numeric()
+
+
+def _bcast_kp(kp: Optional[Dict[str, torch.Tensor]], device, src: int, group) -> Dict[str, torch.Tensor]:
+    """Broadcast a key-point dict from `src` (shapes first, then payload)."""
+    rank = dist.get_rank(group)
+    meta = [None]
+    if rank == src:
+        meta = [{k: tuple(v.shape) for k, v in kp.items() if k in ("value", "jacobian")}]
+    dist.broadcast_object_list(meta, src=src, group=group)
+    out = {}
+    for k in sorted(meta[0]):
+        t = kp[k].to(device=device, dtype=torch.float32).contiguous() if rank == src else \
+            torch.empty(meta[0][k], dtype=torch.float32, device=device)
+        dist.broadcast(t, src=src, group=group)
+        out[k] = t
+    return out
+
+
+def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optional[Dict[str, torch.Tensor]],
+                 kp_driving: Optional[Dict[str, torch.Tensor]], height: int, width: int, uint8: bool = False,
+                 group=None, gather: bool = False) -> Tuple[torch.Tensor, Tuple[int, int]]:
+    """Animate one clip; returns (frames of this rank's shard, (start, stop)).
+
+    Single process: all T frames.  Under torch.distributed: rank 0 supplies ``source_image`` and the
+    key points (other ranks may pass None), every rank returns its contiguous shard; with
+    ``gather=True`` rank 0 instead returns all T frames (others an empty tensor).
+    """
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if distributed else 0
+    world = dist.get_world_size(group) if distributed else 1
+    backend.prepare(height, width)
+    # 1. frame-invariant source tensors: encode once on rank 0, one broadcast
+    if distributed:
+        blob = backend.encode(source_image) if rank == 0 else backend.blob_like()
+        dist.broadcast(blob, src=0, group=group)
+        if rank != 0:
+            backend.install(blob)
+        kp_source = _bcast_kp(kp_source, backend.device, 0, group)
+        kp_driving = _bcast_kp(kp_driving, backend.device, 0, group)
+    else:
+        backend.encode(source_image)
+        kp_source = {k: v.to(backend.device) for k, v in kp_source.items() if k in ("value", "jacobian")}
+        kp_driving = {k: v.to(backend.device) for k, v in kp_driving.items() if k in ("value", "jacobian")}
+    # 2. this rank's contiguous frame range, `batch` frames per launch sequence
+    total = kp_driving["value"].shape[0]
+    start, stop = shard_bounds(total, world, rank)
+    chunks: List[torch.Tensor] = []
+    for s in range(start, stop, backend.batch):
+        e = min(stop, s + backend.batch)
+        chunks.append(backend.run({k: v[s:e] for k, v in kp_driving.items()}, kp_source, uint8))
+    backend.finish()
+    shape_tail = (height, width, 3) if uint8 else (3, height, width)
+    dtype = torch.uint8 if uint8 else torch.float32
+    local = torch.cat(chunks, dim=0) if chunks else torch.empty((0,) + shape_tail, dtype=dtype, device=backend.device)
+    if not (distributed and gather):
+        return local, (start, stop)
+    # 3. optional gather of the shards on rank 0 (padded to the largest shard, then trimmed)
+    longest = shard_bounds(total, world, 0)[1]
+    padded = torch.zeros((longest,) + shape_tail, dtype=dtype, device=backend.device)
+    padded[: stop - start] = local
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+    dist.gather(padded, bufs, dst=0, group=group)
+    if rank != 0:
+        return local[:0], (start, stop)
+    parts = []
+    for r in range(world):
+        a, b = shard_bounds(total, world, r)
+        parts.append(bufs[r][: b - a])
+    return torch.cat(parts, dim=0), (0, total)

@@ -1,0 +1,849 @@
+// C ABI of libeamm_hip.so (see include/eamm_hip.h): handle, strict state_dict intake, BatchNorm folding
+// and weight repacking, workspace, and the launch sequence of the two halves of
+// OcclusionAwareGenerator.forward (reference modules/generator.py:59-97):
+//   eamm_encode_source  -- frame-invariant: first 7x7 block, down blocks, anti-alias down-sampling
+//   eamm_forward_frames -- per frame batch: key-point records, motion front end, hourglass, flow head,
+//                          feature warp, bottleneck, up blocks, final 7x7 + sigmoid
+#include "../../include/eamm_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace eamm;
+
+namespace {
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    size_t numel() const {
+        size_t n = 1;
+        for (auto s : shape) n *= (size_t)s;
+        return n;
+    }
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct eamm_ctx {
+    eamm_config cfg{};
+    int device = 0;
+    std::string err;
+    std::map<std::string, HostTensor> sd;
+    bool finalized = false;
+    int ns_cached = 0;
+
+    // derived geometry
+    int H = 0, W = 0, h = 0, w = 0, hf = 0, wf = 0, K = 0, nb = 0, nd = 0;
+    int Cb = 0;                 // bottleneck channels
+    int Cp0 = 0;                // hourglass input channels padded to a multiple of 32
+    int Csrc = 32;              // RGB source padded for the 7x7 MFMA encoder conv
+    std::vector<int> enc_c;     // hourglass encoder output channels e_1..e_nb
+    std::vector<int> dec_c;     // hourglass decoder output channels u_0..u_{nb-1}
+    std::vector<int> down_c;    // generator encoder channels [be, ...]
+    std::vector<int> up_c;      // generator decoder output channels
+
+    // layers
+    ConvLayer first, final_conv, head;
+    std::vector<ConvLayer> down, hg_enc, hg_dec, res1, res2, up;
+    std::vector<float*> pre_s, pre_t;  // res-block pre-activation scale/shift (norm1)
+    float* aa_w = nullptr;
+    std::vector<void*> owned;   // every device allocation, freed in destroy
+
+    // source cache (exportable): feat [S,hf,wf,Cb], src_small [S,h,w,4], src_full [S,3,H,W]
+    float *feat = nullptr, *src_small = nullptr, *src_full = nullptr;
+    // encoder temporaries
+    float* src_nhwc = nullptr;
+    std::vector<float*> enc_tmp;  // first output, then each down-block output except the last (= feat)
+    // per-frame workspace
+    float* kp_rec = nullptr;
+    int* bad_flag = nullptr;
+    float* hg_in = nullptr;
+    std::vector<float*> e_buf, u_buf;
+    float *logits = nullptr, *deformation = nullptr, *occlusion = nullptr;
+    float *xa = nullptr, *xb = nullptr, *act = nullptr, *tmp = nullptr;
+    std::vector<float*> up_buf;
+    float* partial = nullptr;
+    size_t partial_elems = 0;
+
+    double flops_frame = 0, flops_encode = 0;
+
+    // optional stage timing with HIP events on the caller's stream (bench.py roofline leg)
+    static constexpr int NSTAGE = 8;       // front, hg_enc, hg_dec, head, warp, bottleneck, up, final
+    static constexpr int PROF_CALLS = 256; // event sets kept before the host must read them
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_events;   // PROF_CALLS * (NSTAGE+1)
+    int prof_used = 0;
+    double prof_ms[NSTAGE] = {0};
+    long prof_calls = 0, prof_frames = 0;
+    std::vector<int> prof_n;
+};
+
+namespace {
+
+int fail(eamm_ctx* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return fail((c), EAMM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+template <typename T>
+int dev_alloc(eamm_ctx* c, T** p, size_t elems) {
+    void* q = nullptr;
+    HIP_TRY(c, hipMalloc(&q, std::max<size_t>(elems, 1) * sizeof(T)));
+    c->owned.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+
+int upload(eamm_ctx* c, float** dst, const std::vector<float>& src) {
+    int rc = dev_alloc(c, dst, src.size());
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+const HostTensor* find(const eamm_ctx* c, const std::string& key) {
+    auto it = c->sd.find(key);
+    return it == c->sd.end() ? nullptr : &it->second;
+}
+
+// conv (+ optional BatchNorm folded behind it) -> packed device layer.
+// y = ((conv(x) + b) - mean) * gamma / sqrt(var + eps) + beta   (sync_batchnorm/batchnorm.py:48-53, eps 1e-5)
+struct FoldSpec {
+    std::string conv;            // key prefix holding .weight / .bias
+    std::string norm;            // key prefix holding BatchNorm stats, or empty
+};
+
+int build_layer(eamm_ctx* c, const std::vector<FoldSpec>& parts, int ks, int C0_real, int C0_packed, int C1_real,
+                int C1_packed, ConvLayer* L) {
+    // `parts` are stacked along Cout (the flow head stacks mask + occlusion into one convolution)
+    const int Cin = C0_real + C1_real;
+    const int T = ks * ks;
+    int Cout = 0;
+    for (auto& ps : parts) {
+        const HostTensor* wt = find(c, ps.conv + ".weight");
+        if (!wt || wt->shape.size() != 4 || wt->shape[1] != Cin || wt->shape[2] != ks || wt->shape[3] != ks)
+            return fail(c, EAMM_ERR_KEY, "state_dict entry %s.weight missing or mis-shaped (expected [*,%d,%d,%d])",
+                        ps.conv.c_str(), Cin, ks, ks);
+        Cout += (int)wt->shape[0];
+    }
+    std::vector<float> wf((size_t)Cout * Cin * T), bf(Cout);
+    int o0 = 0;
+    for (auto& ps : parts) {
+        const HostTensor* wt = find(c, ps.conv + ".weight");
+        const HostTensor* bt = find(c, ps.conv + ".bias");
+        const int co = (int)wt->shape[0];
+        if (!bt || (int)bt->numel() != co) return fail(c, EAMM_ERR_KEY, "%s.bias missing or mis-shaped", ps.conv.c_str());
+        const HostTensor *g = nullptr, *be = nullptr, *mu = nullptr, *var = nullptr;
+        if (!ps.norm.empty()) {
+            g = find(c, ps.norm + ".weight");
+            be = find(c, ps.norm + ".bias");
+            mu = find(c, ps.norm + ".running_mean");
+            var = find(c, ps.norm + ".running_var");
+            if (!g || !be || !mu || !var || (int)g->numel() != co || (int)be->numel() != co ||
+                (int)mu->numel() != co || (int)var->numel() != co)
+                return fail(c, EAMM_ERR_KEY, "BatchNorm entries of %s missing or mis-shaped", ps.norm.c_str());
+        }
+        for (int o = 0; o < co; ++o) {
+            double s = 1.0, shift = 0.0, b = bt->data[o];
+            if (g) {
+                s = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+                b = (b - (double)mu->data[o]) * s + (double)be->data[o];
+            }
+            (void)shift;
+            bf[o0 + o] = (float)b;
+            const float* src = wt->data.data() + (size_t)o * Cin * T;
+            float* dst = wf.data() + (size_t)(o0 + o) * Cin * T;
+            for (size_t i = 0; i < (size_t)Cin * T; ++i) dst[i] = (float)((double)src[i] * s);
+        }
+        o0 += co;
+    }
+    const int cin_packed = C0_packed + C1_packed;
+    std::vector<int> map(cin_packed, -1);
+    for (int i = 0; i < C0_real; ++i) map[i] = i;
+    for (int i = 0; i < C1_real; ++i) map[C0_packed + i] = C0_real + i;
+    L->ks = ks;
+    L->C0 = C0_packed;
+    L->C1 = C1_packed;
+    L->Cout = Cout;
+    L->BN = conv_tile_n(Cout);
+    L->ntiles = (Cout + L->BN - 1) / L->BN;
+    L->nchunks = T * (cin_packed / CONV_BK);
+    std::vector<float> packed(conv_packed_elems(ks, cin_packed, Cout, L->BN));
+    conv_pack_host(wf.data(), Cout, Cin, ks, map.data(), cin_packed, L->BN, packed.data());
+    std::vector<float> bias_pad((size_t)L->ntiles * L->BN, 0.f);
+    std::copy(bf.begin(), bf.end(), bias_pad.begin());
+    int rc = upload(c, &L->w, packed);
+    if (rc) return rc;
+    return upload(c, &L->bias, bias_pad);
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+void expected_keys(const eamm_ctx* c, std::vector<std::string>* keys) {
+    auto block = [&](const std::string& p) {
+        keys->push_back(p + ".conv.weight");
+        keys->push_back(p + ".conv.bias");
+        for (const char* s : {".norm.weight", ".norm.bias", ".norm.running_mean", ".norm.running_var"})
+            keys->push_back(p + s);
+    };
+    const std::string dm = "dense_motion_network.";
+    for (int i = 0; i < c->nb; ++i) block(dm + "hourglass.encoder.down_blocks." + std::to_string(i));
+    for (int i = 0; i < c->nb; ++i) block(dm + "hourglass.decoder.up_blocks." + std::to_string(i));
+    keys->push_back(dm + "mask.weight");
+    keys->push_back(dm + "mask.bias");
+    if (c->cfg.estimate_occlusion_map) {
+        keys->push_back(dm + "occlusion.weight");
+        keys->push_back(dm + "occlusion.bias");
+    }
+    if (c->cfg.dm_inv_scale != 1) keys->push_back(dm + "down.weight");
+    block("first");
+    for (int i = 0; i < c->nd; ++i) block("down_blocks." + std::to_string(i));
+    for (int i = 0; i < c->nd; ++i) block("up_blocks." + std::to_string(i));
+    for (int i = 0; i < c->cfg.num_bottleneck_blocks; ++i) {
+        const std::string r = "bottleneck.r" + std::to_string(i);
+        for (const char* s : {".conv1.weight", ".conv1.bias", ".conv2.weight", ".conv2.bias", ".norm1.weight",
+                              ".norm1.bias", ".norm1.running_mean", ".norm1.running_var", ".norm2.weight",
+                              ".norm2.bias", ".norm2.running_mean", ".norm2.running_var"})
+            keys->push_back(r + s);
+    }
+    keys->push_back("final.weight");
+    keys->push_back("final.bias");
+}
+
+double conv_flops(int ks, int cin, int cout, double pixels) { return 2.0 * ks * ks * (double)cin * cout * pixels; }
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+extern "C" {
+
+int eamm_abi_version(void) { return EAMM_ABI_VERSION; }
+
+const char* eamm_last_error(const eamm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, EAMM_ERR_ARG, "null argument");
+    *out = nullptr;
+    const eamm_config& g = *cfg;
+    if (g.num_channels != 3) return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 3 (got %d)", g.num_channels);
+    if (g.num_kp < 1 || g.num_kp + 2 > 32) return fail(nullptr, EAMM_ERR_ARG, "num_kp out of range");
+    if (g.dm_num_blocks < 1) return fail(nullptr, EAMM_ERR_ARG, "dense_motion_params are required");
+    if (!is_pow2(g.dm_inv_scale) || g.dm_inv_scale > 4 || g.dm_inv_scale == 3)
+        return fail(nullptr, EAMM_ERR_ARG, "1/scale_factor must be 1, 2 or 4");
+    if (g.block_expansion % 32 || g.max_features % 32 || g.dm_block_expansion % 32 || g.dm_max_features % 32)
+        return fail(nullptr, EAMM_ERR_ARG, "channel widths must be multiples of 32");
+    if (g.num_down_blocks < 1 || g.num_bottleneck_blocks < 1)
+        return fail(nullptr, EAMM_ERR_ARG, "need at least one down block and one bottleneck block");
+    if (g.max_frames < 1 || g.max_sources < 1) return fail(nullptr, EAMM_ERR_ARG, "max_frames / max_sources < 1");
+    const int div_g = 1 << g.num_down_blocks, div_m = g.dm_inv_scale << g.dm_num_blocks;
+    if (g.height % div_g || g.width % div_g || g.height % div_m || g.width % div_m ||
+        g.height / div_m < 2 || g.width / div_m < 2)
+        return fail(nullptr, EAMM_ERR_ARG, "frame %dx%d not divisible for %d down blocks / %d hourglass levels",
+                    g.height, g.width, g.num_down_blocks, g.dm_num_blocks);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice(%d) failed", device);
+
+    eamm_ctx* c = new eamm_ctx();
+    c->cfg = g;
+    c->device = device;
+    c->H = g.height;
+    c->W = g.width;
+    c->h = c->H / g.dm_inv_scale;
+    c->w = c->W / g.dm_inv_scale;
+    c->nd = g.num_down_blocks;
+    c->nb = g.dm_num_blocks;
+    c->K = g.num_kp;
+    c->hf = c->H >> c->nd;
+    c->wf = c->W >> c->nd;
+    c->Cp0 = round_up((c->K + 1) * 4, 32);
+    // hourglass channel plan (reference modules/util.py:941-987)
+    for (int i = 0; i < c->nb; ++i) c->enc_c.push_back(std::min(g.dm_max_features, g.dm_block_expansion << (i + 1)));
+    for (int i = c->nb - 1; i >= 0; --i) c->dec_c.push_back(std::min(g.dm_max_features, g.dm_block_expansion << i));
+    // generator channel plan (reference modules/generator.py:27-44)
+    c->down_c.push_back(g.block_expansion);
+    for (int i = 0; i < c->nd; ++i) c->down_c.push_back(std::min(g.max_features, g.block_expansion << (i + 1)));
+    for (int i = 0; i < c->nd; ++i) c->up_c.push_back(std::min(g.max_features, g.block_expansion << (c->nd - i - 1)));
+    c->Cb = c->down_c.back();
+    *out = c;
+    return EAMM_OK;
+}
+
+void eamm_destroy(eamm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : c->owned) (void)hipFree(p);
+    for (auto& e : c->prof_events) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int eamm_load_tensor(eamm_ctx* c, const char* key, const float* host, const int64_t* shape, int ndim) {
+    if (!c || !key || !host || ndim < 0 || (ndim > 0 && !shape)) return fail(c, EAMM_ERR_ARG, "null argument");
+    if (c->finalized) return fail(c, EAMM_ERR_STATE, "weights already finalised; create a new handle to reload");
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    t.data.assign(host, host + t.numel());
+    c->sd[key] = std::move(t);
+    return EAMM_OK;
+}
+
+int eamm_finalize_weights(eamm_ctx* c) {
+    if (!c) return EAMM_ERR_ARG;
+    if (c->finalized) return fail(c, EAMM_ERR_STATE, "weights already finalised");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const eamm_config& g = c->cfg;
+    // strict key-set check, like load_state_dict(strict=True) (reference demo.py:91)
+    {
+        std::vector<std::string> want;
+        expected_keys(c, &want);
+        std::string missing, unexpected;
+        for (auto& k : want)
+            if (!c->sd.count(k)) missing += (missing.empty() ? "" : ", ") + k;
+        for (auto& kv : c->sd) {
+            const std::string& k = kv.first;
+            if (k.size() > 20 && k.compare(k.size() - 20, 20, ".num_batches_tracked") == 0) continue;
+            if (std::find(want.begin(), want.end(), k) == want.end()) unexpected += (unexpected.empty() ? "" : ", ") + k;
+        }
+        if (!missing.empty() || !unexpected.empty())
+            return fail(c, EAMM_ERR_KEY, "state_dict mismatch. Missing key(s): [%s]. Unexpected key(s): [%s].",
+                        missing.substr(0, 400).c_str(), unexpected.substr(0, 400).c_str());
+    }
+    const std::string dm = "dense_motion_network.";
+    int rc;
+    // hourglass encoder: e_0 = 44-channel motion tensor (padded to Cp0), e_i = DownBlock2d_i(e_{i-1})
+    c->hg_enc.resize(c->nb);
+    const int cin0 = (c->K + 1) * 4;
+    for (int i = 0; i < c->nb; ++i) {
+        const std::string p = dm + "hourglass.encoder.down_blocks." + std::to_string(i);
+        const int cr = i == 0 ? cin0 : c->enc_c[i - 1], cp = i == 0 ? c->Cp0 : c->enc_c[i - 1];
+        if ((rc = build_layer(c, {{p + ".conv", p + ".norm"}}, 3, cr, cp, 0, 0, &c->hg_enc[i]))) return rc;
+    }
+    // hourglass decoder: u_i = UpBlock2d_i(cat[u_{i-1}, e_{nb-i}])  (util.py:981-987)
+    c->hg_dec.resize(c->nb);
+    for (int i = 0; i < c->nb; ++i) {
+        const std::string p = dm + "hourglass.decoder.up_blocks." + std::to_string(i);
+        const int c0 = i == 0 ? c->enc_c[c->nb - 1] : c->dec_c[i - 1];
+        const int c1 = i == 0 ? 0 : c->enc_c[c->nb - 1 - i];
+        if ((rc = build_layer(c, {{p + ".conv", p + ".norm"}}, 3, c0, c0, c1, c1, &c->hg_dec[i]))) return rc;
+    }
+    // flow head: mask (K+1) and occlusion (1) 7x7 convolutions share one launch (dense_motion.py:98,110)
+    {
+        std::vector<FoldSpec> parts = {{dm + "mask", ""}};
+        if (g.estimate_occlusion_map) parts.push_back({dm + "occlusion", ""});
+        if ((rc = build_layer(c, parts, 7, c->dec_c.back(), c->dec_c.back(), cin0, c->Cp0, &c->head))) return rc;
+    }
+    // generator encoder
+    if ((rc = build_layer(c, {{"first.conv", "first.norm"}}, 7, 3, c->Csrc, 0, 0, &c->first))) return rc;
+    c->down.resize(c->nd);
+    for (int i = 0; i < c->nd; ++i) {
+        const std::string p = "down_blocks." + std::to_string(i);
+        if ((rc = build_layer(c, {{p + ".conv", p + ".norm"}}, 3, c->down_c[i], c->down_c[i], 0, 0, &c->down[i])))
+            return rc;
+    }
+    // bottleneck: conv1 absorbs norm2 (conv1 -> norm2 -> relu), norm1 becomes the producer's second output
+    const int nr = g.num_bottleneck_blocks;
+    c->res1.resize(nr);
+    c->res2.resize(nr);
+    c->pre_s.resize(nr);
+    c->pre_t.resize(nr);
+    for (int i = 0; i < nr; ++i) {
+        const std::string r = "bottleneck.r" + std::to_string(i);
+        if ((rc = build_layer(c, {{r + ".conv1", r + ".norm2"}}, 3, c->Cb, c->Cb, 0, 0, &c->res1[i]))) return rc;
+        if ((rc = build_layer(c, {{r + ".conv2", ""}}, 3, c->Cb, c->Cb, 0, 0, &c->res2[i]))) return rc;
+        const HostTensor *gm = find(c, r + ".norm1.weight"), *bt = find(c, r + ".norm1.bias"),
+                         *mu = find(c, r + ".norm1.running_mean"), *vr = find(c, r + ".norm1.running_var");
+        if ((int)gm->numel() != c->Cb || (int)bt->numel() != c->Cb || (int)mu->numel() != c->Cb ||
+            (int)vr->numel() != c->Cb)
+            return fail(c, EAMM_ERR_KEY, "%s.norm1 mis-shaped", r.c_str());
+        std::vector<float> s(c->Cb), t(c->Cb);
+        for (int ch = 0; ch < c->Cb; ++ch) {
+            const double sc = (double)gm->data[ch] / std::sqrt((double)vr->data[ch] + 1e-5);
+            s[ch] = (float)sc;
+            t[ch] = (float)((double)bt->data[ch] - (double)mu->data[ch] * sc);
+        }
+        if ((rc = upload(c, &c->pre_s[i], s))) return rc;
+        if ((rc = upload(c, &c->pre_t[i], t))) return rc;
+    }
+    c->up.resize(c->nd);
+    for (int i = 0; i < c->nd; ++i) {
+        const std::string p = "up_blocks." + std::to_string(i);
+        const int ci = i == 0 ? c->Cb : c->up_c[i - 1];
+        if ((rc = build_layer(c, {{p + ".conv", p + ".norm"}}, 3, ci, ci, 0, 0, &c->up[i]))) return rc;
+    }
+    if ((rc = build_layer(c, {{"final", ""}}, 7, c->up_c.back(), c->up_c.back(), 0, 0, &c->final_conv))) return rc;
+    if (c->final_conv.Cout != 3) return fail(c, EAMM_ERR_KEY, "final.weight must have 3 output channels");
+    // anti-alias buffer [3,1,13,13]
+    {
+        std::vector<float> aa(3 * 169, 0.f);
+        if (g.dm_inv_scale != 1) {
+            const HostTensor* t = find(c, dm + "down.weight");
+            if (!t || t->numel() != 3 * 169) return fail(c, EAMM_ERR_KEY, "%sdown.weight must be [3,1,13,13]", dm.c_str());
+            aa = t->data;
+        }
+        if ((rc = upload(c, &c->aa_w, aa))) return rc;
+    }
+
+    // ---- workspace --------------------------------------------------------------------------
+    const size_t S = g.max_sources, F = g.max_frames;
+    const size_t HW = (size_t)c->H * c->W, hw = (size_t)c->h * c->w, hwf = (size_t)c->hf * c->wf;
+    if ((rc = dev_alloc(c, &c->feat, S * hwf * c->Cb))) return rc;
+    if ((rc = dev_alloc(c, &c->src_small, S * hw * 4))) return rc;
+    if ((rc = dev_alloc(c, &c->src_full, S * 3 * HW))) return rc;
+    if ((rc = dev_alloc(c, &c->src_nhwc, S * HW * c->Csrc))) return rc;
+    c->enc_tmp.resize(c->nd);
+    for (int i = 0; i < c->nd; ++i)  // enc_tmp[0] = first output @HxW; enc_tmp[i] = down[i-1] output
+        if ((rc = dev_alloc(c, &c->enc_tmp[i], S * (HW >> (2 * i)) * c->down_c[i]))) return rc;
+    if ((rc = dev_alloc(c, &c->kp_rec, F * c->K * KP_STRIDE))) return rc;
+    if ((rc = dev_alloc(c, &c->bad_flag, 1))) return rc;
+    HIP_TRY(c, hipMemset(c->bad_flag, 0, sizeof(int)));
+    if ((rc = dev_alloc(c, &c->hg_in, F * hw * c->Cp0))) return rc;
+    c->e_buf.resize(c->nb);
+    c->u_buf.resize(c->nb);
+    for (int i = 0; i < c->nb; ++i) {
+        if ((rc = dev_alloc(c, &c->e_buf[i], F * (hw >> (2 * (i + 1))) * c->enc_c[i]))) return rc;
+        if ((rc = dev_alloc(c, &c->u_buf[i], F * (hw >> (2 * (c->nb - 1 - i))) * c->dec_c[i]))) return rc;
+    }
+    if ((rc = dev_alloc(c, &c->logits, F * hw * 32))) return rc;
+    if ((rc = dev_alloc(c, &c->deformation, F * hw * 2))) return rc;
+    if ((rc = dev_alloc(c, &c->occlusion, F * hw))) return rc;
+    if ((rc = dev_alloc(c, &c->xa, F * hwf * c->Cb))) return rc;
+    if ((rc = dev_alloc(c, &c->xb, F * hwf * c->Cb))) return rc;
+    if ((rc = dev_alloc(c, &c->act, F * hwf * c->Cb))) return rc;
+    if ((rc = dev_alloc(c, &c->tmp, F * hwf * c->Cb))) return rc;
+    c->up_buf.resize(c->nd);
+    for (int i = 0; i < c->nd; ++i)
+        if ((rc = dev_alloc(c, &c->up_buf[i], F * (hwf << (2 * (i + 1))) * c->up_c[i]))) return rc;
+    // split-K slab: the largest any layer asks for at any batch size up to the maximum (a smaller batch
+    // can pick more K slices than the full one); conv_launch also clamps its slice count to the slab.
+    {
+        size_t need = 0;
+        auto upd = [&](const ConvLayer& L, size_t M) { need = std::max(need, conv_plan(L, (int)M).partial_elems); };
+        for (size_t f = 1; f <= S; ++f) {
+            upd(c->first, f * HW);
+            for (int i = 0; i < c->nd; ++i) upd(c->down[i], f * (HW >> (2 * i)));
+        }
+        for (size_t f = 1; f <= F; ++f) {
+            for (int i = 0; i < c->nb; ++i) {
+                upd(c->hg_enc[i], f * (hw >> (2 * i)));
+                upd(c->hg_dec[i], f * (hw >> (2 * (c->nb - 1 - i))));
+            }
+            upd(c->head, f * hw);
+            upd(c->res1[0], f * hwf);
+            for (int i = 0; i < c->nd; ++i) upd(c->up[i], f * (hwf << (2 * (i + 1))));
+            upd(c->final_conv, f * HW);
+        }
+        c->partial_elems = need;
+        if ((rc = dev_alloc(c, &c->partial, c->partial_elems))) return rc;
+    }
+
+    // ---- algorithmic FLOPs (reference layer shapes, real channel counts)
+    {
+        double fe = conv_flops(7, 3, c->down_c[0], (double)HW);
+        for (int i = 0; i < c->nd; ++i) fe += conv_flops(3, c->down_c[i], c->down_c[i + 1], (double)(HW >> (2 * i)));
+        c->flops_encode = fe;
+        double ff = 0;
+        for (int i = 0; i < c->nb; ++i) {
+            ff += conv_flops(3, i == 0 ? cin0 : c->enc_c[i - 1], c->enc_c[i], (double)(hw >> (2 * i)));
+            const int ci = c->hg_dec[i].C0 + c->hg_dec[i].C1;
+            ff += conv_flops(3, ci, c->dec_c[i], (double)(hw >> (2 * (c->nb - 1 - i))));
+        }
+        ff += conv_flops(7, c->dec_c.back() + cin0, c->K + 1 + (g.estimate_occlusion_map ? 1 : 0), (double)hw);
+        ff += 2.0 * nr * conv_flops(3, c->Cb, c->Cb, (double)hwf);
+        for (int i = 0; i < c->nd; ++i)
+            ff += conv_flops(3, i == 0 ? c->Cb : c->up_c[i - 1], c->up_c[i], (double)(hwf << (2 * (i + 1))));
+        ff += conv_flops(7, c->up_c.back(), 3, (double)HW);
+        ff += 9.0 * hwf * c->Cb;  // bilinear feature warp + occlusion multiply
+        c->flops_frame = ff;
+    }
+    c->sd.clear();
+    HIP_TRY(c, hipDeviceSynchronize());
+    c->finalized = true;
+    return EAMM_OK;
+}
+
+int eamm_encode_source(eamm_ctx* c, const float* source, int ns, void* stream_) {
+    if (!c || !source) return fail(c, EAMM_ERR_ARG, "null argument");
+    if (!c->finalized) return fail(c, EAMM_ERR_STATE, "call eamm_finalize_weights first");
+    if (ns < 1 || ns > c->cfg.max_sources) return fail(c, EAMM_ERR_ARG, "ns=%d outside [1,%d]", ns, c->cfg.max_sources);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    const size_t HW = (size_t)c->H * c->W;
+    HIP_TRY(c, hipMemcpyAsync(c->src_full, source, (size_t)ns * 3 * HW * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, source_prepare_launch(source, c->aa_w, ns, c->H, c->W, c->cfg.dm_inv_scale, c->Csrc, c->src_nhwc,
+                                     c->src_small, s));
+    ConvIO io{};
+    io.in0 = c->src_nhwc;
+    io.B = ns;
+    io.Hin = c->H;
+    io.Win = c->W;
+    io.act = ACT_RELU;
+    io.out = c->enc_tmp[0];
+    io.partial = c->partial;
+        io.partial_cap = c->partial_elems;
+    HIP_TRY(c, conv_launch(c->first, io, s));                     // SameBlock2d 7x7   generator.py:61
+    for (int i = 0; i < c->nd; ++i) {                             // DownBlock2d       generator.py:62-63
+        ConvIO d{};
+        d.in0 = c->enc_tmp[i];
+        d.B = ns;
+        d.Hin = c->H >> i;
+        d.Win = c->W >> i;
+        d.act = ACT_RELU;
+        d.pool = 1;
+        d.out = (i == c->nd - 1) ? c->feat : c->enc_tmp[i + 1];
+        d.partial = c->partial;
+        d.partial_cap = c->partial_elems;
+        HIP_TRY(c, conv_launch(c->down[i], d, s));
+    }
+    c->ns_cached = ns;
+    return EAMM_OK;
+}
+
+int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd_jac, const float* ks_val,
+                        const float* ks_jac, const eamm_outputs* o, void* stream_) {
+    if (!c || !kd_val || !ks_val || !o || !o->prediction) return fail(c, EAMM_ERR_ARG, "null argument");
+    if (!c->finalized) return fail(c, EAMM_ERR_STATE, "call eamm_finalize_weights first");
+    if (c->ns_cached < 1) return fail(c, EAMM_ERR_STATE, "no source cached: call eamm_encode_source first");
+    if (n < 1 || n > c->cfg.max_frames) return fail(c, EAMM_ERR_ARG, "n=%d outside [1,%d]", n, c->cfg.max_frames);
+    if (kd_jac != nullptr && ks_jac == nullptr)
+        return fail(c, EAMM_ERR_ARG, "kp_driving jacobian given without kp_source jacobian");
+    const int ns = c->ns_cached;
+    if (ns != 1 && ns != n) return fail(c, EAMM_ERR_ARG, "%d cached sources cannot serve %d frames (need 1 or n)", ns, n);
+    if ((o->occlusion_map) && !c->cfg.estimate_occlusion_map)
+        return fail(c, EAMM_ERR_ARG, "occlusion_map requested but estimate_occlusion_map is off");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    const int h = c->h, w = c->w, hf = c->hf, wf = c->wf, K = c->K;
+    const bool occ = c->cfg.estimate_occlusion_map != 0;
+
+    hipEvent_t* ev = nullptr;  // stage boundaries, recorded only while profiling
+    if (c->profiling && c->prof_used < eamm_ctx::PROF_CALLS) {
+        ev = c->prof_events.data() + (size_t)c->prof_used * (eamm_ctx::NSTAGE + 1);
+        c->prof_n.push_back(n);
+        ++c->prof_used;
+    }
+#define STAGE_MARK(i)                                  \
+    do {                                               \
+        if (ev) HIP_TRY(c, hipEventRecord(ev[i], s)); \
+    } while (0)
+    STAGE_MARK(0);
+    // key-point records; 'jacobian' missing from kp_driving => identity (dense_motion.py:55)
+    HIP_TRY(c, kp_prepare_launch(kd_val, kd_jac, ks_val, kd_jac ? ks_jac : nullptr, n, ns, K, c->kp_rec, c->bad_flag, s));
+    // heat-maps + sparse motions + K+1 warped sources -> hourglass input     dense_motion.py:88-94
+    HIP_TRY(c, motion_front_launch(c->kp_rec, c->src_small, n, ns, K, h, w, c->cfg.kp_variance, c->Cp0, c->hg_in,
+                                   o->sparse_deformed, s));
+    STAGE_MARK(1);
+    // hourglass encoder                                                       util.py:956-960
+    for (int i = 0; i < c->nb; ++i) {
+        ConvIO io{};
+        io.in0 = i == 0 ? c->hg_in : c->e_buf[i - 1];
+        io.B = n;
+        io.Hin = h >> i;
+        io.Win = w >> i;
+        io.act = ACT_RELU;
+        io.pool = 1;
+        io.out = c->e_buf[i];
+        io.partial = c->partial;
+        io.partial_cap = c->partial_elems;
+        HIP_TRY(c, conv_launch(c->hg_enc[i], io, s));
+    }
+    STAGE_MARK(2);
+    // hourglass decoder: nearest x2 and the skip concatenation are folded into the operand loader
+    for (int i = 0; i < c->nb; ++i) {
+        ConvIO io{};
+        io.in0 = i == 0 ? c->e_buf[c->nb - 1] : c->u_buf[i - 1];
+        io.in1 = i == 0 ? nullptr : c->e_buf[c->nb - 1 - i];
+        io.B = n;
+        io.Hin = h >> (c->nb - i);
+        io.Win = w >> (c->nb - i);
+        io.up = 1;
+        io.act = ACT_RELU;
+        io.out = c->u_buf[i];
+        io.partial = c->partial;
+        io.partial_cap = c->partial_elems;
+        HIP_TRY(c, conv_launch(c->hg_dec[i], io, s));
+    }
+    STAGE_MARK(3);
+    // mask / occlusion logits, then softmax + flow combine + sigmoid         dense_motion.py:98-111
+    {
+        ConvIO io{};
+        io.in0 = c->u_buf[c->nb - 1];
+        io.in1 = c->hg_in;
+        io.B = n;
+        io.Hin = h;
+        io.Win = w;
+        io.act = ACT_NONE;
+        io.out = c->logits;
+        io.partial = c->partial;
+        io.partial_cap = c->partial_elems;
+        ConvLayer head = c->head;
+        head.Cout = 32;  // logits are written with a 32-float pixel stride; channels >= K+2 have zero weights
+        HIP_TRY(c, conv_launch(head, io, s));
+        float* defo = c->deformation;
+        HIP_TRY(c, motion_head_launch(c->logits, c->kp_rec, n, K, h, w, occ ? 1 : 0, defo, c->occlusion, o->mask,
+                                      o->occlusion_map, s));
+        if (o->deformation)
+            HIP_TRY(c, hipMemcpyAsync(o->deformation, defo, (size_t)n * h * w * 2 * sizeof(float),
+                                      hipMemcpyDeviceToDevice, s));
+    }
+    STAGE_MARK(4);
+    // feature warp x occlusion (+ r0's pre-activation)                         generator.py:79-84
+    HIP_TRY(c, warp_features_launch(c->feat, c->deformation, occ ? c->occlusion : nullptr, n, ns, hf, wf, c->Cb, h, w,
+                                    c->xa, c->act, c->pre_s[0], c->pre_t[0], s));
+    if (o->deformed)                                                         // generator.py:86
+        HIP_TRY(c, warp_image_launch(c->src_full, c->deformation, n, ns, c->H, c->W, h, w, o->deformed, s));
+    STAGE_MARK(5);
+    // bottleneck                                                               generator.py:89
+    const int nr = c->cfg.num_bottleneck_blocks;
+    float *x = c->xa, *xn = c->xb;
+    for (int i = 0; i < nr; ++i) {
+        ConvIO a{};
+        a.in0 = c->act;
+        a.B = n;
+        a.Hin = hf;
+        a.Win = wf;
+        a.act = ACT_RELU;  // conv1 -> norm2 (folded) -> relu
+        a.out = c->tmp;
+        a.partial = c->partial;
+        a.partial_cap = c->partial_elems;
+        HIP_TRY(c, conv_launch(c->res1[i], a, s));
+        ConvIO b{};
+        b.in0 = c->tmp;
+        b.B = n;
+        b.Hin = hf;
+        b.Win = wf;
+        b.act = ACT_NONE;
+        b.resid = x;       // out += x
+        b.out = xn;
+        if (i + 1 < nr) {  // next block's relu(norm1(.))
+            b.out2 = c->act;
+            b.s2 = c->pre_s[i + 1];
+            b.t2 = c->pre_t[i + 1];
+        }
+        b.partial = c->partial;
+        b.partial_cap = c->partial_elems;
+        HIP_TRY(c, conv_launch(c->res2[i], b, s));
+        std::swap(x, xn);
+    }
+    STAGE_MARK(6);
+    // up blocks                                                                generator.py:90-91
+    const float* cur = x;
+    for (int i = 0; i < c->nd; ++i) {
+        ConvIO io{};
+        io.in0 = cur;
+        io.B = n;
+        io.Hin = hf << i;
+        io.Win = wf << i;
+        io.up = 1;
+        io.act = ACT_RELU;
+        io.out = c->up_buf[i];
+        io.partial = c->partial;
+        io.partial_cap = c->partial_elems;
+        HIP_TRY(c, conv_launch(c->up[i], io, s));
+        cur = c->up_buf[i];
+    }
+    STAGE_MARK(7);
+    // final 7x7 + sigmoid, written NCHW straight into the caller's buffer      generator.py:92-93
+    {
+        ConvIO io{};
+        io.in0 = cur;
+        io.B = n;
+        io.Hin = c->H;
+        io.Win = c->W;
+        io.act = ACT_SIGMOID;
+        io.nchw = 1;
+        io.out = o->prediction;
+        io.partial = c->partial;
+        io.partial_cap = c->partial_elems;
+        HIP_TRY(c, conv_launch(c->final_conv, io, s));
+    }
+    if (o->frames_u8) HIP_TRY(c, to_u8_launch(o->prediction, n, c->H, c->W, o->frames_u8, s));
+    STAGE_MARK(8);
+#undef STAGE_MARK
+    return EAMM_OK;
+}
+
+int eamm_profile_enable(eamm_ctx* c, int on) {
+    if (!c) return EAMM_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (on && c->prof_events.empty()) {
+        c->prof_events.resize((size_t)eamm_ctx::PROF_CALLS * (eamm_ctx::NSTAGE + 1));
+        for (auto& e : c->prof_events) HIP_TRY(c, hipEventCreate(&e));
+    }
+    c->profiling = on != 0;
+    return EAMM_OK;
+}
+
+int eamm_profile_read(eamm_ctx* c, double* stage_ms, int nstage, int64_t* calls, int64_t* frames, int reset) {
+    if (!c || !stage_ms || nstage != eamm_ctx::NSTAGE) return fail(c, EAMM_ERR_ARG, "nstage must be %d", eamm_ctx::NSTAGE);
+    for (int k = 0; k < c->prof_used; ++k) {  // fold finished event sets into the totals
+        hipEvent_t* ev = c->prof_events.data() + (size_t)k * (eamm_ctx::NSTAGE + 1);
+        HIP_TRY(c, hipEventSynchronize(ev[eamm_ctx::NSTAGE]));
+        for (int i = 0; i < eamm_ctx::NSTAGE; ++i) {
+            float ms = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            c->prof_ms[i] += ms;
+        }
+        c->prof_calls += 1;
+        c->prof_frames += c->prof_n[k];
+    }
+    c->prof_used = 0;
+    c->prof_n.clear();
+    for (int i = 0; i < nstage; ++i) stage_ms[i] = c->prof_ms[i];
+    if (calls) *calls = c->prof_calls;
+    if (frames) *frames = c->prof_frames;
+    if (reset) {
+        for (double& v : c->prof_ms) v = 0;
+        c->prof_calls = c->prof_frames = 0;
+    }
+    return EAMM_OK;
+}
+
+int eamm_check_numeric(eamm_ctx* c, void* stream_) {
+    if (!c) return EAMM_ERR_ARG;
+    int flag = 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(c, hipMemcpyAsync(&flag, c->bad_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (flag) {
+        HIP_TRY(c, hipMemsetAsync(c->bad_flag, 0, sizeof(int), s));
+        return fail(c, EAMM_ERR_NUMERIC, "singular key-point jacobian (torch.inverse would raise, dense_motion.py:56)");
+    }
+    return EAMM_OK;
+}
+
+size_t eamm_source_cache_bytes(const eamm_ctx* c, int ns) {
+    if (!c) return 0;
+    const size_t per = (size_t)c->hf * c->wf * c->Cb + (size_t)c->h * c->w * 4 + (size_t)3 * c->H * c->W;
+    return per * (size_t)ns * sizeof(float);
+}
+
+int eamm_export_source_cache(eamm_ctx* c, void* dst, int ns, void* stream_) {
+    if (!c || !dst) return fail(c, EAMM_ERR_ARG, "null argument");
+    if (ns < 1 || ns > c->ns_cached) return fail(c, EAMM_ERR_STATE, "only %d sources are cached", c->ns_cached);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    const size_t a = (size_t)ns * c->hf * c->wf * c->Cb, b = (size_t)ns * c->h * c->w * 4, d = (size_t)ns * 3 * c->H * c->W;
+    float* p = reinterpret_cast<float*>(dst);
+    HIP_TRY(c, hipMemcpyAsync(p, c->feat, a * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(p + a, c->src_small, b * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(p + a + b, c->src_full, d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return EAMM_OK;
+}
+
+int eamm_import_source_cache(eamm_ctx* c, const void* src, int ns, void* stream_) {
+    if (!c || !src) return fail(c, EAMM_ERR_ARG, "null argument");
+    if (!c->finalized) return fail(c, EAMM_ERR_STATE, "call eamm_finalize_weights first");
+    if (ns < 1 || ns > c->cfg.max_sources) return fail(c, EAMM_ERR_ARG, "ns=%d outside [1,%d]", ns, c->cfg.max_sources);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    const size_t a = (size_t)ns * c->hf * c->wf * c->Cb, b = (size_t)ns * c->h * c->w * 4, d = (size_t)ns * 3 * c->H * c->W;
+    const float* p = reinterpret_cast<const float*>(src);
+    HIP_TRY(c, hipMemcpyAsync(c->feat, p, a * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->src_small, p + a, b * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->src_full, p + a + b, d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    c->ns_cached = ns;
+    return EAMM_OK;
+}
+
+double eamm_flops_per_frame(const eamm_ctx* c) { return c ? c->flops_frame : 0.0; }
+double eamm_encode_flops(const eamm_ctx* c) { return c ? c->flops_encode : 0.0; }
+
+int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int up,
+                 const float* w_host, const float* b_host, int Cout, int ks, int act, int pool, const float* resid,
+                 int splitk, int tile_n, float* out, int iters, float* avg_ms, void* stream_) {
+    if (!in0 || !w_host || !b_host || !out || (ks != 3 && ks != 7) || C0 % CONV_BK || C1 % CONV_BK)
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: bad argument");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    ConvLayer L;
+    L.ks = ks;
+    L.C0 = C0;
+    L.C1 = C1;
+    L.Cout = Cout;
+    L.BN = tile_n > 0 ? tile_n : conv_tile_n(Cout);
+    if (L.BN != 32 && L.BN != 64 && L.BN != 128) return fail(nullptr, EAMM_ERR_ARG, "tile_n must be 32/64/128");
+    L.ntiles = (Cout + L.BN - 1) / L.BN;
+    L.nchunks = ks * ks * ((C0 + C1) / CONV_BK);
+    std::vector<float> packed(conv_packed_elems(ks, C0 + C1, Cout, L.BN));
+    conv_pack_host(w_host, Cout, C0 + C1, ks, nullptr, C0 + C1, L.BN, packed.data());
+    std::vector<float> bias((size_t)L.ntiles * L.BN, 0.f);
+    std::copy(b_host, b_host + Cout, bias.begin());
+    int rc = EAMM_OK;
+    float* partial = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(s);
+        if (L.w) (void)hipFree(L.w);
+        if (L.bias) (void)hipFree(L.bias);
+        if (partial) (void)hipFree(partial);
+    };
+#define OP_TRY(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            rc = fail(nullptr, EAMM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));      \
+            cleanup();                                                                            \
+            return rc;                                                                            \
+        }                                                                                         \
+    } while (0)
+    OP_TRY(hipMalloc((void**)&L.w, packed.size() * sizeof(float)));
+    OP_TRY(hipMalloc((void**)&L.bias, bias.size() * sizeof(float)));
+    OP_TRY(hipMemcpy(L.w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    OP_TRY(hipMemcpy(L.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    const int M = B * (Hin << up) * (Win << up);
+    const ConvPlan pl = conv_plan(L, M, splitk);
+    if (pl.partial_elems) OP_TRY(hipMalloc((void**)&partial, pl.partial_elems * sizeof(float)));
+    ConvIO io{};
+    io.in0 = in0;
+    io.in1 = C1 ? in1 : nullptr;
+    io.B = B;
+    io.Hin = Hin;
+    io.Win = Win;
+    io.up = up;
+    io.act = act;
+    io.pool = pool;
+    io.resid = resid;
+    io.out = out;
+    io.partial = partial;
+    io.partial_cap = pl.partial_elems;
+    OP_TRY(conv_launch(L, io, s, splitk));
+    if (iters > 0 && avg_ms) {  // kernel timing: `iters` back-to-back launches between two HIP events on `s`
+        hipEvent_t e0, e1;
+        OP_TRY(hipEventCreate(&e0));
+        OP_TRY(hipEventCreate(&e1));
+        OP_TRY(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) OP_TRY(conv_launch(L, io, s, splitk));
+        OP_TRY(hipEventRecord(e1, s));
+        OP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        OP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *avg_ms = ms / iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    cleanup();
+#undef OP_TRY
+    return EAMM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// Internal (non-ABI) declarations shared by the HIP translation units of libeamm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace eamm {
+
+constexpr int CONV_BK = 32;           // K-chunk: 32 input channels of one filter tap
+constexpr int CONV_LDK = CONV_BK + 4; // LDS row stride (dwords): +16 B keeps ds_read_b128 conflict-free
+constexpr int KP_STRIDE = 8;          // per (frame, keypoint) record: kd.xy, ks.xy, J00 J01 J10 J11
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+
+// One convolution launch. Activations are NHWC fp32; the GEMM view is
+//   M = B*H*W output pixels (2x2-quad order), N = Cout, K = taps * (C0 + C1).
+struct ConvArgs {
+    const float* in0;      // [B,Hin,Win,C0]
+    const float* in1;      // [B,Hin,Win,C1] second half of a channel concatenation, or null
+    int C0, C1;            // multiples of CONV_BK
+    unsigned in0_bytes, in1_bytes, w_bytes;  // buffer-descriptor ranges
+    int Hin, Win;          // stored input size
+    int up;                // 1: convolve the nearest-x2 up-sampled input (H = 2*Hin)
+    int H, W;              // convolution-space size (even)
+    int M;                 // B*H*W
+    const float* w;        // packed [ntiles][nchunks][BN][BK], BatchNorm already folded in
+    const float* bias;     // [ntiles*BN]
+    int Cout;              // real output channels (= output stride)
+    int nchunks;           // taps * (C0+C1)/BK
+    int mtiles, ntiles;
+    int chunks_per_split;  // K range of one split-K slice
+    int Mpad, Npad;        // partial slab dims
+    float* partial;        // non-null: split-K, raw accumulators to [split][Mpad][Npad]
+    int act;               // Act
+    int pool;              // avgpool2x2 after the activation
+    int nchw;              // write out as [B,Cout,H,W] (final image) instead of NHWC
+    const float* resid;    // NHWC, added before the activation
+    float* out;            // NHWC [B,H,W,Cout] (or pooled [B,H/2,W/2,Cout])
+    float* out2;           // optional second output relu(out*s2 + t2): the next res-block's pre-activation
+    const float* s2;
+    const float* t2;
+};
+
+// Packed convolution weights resident on the device.
+struct ConvLayer {
+    int ks = 0, C0 = 0, C1 = 0, Cout = 0;
+    int BN = 0, ntiles = 0, nchunks = 0;
+    float* w = nullptr;     // device
+    float* bias = nullptr;  // device, [ntiles*BN]
+    double flops_per_pixel() const { return 2.0 * ks * ks * (double)(C0 + C1) * Cout; }
+};
+
+int conv_tile_n(int Cout);
+size_t conv_packed_elems(int ks, int cin_packed, int Cout, int BN);
+// Host-side repack: OIHW (BatchNorm folded by the caller) -> [ntiles][nchunks][BN][BK].
+// cin_map[c] = original input channel of packed channel c, or -1 for zero padding.
+void conv_pack_host(const float* w_oihw, int Cout, int Cin, int ks, const int* cin_map, int cin_packed,
+                    int BN, float* dst);
+
+struct ConvPlan {           // launch geometry of one layer at one problem size
+    int mtiles, ntiles, splits, chunks_per_split, Mpad, Npad;
+    size_t partial_elems;   // 0 when splits == 1
+};
+ConvPlan conv_plan(const ConvLayer& L, int M, int force_splits = 0);
+
+struct ConvIO {
+    const float* in0; const float* in1;
+    int B, Hin, Win, up;
+    int act, pool, nchw;
+    const float* resid;
+    float* out; float* out2; const float* s2; const float* t2;
+    float* partial;         // split-K workspace
+    size_t partial_cap;     // its capacity in floats (the slice count is clamped to fit)
+};
+hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream, int force_splits = 0);
+
+// ---- motion / warp / image kernels (motion.hip) ---------------------------------------------
+hipError_t kp_prepare_launch(const float* kd_val, const float* kd_jac, const float* ks_val, const float* ks_jac,
+                             int n, int ns, int K, float* kp_rec, int* bad_flag, hipStream_t s);
+hipError_t motion_front_launch(const float* kp_rec, const float* src_small /*[ns,h,w,4]*/, int n, int ns, int K,
+                               int h, int w, float variance, int Cpad, float* hg_in /*[n,h,w,Cpad]*/,
+                               float* sparse_deformed /*[n,K+1,3,h,w] or null*/, hipStream_t s);
+hipError_t motion_head_launch(const float* logits /*[n,h,w,32]*/, const float* kp_rec, int n, int K, int h, int w,
+                              int has_occ, float* deformation /*[n,h,w,2]*/, float* occlusion /*[n,h,w]*/,
+                              float* mask_out /*[n,K+1,h,w] or null*/, float* occ_out /*[n,1,h,w] or null*/,
+                              hipStream_t s);
+hipError_t warp_features_launch(const float* feat /*[ns,hf,wf,C]*/, const float* deformation /*[n,h,w,2]*/,
+                                const float* occlusion /*[n,h,w] or null*/, int n, int ns, int hf, int wf, int C,
+                                int h, int w, float* out, float* out2, const float* s2, const float* t2,
+                                hipStream_t s);
+hipError_t warp_image_launch(const float* src /*[ns,3,H,W]*/, const float* deformation /*[n,h,w,2]*/, int n, int ns,
+                             int H, int W, int h, int w, float* out /*[n,3,H,W]*/, hipStream_t s);
+hipError_t source_prepare_launch(const float* src /*[ns,3,H,W]*/, const float* aa_w /*[3,13,13] dev*/, int ns, int H,
+                                 int W, int inv_scale, int Cpad, float* src_nhwc /*[ns,H,W,Cpad]*/,
+                                 float* src_small /*[ns,h,w,4]*/, hipStream_t s);
+hipError_t to_u8_launch(const float* pred /*[n,3,H,W]*/, int n, int H, int W, uint8_t* out /*[n,H,W,3]*/,
+                        hipStream_t s);
+
+}  // namespace eamm

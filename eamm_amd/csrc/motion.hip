@@ -1,0 +1,470 @@
+// HBM-bound kernels of the dense-motion path: key-point records, heat-map / sparse-motion /
+// warped-source front end, softmax-over-motions flow head, flow-gathered feature warp, and the
+// once-per-clip source preparation.  One thread per output element group, NHWC / float4 accesses.
+//
+// Semantics follow SURVEY.md Appendix A; each kernel cites the reference lines it replaces.
+#include "kernels.h"
+
+#include <algorithm>
+
+namespace eamm {
+
+// x = 2*(j/(n-1)) - 1, as make_coordinate_grid builds it (reference modules/util.py:844-848).
+__device__ __forceinline__ float grid_coord(int j, int n) { return 2.f * ((float)j / (float)(n - 1)) - 1.f; }
+
+// T_k(z) = J_k (z - kp_d) + kp_s (reference modules/dense_motion.py:53-63); rec = kd.xy ks.xy J00 J01 J10 J11.
+__device__ __forceinline__ void sparse_motion(const float* __restrict__ rec, float gx, float gy, float& tx,
+                                              float& ty) {
+    const float rx = gx - rec[0], ry = gy - rec[1];
+    tx = fmaf(rec[5], ry, rec[4] * rx) + rec[2];
+    ty = fmaf(rec[7], ry, rec[6] * rx) + rec[3];
+}
+
+// F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False) coordinates and weights.
+struct Bilinear {
+    int x0, y0;
+    float wnw, wne, wsw, wse;
+};
+__device__ __forceinline__ Bilinear bilinear_setup(float gx, float gy, int W, int H) {
+    const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+    const float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    Bilinear b;
+    // clamp before the int conversion so that wild coordinates stay out of range instead of wrapping
+    b.x0 = (int)fminf(fmaxf(fx, -2.f), (float)W);
+    b.y0 = (int)fminf(fmaxf(fy, -2.f), (float)H);
+    const float ax = ix - fx, ay = iy - fy;  // weight of the +1 corner
+    b.wnw = (1.f - ax) * (1.f - ay);
+    b.wne = ax * (1.f - ay);
+    b.wsw = (1.f - ax) * ay;
+    b.wse = ax * ay;
+    if (!(ix > -2.f && ix < (float)W + 1.f && iy > -2.f && iy < (float)H + 1.f)) {  // also catches NaN
+        b.wnw = b.wne = b.wsw = b.wse = 0.f;
+        b.x0 = b.y0 = -2;
+    }
+    return b;
+}
+
+// F.interpolate(mode='bilinear', align_corners=False) source position (reference generator.py:55,83).
+struct Lerp {
+    int i0, i1;
+    float l1;
+};
+__device__ __forceinline__ Lerp lerp_setup(int dst, int in, int out) {
+    const float scale = (float)in / (float)out;
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = fmaxf(s, 0.f);
+    Lerp l;
+    l.i0 = (int)s;
+    l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+    l.l1 = s - (float)l.i0;
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// key-point records: J_k = J_source,k * inverse(J_driving,k)  (dense_motion.py:55-56)
+// ---------------------------------------------------------------------------------------------
+__global__ void kp_prepare_kernel(const float* __restrict__ kd_val, const float* __restrict__ kd_jac,
+                                  const float* __restrict__ ks_val, const float* __restrict__ ks_jac, int n, int ns,
+                                  int K, float* __restrict__ rec, int* __restrict__ bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * K) return;
+    const int f = i / K, k = i - f * K;
+    const int sf = (ns == 1) ? 0 : f;
+    float* r = rec + (size_t)i * KP_STRIDE;
+    r[0] = kd_val[i * 2 + 0];
+    r[1] = kd_val[i * 2 + 1];
+    r[2] = ks_val[(sf * K + k) * 2 + 0];
+    r[3] = ks_val[(sf * K + k) * 2 + 1];
+    float j00 = 1.f, j01 = 0.f, j10 = 0.f, j11 = 1.f;
+    if (kd_jac != nullptr) {
+        const float* d = kd_jac + (size_t)i * 4;
+        const float* s = ks_jac + (size_t)(sf * K + k) * 4;
+        const float det = d[0] * d[3] - d[1] * d[2];
+        if (!(fabsf(det) > 0.f) || !isfinite(det)) atomicExch(bad, 1);  // torch.inverse raises here
+        const float inv = 1.f / det;
+        const float i00 = d[3] * inv, i01 = -d[1] * inv, i10 = -d[2] * inv, i11 = d[0] * inv;
+        j00 = fmaf(s[1], i10, s[0] * i00);
+        j01 = fmaf(s[1], i11, s[0] * i01);
+        j10 = fmaf(s[3], i10, s[2] * i00);
+        j11 = fmaf(s[3], i11, s[2] * i01);
+    }
+    r[4] = j00;
+    r[5] = j01;
+    r[6] = j10;
+    r[7] = j11;
+}
+
+// ---------------------------------------------------------------------------------------------
+// front end: heat-maps (dense_motion.py:32-45, util.py:815-836), sparse motions (:47-67) and the K+1
+// bilinear warps of the down-sampled source (:69-79), written straight into the hourglass input
+// layout: channel 4k = heat_k, 4k+1..3 = RGB warped by T_k (:93-94), zero-padded to Cpad channels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void motion_front_kernel(const float* __restrict__ rec_all,
+                                                           const float4* __restrict__ src_small, int ns, int K, int h,
+                                                           int w, float variance, int Cpad,
+                                                           float* __restrict__ hg_in,
+                                                           float* __restrict__ sparse_deformed) {
+    const int f = blockIdx.y;
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= h * w) return;
+    const int y = pi / w, x = pi - y * w;
+    const float gx = grid_coord(x, w), gy = grid_coord(y, h);
+    const float4* src = src_small + (size_t)((ns == 1) ? 0 : f) * h * w;
+    const float* rec = rec_all + (size_t)f * K * KP_STRIDE;
+    float4* dst = reinterpret_cast<float4*>(hg_in + ((size_t)f * h * w + pi) * Cpad);
+    const size_t plane = (size_t)h * w;
+    float* sd = sparse_deformed ? sparse_deformed + (size_t)f * (K + 1) * 3 * plane + pi : nullptr;
+    for (int k = 0; k <= K; ++k) {
+        float tx = gx, ty = gy, heat = 0.f;
+        if (k > 0) {
+            const float* r = rec + (k - 1) * KP_STRIDE;
+            sparse_motion(r, gx, gy, tx, ty);
+            const float dx = gx - r[0], dy = gy - r[1];
+            const float sx = gx - r[2], sy = gy - r[3];
+            heat = expf(-0.5f * (dx * dx + dy * dy) / variance) - expf(-0.5f * (sx * sx + sy * sy) / variance);
+        }
+        const Bilinear b = bilinear_setup(tx, ty, w, h);
+        float r_ = 0.f, g_ = 0.f, b_ = 0.f;
+        const bool x0ok = (unsigned)b.x0 < (unsigned)w, x1ok = (unsigned)(b.x0 + 1) < (unsigned)w;
+        const bool y0ok = (unsigned)b.y0 < (unsigned)h, y1ok = (unsigned)(b.y0 + 1) < (unsigned)h;
+        if (y0ok && x0ok) {
+            const float4 v = src[b.y0 * w + b.x0];
+            r_ = fmaf(v.x, b.wnw, r_); g_ = fmaf(v.y, b.wnw, g_); b_ = fmaf(v.z, b.wnw, b_);
+        }
+        if (y0ok && x1ok) {
+            const float4 v = src[b.y0 * w + b.x0 + 1];
+            r_ = fmaf(v.x, b.wne, r_); g_ = fmaf(v.y, b.wne, g_); b_ = fmaf(v.z, b.wne, b_);
+        }
+        if (y1ok && x0ok) {
+            const float4 v = src[(b.y0 + 1) * w + b.x0];
+            r_ = fmaf(v.x, b.wsw, r_); g_ = fmaf(v.y, b.wsw, g_); b_ = fmaf(v.z, b.wsw, b_);
+        }
+        if (y1ok && x1ok) {
+            const float4 v = src[(b.y0 + 1) * w + b.x0 + 1];
+            r_ = fmaf(v.x, b.wse, r_); g_ = fmaf(v.y, b.wse, g_); b_ = fmaf(v.z, b.wse, b_);
+        }
+        dst[k] = make_float4(heat, r_, g_, b_);
+        if (sd) {
+            sd[(size_t)(k * 3 + 0) * plane] = r_;
+            sd[(size_t)(k * 3 + 1) * plane] = g_;
+            sd[(size_t)(k * 3 + 2) * plane] = b_;
+        }
+    }
+    for (int c4 = K + 1; c4 < Cpad / 4; ++c4) dst[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// head: mask = softmax over the K+1 motion logits, deformation = sum_k mask_k * T_k, occlusion =
+// sigmoid(logit K+1)  (dense_motion.py:98-111).  logits come from the 7x7 MFMA convolution as
+// [n,h,w,32] (channels 0..K mask, K+1 occlusion, rest padding).
+// ---------------------------------------------------------------------------------------------
+constexpr int HEAD_MAXK = 31;
+__global__ __launch_bounds__(256) void motion_head_kernel(const float* __restrict__ logits,
+                                                          const float* __restrict__ rec_all, int K, int h, int w,
+                                                          int has_occ, float* __restrict__ deformation,
+                                                          float* __restrict__ occlusion, float* __restrict__ mask_out,
+                                                          float* __restrict__ occ_out) {
+    const int f = blockIdx.y;
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= h * w) return;
+    const int y = pi / w, x = pi - y * w;
+    const float gx = grid_coord(x, w), gy = grid_coord(y, h);
+    const float* rec = rec_all + (size_t)f * K * KP_STRIDE;
+    const float4* lg4 = reinterpret_cast<const float4*>(logits + ((size_t)f * h * w + pi) * 32);
+    float l[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 v = lg4[i];
+        l[4 * i + 0] = v.x; l[4 * i + 1] = v.y; l[4 * i + 2] = v.z; l[4 * i + 3] = v.w;
+    }
+    float mx = l[0];
+#pragma unroll
+    for (int k = 1; k < 32; ++k)
+        if (k <= K) mx = fmaxf(mx, l[k]);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+        if (k <= K) {
+            l[k] = expf(l[k] - mx);
+            sum += l[k];
+        }
+    float dx = 0.f, dy = 0.f;
+    const size_t plane = (size_t)h * w;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+        if (k <= K) {
+            const float mk = l[k] / sum;
+            float tx = gx, ty = gy;
+            if (k > 0) sparse_motion(rec + (k - 1) * KP_STRIDE, gx, gy, tx, ty);
+            dx = fmaf(mk, tx, dx);
+            dy = fmaf(mk, ty, dy);
+            if (mask_out) mask_out[((size_t)f * (K + 1) + k) * plane + pi] = mk;
+        }
+    reinterpret_cast<float2*>(deformation)[(size_t)f * plane + pi] = make_float2(dx, dy);
+    if (has_occ) {
+        float ov = 0.f;
+#pragma unroll
+        for (int k = 1; k < 32; ++k)
+            if (k == K + 1) ov = l[k];
+        const float o = 1.f / (1.f + expf(-ov));
+        occlusion[(size_t)f * plane + pi] = o;
+        if (occ_out) occ_out[(size_t)f * plane + pi] = o;
+    }
+}
+
+// flow / occlusion at feature-map pixel (y,x): direct read when the motion grid matches the feature
+// map, else the reference's bilinear resize (generator.py:52-56, 82-83).
+__device__ __forceinline__ void flow_at(const float2* __restrict__ defo, const float* __restrict__ occ, int h,
+                                        int w, int H, int W, int y, int x, float& gx, float& gy, float& o) {
+    if (h == H && w == W) {
+        const float2 d = defo[y * w + x];
+        gx = d.x;
+        gy = d.y;
+        o = occ ? occ[y * w + x] : 1.f;
+        return;
+    }
+    const Lerp ly = lerp_setup(y, h, H), lx = lerp_setup(x, w, W);
+    const float2 d00 = defo[ly.i0 * w + lx.i0], d01 = defo[ly.i0 * w + lx.i1];
+    const float2 d10 = defo[ly.i1 * w + lx.i0], d11 = defo[ly.i1 * w + lx.i1];
+    const float wy1 = ly.l1, wy0 = 1.f - wy1, wx1 = lx.l1, wx0 = 1.f - wx1;
+    gx = wy0 * (wx0 * d00.x + wx1 * d01.x) + wy1 * (wx0 * d10.x + wx1 * d11.x);
+    gy = wy0 * (wx0 * d00.y + wx1 * d01.y) + wy1 * (wx0 * d10.y + wx1 * d11.y);
+    o = 1.f;
+    if (occ) {
+        o = wy0 * (wx0 * occ[ly.i0 * w + lx.i0] + wx1 * occ[ly.i0 * w + lx.i1]) +
+            wy1 * (wx0 * occ[ly.i1 * w + lx.i0] + wx1 * occ[ly.i1 * w + lx.i1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// feature warp: out = grid_sample(feat, deformation) * occlusion  (generator.py:50-57, 79-84), NHWC,
+// one thread per (pixel, 4 channels): a wave covers 256 contiguous channels of one pixel, so every
+// corner gather is a 1 KiB coalesced read.  Also emits the first res-block's pre-activation
+// relu(bn1(out)) (util.py:873-874) so that the bottleneck convolutions read ready operands.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_features_kernel(const float* __restrict__ feat,
+                                                            const float* __restrict__ deformation,
+                                                            const float* __restrict__ occlusion, int n, int ns,
+                                                            int hf, int wf, int C, int h, int w,
+                                                            float* __restrict__ out, float* __restrict__ out2,
+                                                            const float* __restrict__ s2,
+                                                            const float* __restrict__ t2) {
+    const int c4n = C >> 2;
+    const size_t total = (size_t)n * hf * wf * c4n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const size_t pix = idx / c4n;
+        const int x = (int)(pix % wf);
+        const int y = (int)((pix / wf) % hf);
+        const int f = (int)(pix / ((size_t)wf * hf));
+        float gx, gy, o;
+        flow_at(reinterpret_cast<const float2*>(deformation) + (size_t)f * h * w,
+                occlusion ? occlusion + (size_t)f * h * w : nullptr, h, w, hf, wf, y, x, gx, gy, o);
+        const Bilinear b = bilinear_setup(gx, gy, wf, hf);
+        const float4* src = reinterpret_cast<const float4*>(feat + (size_t)((ns == 1) ? 0 : f) * hf * wf * C) + c4;
+        const bool x0ok = (unsigned)b.x0 < (unsigned)wf, x1ok = (unsigned)(b.x0 + 1) < (unsigned)wf;
+        const bool y0ok = (unsigned)b.y0 < (unsigned)hf, y1ok = (unsigned)(b.y0 + 1) < (unsigned)hf;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y0ok && x0ok) {
+            const float4 v = src[(size_t)(b.y0 * wf + b.x0) * c4n];
+            acc.x = fmaf(v.x, b.wnw, acc.x); acc.y = fmaf(v.y, b.wnw, acc.y);
+            acc.z = fmaf(v.z, b.wnw, acc.z); acc.w = fmaf(v.w, b.wnw, acc.w);
+        }
+        if (y0ok && x1ok) {
+            const float4 v = src[(size_t)(b.y0 * wf + b.x0 + 1) * c4n];
+            acc.x = fmaf(v.x, b.wne, acc.x); acc.y = fmaf(v.y, b.wne, acc.y);
+            acc.z = fmaf(v.z, b.wne, acc.z); acc.w = fmaf(v.w, b.wne, acc.w);
+        }
+        if (y1ok && x0ok) {
+            const float4 v = src[(size_t)((b.y0 + 1) * wf + b.x0) * c4n];
+            acc.x = fmaf(v.x, b.wsw, acc.x); acc.y = fmaf(v.y, b.wsw, acc.y);
+            acc.z = fmaf(v.z, b.wsw, acc.z); acc.w = fmaf(v.w, b.wsw, acc.w);
+        }
+        if (y1ok && x1ok) {
+            const float4 v = src[(size_t)((b.y0 + 1) * wf + b.x0 + 1) * c4n];
+            acc.x = fmaf(v.x, b.wse, acc.x); acc.y = fmaf(v.y, b.wse, acc.y);
+            acc.z = fmaf(v.z, b.wse, acc.z); acc.w = fmaf(v.w, b.wse, acc.w);
+        }
+        acc.x *= o; acc.y *= o; acc.z *= o; acc.w *= o;
+        reinterpret_cast<float4*>(out)[idx] = acc;
+        if (out2) {
+            const float4 s = reinterpret_cast<const float4*>(s2)[c4];
+            const float4 t = reinterpret_cast<const float4*>(t2)[c4];
+            float4 a;
+            a.x = fmaxf(fmaf(acc.x, s.x, t.x), 0.f); a.y = fmaxf(fmaf(acc.y, s.y, t.y), 0.f);
+            a.z = fmaxf(fmaf(acc.z, s.z, t.z), 0.f);
+            a.w = fmaxf(fmaf(acc.w, s.w, t.w), 0.f);
+            reinterpret_cast<float4*>(out2)[idx] = a;
+        }
+    }
+}
+
+// 'deformed' side output: flow resized to the frame, grid_sample of the RGB source (generator.py:86).
+__global__ __launch_bounds__(256) void warp_image_kernel(const float* __restrict__ src,
+                                                         const float* __restrict__ deformation, int n, int ns, int H,
+                                                         int W, int h, int w, float* __restrict__ out) {
+    const size_t total = (size_t)n * H * W;
+    const size_t plane = (size_t)H * W;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const int y = (int)((idx / W) % H);
+        const int f = (int)(idx / plane);
+        float gx, gy, o;
+        flow_at(reinterpret_cast<const float2*>(deformation) + (size_t)f * h * w, nullptr, h, w, H, W, y, x, gx, gy,
+                o);
+        const Bilinear b = bilinear_setup(gx, gy, W, H);
+        const float* s = src + (size_t)((ns == 1) ? 0 : f) * 3 * plane;
+        const bool x0ok = (unsigned)b.x0 < (unsigned)W, x1ok = (unsigned)(b.x0 + 1) < (unsigned)W;
+        const bool y0ok = (unsigned)b.y0 < (unsigned)H, y1ok = (unsigned)(b.y0 + 1) < (unsigned)H;
+        for (int c = 0; c < 3; ++c) {
+            const float* pc = s + c * plane;
+            float v = 0.f;
+            if (y0ok && x0ok) v = fmaf(pc[b.y0 * W + b.x0], b.wnw, v);
+            if (y0ok && x1ok) v = fmaf(pc[b.y0 * W + b.x0 + 1], b.wne, v);
+            if (y1ok && x0ok) v = fmaf(pc[(b.y0 + 1) * W + b.x0], b.wsw, v);
+            if (y1ok && x1ok) v = fmaf(pc[(b.y0 + 1) * W + b.x0 + 1], b.wse, v);
+            out[((size_t)f * 3 + c) * plane + (size_t)y * W + x] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// once per clip: NCHW RGB source -> (a) NHWC zero-padded to Cpad channels for the 7x7 MFMA encoder
+// convolution, (b) anti-aliased, down-sampled [h,w,4] copy for the motion front end
+// (AntiAliasInterpolation2d, util.py:1044-1052: zero pad 6, depthwise 13x13, keep every inv_scale-th
+// row/column -- only the kept outputs are computed).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void source_to_nhwc_kernel(const float* __restrict__ src, int ns, int H, int W,
+                                                             int Cpad, float* __restrict__ dst) {
+    const size_t plane = (size_t)H * W;
+    const int c4n = Cpad >> 2;
+    const size_t total = (size_t)ns * plane * c4n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const size_t pix = idx / c4n;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 == 0) {
+            const size_t b = pix / plane, r = pix % plane;
+            const float* p = src + b * 3 * plane + r;
+            v = make_float4(p[0], p[plane], p[2 * plane], 0.f);
+        }
+        reinterpret_cast<float4*>(dst)[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void antialias_down_kernel(const float* __restrict__ src,
+                                                             const float* __restrict__ aa_w, int ns, int H, int W,
+                                                             int inv_scale, float4* __restrict__ dst) {
+    const int h = H / inv_scale, w = W / inv_scale;
+    const size_t plane = (size_t)H * W;
+    const size_t total = (size_t)ns * h * w;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % w), y = (int)((idx / w) % h), b = (int)(idx / ((size_t)w * h));
+    float acc[3] = {0.f, 0.f, 0.f};
+    if (inv_scale == 1) {
+        for (int c = 0; c < 3; ++c) acc[c] = src[((size_t)b * 3 + c) * plane + (size_t)y * W + x];
+    } else {
+        const int cy = y * inv_scale - 6, cx = x * inv_scale - 6;
+        for (int c = 0; c < 3; ++c) {
+            const float* p = src + ((size_t)b * 3 + c) * plane;
+            const float* k = aa_w + c * 169;
+            float s = 0.f;
+            for (int ky = 0; ky < 13; ++ky) {
+                const int yy = cy + ky;
+                if ((unsigned)yy >= (unsigned)H) continue;
+                for (int kx = 0; kx < 13; ++kx) {
+                    const int xx = cx + kx;
+                    if ((unsigned)xx >= (unsigned)W) continue;
+                    s = fmaf(p[(size_t)yy * W + xx], k[ky * 13 + kx], s);
+                }
+            }
+            acc[c] = s;
+        }
+    }
+    dst[idx] = make_float4(acc[0], acc[1], acc[2], 0.f);
+}
+
+// prediction [n,3,H,W] float -> [n,H,W,3] uint8 (img_as_ubyte rounding), the frame format demo.py:507 saves.
+__global__ __launch_bounds__(256) void to_u8_kernel(const float* __restrict__ pred, int n, int H, int W,
+                                                    uint8_t* __restrict__ out) {
+    const size_t plane = (size_t)H * W;
+    const size_t total = (size_t)n * plane;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = idx / plane, r = idx % plane;
+        const float* p = pred + f * 3 * plane + r;
+        for (int c = 0; c < 3; ++c) {
+            const float v = fminf(fmaxf(rintf(p[c * plane] * 255.f), 0.f), 255.f);
+            out[idx * 3 + c] = (uint8_t)v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline int grid_for(size_t total, int cap = 16384) {
+    return (int)std::min<size_t>((total + 255) / 256, (size_t)cap);
+}
+
+hipError_t kp_prepare_launch(const float* kd_val, const float* kd_jac, const float* ks_val, const float* ks_jac, int n,
+                             int ns, int K, float* kp_rec, int* bad_flag, hipStream_t s) {
+    hipLaunchKernelGGL(kp_prepare_kernel, dim3((n * K + 255) / 256), dim3(256), 0, s, kd_val, kd_jac, ks_val, ks_jac,
+                       n, ns, K, kp_rec, bad_flag);
+    return hipGetLastError();
+}
+
+hipError_t motion_front_launch(const float* kp_rec, const float* src_small, int n, int ns, int K, int h, int w,
+                               float variance, int Cpad, float* hg_in, float* sparse_deformed, hipStream_t s) {
+    hipLaunchKernelGGL(motion_front_kernel, dim3((h * w + 255) / 256, n), dim3(256), 0, s, kp_rec,
+                       reinterpret_cast<const float4*>(src_small), ns, K, h, w, variance, Cpad, hg_in,
+                       sparse_deformed);
+    return hipGetLastError();
+}
+
+hipError_t motion_head_launch(const float* logits, const float* kp_rec, int n, int K, int h, int w, int has_occ,
+                              float* deformation, float* occlusion, float* mask_out, float* occ_out, hipStream_t s) {
+    if (K > HEAD_MAXK - 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(motion_head_kernel, dim3((h * w + 255) / 256, n), dim3(256), 0, s, logits, kp_rec, K, h, w,
+                       has_occ, deformation, occlusion, mask_out, occ_out);
+    return hipGetLastError();
+}
+
+hipError_t warp_features_launch(const float* feat, const float* deformation, const float* occlusion, int n, int ns,
+                                int hf, int wf, int C, int h, int w, float* out, float* out2, const float* s2,
+                                const float* t2, hipStream_t s) {
+    const size_t total = (size_t)n * hf * wf * (C / 4);
+    hipLaunchKernelGGL(warp_features_kernel, dim3(grid_for(total, 1 << 20)), dim3(256), 0, s, feat, deformation,
+                       occlusion, n, ns, hf, wf, C, h, w, out, out2, s2, t2);
+    return hipGetLastError();
+}
+
+hipError_t warp_image_launch(const float* src, const float* deformation, int n, int ns, int H, int W, int h, int w,
+                             float* out, hipStream_t s) {
+    const size_t total = (size_t)n * H * W;
+    hipLaunchKernelGGL(warp_image_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, deformation, n, ns, H, W, h, w,
+                       out);
+    return hipGetLastError();
+}
+
+hipError_t source_prepare_launch(const float* src, const float* aa_w, int ns, int H, int W, int inv_scale, int Cpad,
+                                 float* src_nhwc, float* src_small, hipStream_t s) {
+    const size_t t1 = (size_t)ns * H * W * (Cpad / 4);
+    hipLaunchKernelGGL(source_to_nhwc_kernel, dim3(grid_for(t1)), dim3(256), 0, s, src, ns, H, W, Cpad, src_nhwc);
+    const size_t t2 = (size_t)ns * (H / inv_scale) * (W / inv_scale);
+    hipLaunchKernelGGL(antialias_down_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, src, aa_w, ns, H, W,
+                       inv_scale, reinterpret_cast<float4*>(src_small));
+    return hipGetLastError();
+}
+
+hipError_t to_u8_launch(const float* pred, int n, int H, int W, uint8_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(to_u8_kernel, dim3(grid_for((size_t)n * H * W)), dim3(256), 0, s, pred, n, H, W, out);
+    return hipGetLastError();
+}
+
+}  // namespace eamm

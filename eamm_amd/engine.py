@@ -1,0 +1,202 @@
+"""Python handle around the C ABI (include/eamm_hip.h): one ``Engine`` = one ``eamm_ctx``.
+
+PyTorch is plumbing here -- it owns device memory (tensors), the current HIP stream and, for the
+multi-GPU clip pipeline, ``torch.distributed``; every FLOP of the path runs in libeamm_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional
+
+import torch
+
+from . import _lib
+
+_OUTPUT_KEYS = ("prediction", "mask", "sparse_deformed", "occlusion_map", "deformed", "deformation")
+
+
+def config_struct(cfg: dict, height: int, width: int, max_frames: int, max_sources: int) -> _lib.EammConfig:
+    """Constructor kwargs of OcclusionAwareGenerator (reference generator.py:14-15) -> eamm_config."""
+    dm = cfg.get("dense_motion_params")
+    if dm is None:
+        raise ValueError("dense_motion_params=None (a generator without a motion network) is outside the "
+                         "accelerated path; every shipped config sets it (config/*.yaml generator_params)")
+    scale = dm.get("scale_factor", 1)
+    inv = int(round(1.0 / scale))
+    if abs(inv * scale - 1.0) > 1e-6:
+        raise ValueError(f"scale_factor={scale} is not 1/integer")
+    s = _lib.EammConfig()
+    s.num_channels = cfg["num_channels"]
+    s.num_kp = cfg["num_kp"]
+    s.block_expansion = cfg["block_expansion"]
+    s.max_features = cfg["max_features"]
+    s.num_down_blocks = cfg["num_down_blocks"]
+    s.num_bottleneck_blocks = cfg["num_bottleneck_blocks"]
+    s.estimate_occlusion_map = int(bool(cfg.get("estimate_occlusion_map", False)))
+    s.dm_block_expansion = dm["block_expansion"]
+    s.dm_max_features = dm["max_features"]
+    s.dm_num_blocks = dm["num_blocks"]
+    s.dm_inv_scale = inv
+    s.kp_variance = float(dm.get("kp_variance", 0.01))
+    s.height, s.width = int(height), int(width)
+    s.max_frames, s.max_sources = int(max_frames), int(max_sources)
+    return s
+
+
+def _dev_ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    def __init__(self, cfg: dict, height: int, width: int, max_frames: int = 16, max_sources: int = 1,
+                 device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("eamm_amd.Engine needs a ROCm GPU: the path has no CPU fallback")
+        self.cfg = dict(cfg)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"eamm_amd.Engine needs a GPU device, got {self.device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.height, self.width = int(height), int(width)
+        self.max_frames, self.max_sources = int(max_frames), int(max_sources)
+        self.num_kp = cfg["num_kp"]
+        self._L = _lib.lib()
+        self._cs = config_struct(cfg, height, width, max_frames, max_sources)
+        self.inv_scale = self._cs.dm_inv_scale
+        self.h, self.w = self.height // self.inv_scale, self.width // self.inv_scale
+        self.has_occlusion = bool(self._cs.estimate_occlusion_map)
+        ctx = C.c_void_p()
+        _lib.check(self._L.eamm_create(C.byref(self._cs), self.device.index, C.byref(ctx)), None)
+        self._ctx = ctx
+        self._finalized = False
+        self.ns_cached = 0
+
+    # -- lifecycle -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.eamm_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- weights ---------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor]):
+        """checkpoint['generator'] (reference demo.py:91) -> folded, MFMA-packed device weights."""
+        for key, t in state_dict.items():
+            if key.endswith("num_batches_tracked"):
+                continue
+            host = t.detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * max(1, host.dim()))(*host.shape)
+            _lib.check(self._L.eamm_load_tensor(self._ctx, key.encode(), C.c_void_p(host.data_ptr()), shape,
+                                                host.dim()), self._ctx)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.eamm_finalize_weights(self._ctx), self._ctx)
+        self._finalized = True
+
+    # -- forward ---------------------------------------------------------------------------------
+    def _check_dev(self, t: torch.Tensor, name: str, shape_tail):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"{name} must be a torch.Tensor")
+        if t.device != self.device:
+            raise RuntimeError(f"{name} is on {t.device}, the generator is on {self.device}")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+        if tuple(t.shape[1:]) != tuple(shape_tail):
+            raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected [*,{','.join(map(str, shape_tail))}]")
+        return t.contiguous()
+
+    def encode_source(self, source: torch.Tensor) -> int:
+        src = self._check_dev(source, "source_image", (3, self.height, self.width))
+        ns = src.shape[0]
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.eamm_encode_source(self._ctx, _dev_ptr(src), ns, self._stream()), self._ctx)
+        self.ns_cached = ns
+        return ns
+
+    def forward_frames(self, kp_driving: dict, kp_source: dict, outputs: Iterable[str] = ("prediction",),
+                       uint8_frames: bool = False) -> Dict[str, torch.Tensor]:
+        K, H, W, h, w = self.num_kp, self.height, self.width, self.h, self.w
+        kd = self._check_dev(kp_driving["value"], "kp_driving['value']", (K, 2))
+        ks = self._check_dev(kp_source["value"], "kp_source['value']", (K, 2))
+        n = kd.shape[0]
+        kdj = ksj = None
+        if "jacobian" in kp_driving:  # dense_motion.py:55
+            kdj = self._check_dev(kp_driving["jacobian"], "kp_driving['jacobian']", (K, 2, 2))
+            ksj = self._check_dev(kp_source["jacobian"], "kp_source['jacobian']", (K, 2, 2))
+            if kdj.shape[0] != n or ksj.shape[0] != ks.shape[0]:
+                raise RuntimeError("jacobian batch size does not match value batch size")
+        if ks.shape[0] != self.ns_cached:
+            raise RuntimeError(f"kp_source has {ks.shape[0]} sets but {self.ns_cached} source(s) are encoded")
+        want = set(outputs) | {"prediction"}
+        unknown = want - set(_OUTPUT_KEYS)
+        if unknown:
+            raise KeyError(f"unknown output(s) {sorted(unknown)}")
+        if "occlusion_map" in want and not self.has_occlusion:
+            want.discard("occlusion_map")
+        shapes = {"prediction": (n, 3, H, W), "mask": (n, K + 1, h, w), "sparse_deformed": (n, K + 1, 3, h, w),
+                  "occlusion_map": (n, 1, h, w), "deformed": (n, 3, H, W), "deformation": (n, h, w, 2)}
+        res = {k: torch.empty(shapes[k], dtype=torch.float32, device=self.device) for k in _OUTPUT_KEYS if k in want}
+        o = _lib.EammOutputs()
+        for k, t in res.items():
+            setattr(o, k, t.data_ptr())
+        if uint8_frames:
+            res["frames_u8"] = torch.empty((n, H, W, 3), dtype=torch.uint8, device=self.device)
+            o.frames_u8 = res["frames_u8"].data_ptr()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.eamm_forward_frames(self._ctx, n, _dev_ptr(kd), _dev_ptr(kdj), _dev_ptr(ks),
+                                                   _dev_ptr(ksj), C.byref(o), self._stream()), self._ctx)
+        return res
+
+    def check_numeric(self):
+        """Synchronise and raise if a singular key-point jacobian was met (torch.inverse semantics)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.eamm_check_numeric(self._ctx, self._stream()), self._ctx)
+
+    # -- source cache (multi-GPU broadcast payload) -------------------------------------------------
+    def source_cache_numel(self, ns: int = 1) -> int:
+        return self._L.eamm_source_cache_bytes(self._ctx, ns) // 4
+
+    def export_source_cache(self, ns: Optional[int] = None) -> torch.Tensor:
+        ns = self.ns_cached if ns is None else ns
+        blob = torch.empty(self.source_cache_numel(ns), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.eamm_export_source_cache(self._ctx, _dev_ptr(blob), ns, self._stream()), self._ctx)
+        return blob
+
+    def import_source_cache(self, blob: torch.Tensor, ns: int = 1):
+        if blob.device != self.device or blob.dtype != torch.float32 or blob.numel() != self.source_cache_numel(ns):
+            raise RuntimeError("source cache blob has the wrong device, dtype or size")
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.eamm_import_source_cache(self._ctx, _dev_ptr(blob.contiguous()), ns, self._stream()),
+                       self._ctx)
+        self.ns_cached = ns
+
+    # -- stage timing (HIP events inside the library, on the stream the kernels run on) -----------------
+    STAGES = ("front", "hg_enc", "hg_dec", "head", "warp", "bottleneck", "up", "final")
+
+    def profile(self, on: bool = True):
+        _lib.check(self._L.eamm_profile_enable(self._ctx, int(on)), self._ctx)
+
+    def profile_read(self, reset: bool = True) -> dict:
+        ms = (C.c_double * len(self.STAGES))()
+        calls, frames = C.c_int64(), C.c_int64()
+        _lib.check(self._L.eamm_profile_read(self._ctx, ms, len(self.STAGES), C.byref(calls), C.byref(frames),
+                                             int(reset)), self._ctx)
+        return {"calls": calls.value, "frames": frames.value, "ms": dict(zip(self.STAGES, list(ms)))}
+
+    # -- accounting --------------------------------------------------------------------------------
+    @property
+    def flops_per_frame(self) -> float:
+        return self._L.eamm_flops_per_frame(self._ctx)
+
+    @property
+    def encode_flops(self) -> float:
+        return self._L.eamm_encode_flops(self._ctx)

@@ -1,0 +1,171 @@
+"""Drop-in ``OcclusionAwareGenerator`` whose forward pass runs in libeamm_hip.so.
+
+Mirrors the reference module's interface for this path (reference modules/generator.py:8-97):
+same constructor keywords (``demo.py:54-55`` splats the YAML sections into it), same
+``forward(source_image, kp_driving, kp_source) -> dict`` contract and the same ``state_dict`` key
+set, so ``generator.load_state_dict(checkpoint['generator'])`` / ``.cuda()`` / ``.eval()``
+(demo.py:56-57, 91, 105) work unchanged.  The sub-modules below only HOLD parameters under the
+reference's names; they are never called.  All computation happens in the HIP library; there is no
+PyTorch/CPU fallback and ``forward`` raises when the module is not on a GPU.
+
+Beyond the reference interface the module exposes the two halves of forward separately
+(``encode_source`` / ``forward_frames``) so that a clip can reuse the frame-invariant source
+encoder (the reference recomputes it per frame, generator.py:61-63 inside demo.py:279's loop).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional
+
+import torch
+from torch import nn
+
+from .engine import Engine
+from .weights import antialias_kernel, generator_channels, hourglass_channels
+
+
+class _ConvNorm(nn.Module):
+    """Parameter holder named like DownBlock2d / UpBlock2d / SameBlock2d (util.py:883-938)."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel_size=k, padding=k // 2)
+        self.norm = nn.BatchNorm2d(cout, affine=True)
+
+
+class _ResHolder(nn.Module):
+    """Parameter holder named like ResBlock2d (util.py:858-870)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = nn.Conv2d(c, c, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv2d(c, c, kernel_size=3, padding=1)
+        self.norm1 = nn.BatchNorm2d(c, affine=True)
+        self.norm2 = nn.BatchNorm2d(c, affine=True)
+
+
+class _Stack(nn.Module):
+    def __init__(self, name, blocks):
+        super().__init__()
+        setattr(self, name, nn.ModuleList(blocks))
+
+
+class _AntiAlias(nn.Module):
+    """Holder of the 13x13 Gaussian buffer of AntiAliasInterpolation2d (util.py:1005-1042)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.register_buffer("weight", antialias_kernel(channels))
+
+
+class _DenseMotionHolder(nn.Module):
+    """Parameters of DenseMotionNetwork under the reference's names (dense_motion.py:12-30)."""
+
+    def __init__(self, block_expansion, num_blocks, max_features, num_kp, num_channels,
+                 estimate_occlusion_map=False, scale_factor=1, kp_variance=0.01):
+        super().__init__()
+        enc, dec, out_filters = hourglass_channels(block_expansion, (num_kp + 1) * (num_channels + 1), num_blocks,
+                                                   max_features)
+        hg = nn.Module()
+        hg.encoder = _Stack("down_blocks", [_ConvNorm(ci, co, 3) for ci, co in enc])
+        hg.decoder = _Stack("up_blocks", [_ConvNorm(ci, co, 3) for ci, co in dec])
+        self.hourglass = hg
+        self.mask = nn.Conv2d(out_filters, num_kp + 1, kernel_size=(7, 7), padding=(3, 3))
+        self.occlusion = nn.Conv2d(out_filters, 1, kernel_size=(7, 7), padding=(3, 3)) if estimate_occlusion_map else None
+        if scale_factor != 1:
+            self.down = _AntiAlias(num_channels)
+        self.num_kp, self.scale_factor, self.kp_variance = num_kp, scale_factor, kp_variance
+
+
+class OcclusionAwareGenerator(nn.Module):
+    """MI355X-native stand-in for reference modules/generator.py:OcclusionAwareGenerator."""
+
+    def __init__(self, num_channels, num_kp, block_expansion, max_features, num_down_blocks,
+                 num_bottleneck_blocks, estimate_occlusion_map=False, dense_motion_params=None,
+                 estimate_jacobian=False, max_frames=16):
+        super().__init__()
+        if dense_motion_params is None:
+            raise ValueError("dense_motion_params=None is outside the accelerated path (every shipped config sets it)")
+        self._cfg = dict(num_channels=num_channels, num_kp=num_kp, block_expansion=block_expansion,
+                         max_features=max_features, num_down_blocks=num_down_blocks,
+                         num_bottleneck_blocks=num_bottleneck_blocks, estimate_occlusion_map=estimate_occlusion_map,
+                         dense_motion_params=dict(dense_motion_params), estimate_jacobian=estimate_jacobian)
+        self.dense_motion_network = _DenseMotionHolder(num_kp=num_kp, num_channels=num_channels,
+                                                       estimate_occlusion_map=estimate_occlusion_map,
+                                                       **dense_motion_params)
+        down, up, bott = generator_channels(self._cfg)
+        self.first = _ConvNorm(num_channels, block_expansion, 7)
+        self.down_blocks = nn.ModuleList([_ConvNorm(ci, co, 3) for ci, co in down])
+        self.up_blocks = nn.ModuleList([_ConvNorm(ci, co, 3) for ci, co in up])
+        self.bottleneck = nn.Sequential()
+        for i in range(num_bottleneck_blocks):
+            self.bottleneck.add_module("r" + str(i), _ResHolder(bott))
+        self.final = nn.Conv2d(block_expansion, num_channels, kernel_size=(7, 7), padding=(3, 3))
+        self.estimate_occlusion_map = estimate_occlusion_map
+        self.num_channels = num_channels
+        self.max_frames = int(max_frames)
+        self._engine: Optional[Engine] = None
+        self._engine_key = None
+        for p in self.parameters():  # inference-only path
+            p.requires_grad_(False)
+
+    # -- engine management ---------------------------------------------------------------------------
+    def _weights_version(self):
+        return tuple(t._version for t in self.state_dict(keep_vars=True).values())
+
+    def _ensure_engine(self, height: int, width: int, frames: int, sources: int) -> Engine:
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("eamm_amd.OcclusionAwareGenerator runs only on a ROCm GPU: move the module with "
+                               ".cuda() first (there is no CPU fallback for this path)")
+        if self.training:
+            raise RuntimeError("inference-only: BatchNorm uses running statistics (sync_batchnorm/batchnorm.py:48-53);"
+                               " call .eval() as demo.py:105 does")
+        e = self._engine
+        key = (dev, height, width, self._weights_version())
+        if e is None or self._engine_key != key or e.max_frames < frames or e.max_sources < sources:
+            if e is not None:
+                e.close()
+            e = Engine(self._cfg, height, width, max_frames=max(frames, self.max_frames),
+                       max_sources=max(sources, 1), device=dev)
+            e.load_state_dict(self.state_dict())
+            self._engine, self._engine_key = e, key
+        return e
+
+    # -- the reference contract -----------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, source_image, kp_driving, kp_source):
+        """Reference generator.py:59-97: batch of independent (source, kp_source, kp_driving) triples."""
+        if source_image.dim() != 4:
+            raise RuntimeError(f"source_image must be [B,3,H,W], got {tuple(source_image.shape)}")
+        b, _, hh, ww = source_image.shape
+        e = self._ensure_engine(hh, ww, b, b)
+        e.encode_source(source_image)
+        want = ["prediction", "mask", "sparse_deformed", "deformed"]
+        if self.estimate_occlusion_map:
+            want.append("occlusion_map")
+        kd = {k: kp_driving[k] for k in ("value", "jacobian") if k in kp_driving}
+        ks = {k: kp_source[k] for k in ("value", "jacobian") if k in kp_source}
+        if kd["value"].shape[0] != b or ks["value"].shape[0] != b:
+            raise RuntimeError("key-point batch size does not match source_image batch size")
+        out = e.forward_frames(kd, ks, outputs=want)
+        e.check_numeric()  # torch.inverse raises (and synchronises) on a singular jacobian, dense_motion.py:56
+        return {k: out[k] for k in ("mask", "sparse_deformed", "occlusion_map", "deformed", "prediction") if k in out}
+
+    # -- clip interface: encoder hoisted out of the frame loop ------------------------------------------
+    @torch.no_grad()
+    def encode_source(self, source_image: torch.Tensor, max_frames: Optional[int] = None) -> Engine:
+        ns, _, hh, ww = source_image.shape
+        e = self._ensure_engine(hh, ww, max_frames or self.max_frames, ns)
+        e.encode_source(source_image)
+        return e
+
+    @torch.no_grad()
+    def forward_frames(self, kp_driving: Dict[str, torch.Tensor], kp_source: Dict[str, torch.Tensor],
+                       outputs: Iterable[str] = ("prediction",), uint8_frames: bool = False):
+        if self._engine is None or self._engine.ns_cached < 1:
+            raise RuntimeError("call encode_source(source_image) first")
+        return self._engine.forward_frames(kp_driving, kp_source, outputs=outputs, uint8_frames=uint8_frames)
+
+    @property
+    def engine(self) -> Optional[Engine]:
+        return self._engine

@@ -1,0 +1,169 @@
+/*
+ * eamm_hip.h -- C ABI of libeamm_hip.so: the MI355X (gfx950) implementation of EAMM's
+ * dense-motion + OcclusionAwareGenerator forward path.
+ *
+ * The reference has no FFI layer for this path: its boundary is the Python nn.Module
+ * `OcclusionAwareGenerator` (reference modules/generator.py:8-97).  The entry points below are what
+ * a binding for that module needs (see INTEGRATION.md for the ctypes stub); every one cites the
+ * reference interface it stands in for.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative eamm_status otherwise; the message is
+ *     available from eamm_last_error(ctx) (ctx may be NULL for a failed eamm_create);
+ *   - the CALLER owns every device buffer passed in or out; the library owns only its handle, the
+ *     packed weights, the cached source tensors and its workspace;
+ *   - all work is enqueued on the caller's stream (a hipStream_t passed as void*); no call
+ *     synchronises the device except eamm_create / eamm_finalize_weights / eamm_destroy;
+ *   - one handle per (device, stream); handles are independent, so different host threads may
+ *     drive different handles concurrently (reference threading model: one module replica per
+ *     device, train.py:53-63);
+ *   - boundary tensors are float32, contiguous, NCHW -- the reference's layout -- unless stated.
+ */
+#ifndef EAMM_HIP_H_
+#define EAMM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAMM_ABI_VERSION 1
+
+typedef enum eamm_status {
+    EAMM_OK = 0,
+    EAMM_ERR_ARG = -1,        /* bad argument / unsupported configuration            */
+    EAMM_ERR_STATE = -2,      /* call order (weights not finalised, no source cached) */
+    EAMM_ERR_KEY = -3,        /* unknown / missing / mis-shaped state_dict entry      */
+    EAMM_ERR_HIP = -4,        /* HIP runtime error                                    */
+    EAMM_ERR_NUMERIC = -5     /* singular key-point jacobian                          */
+} eamm_status;
+
+typedef struct eamm_ctx eamm_ctx;
+
+/*
+ * Constructor arguments of OcclusionAwareGenerator (reference modules/generator.py:14-15) with
+ * dense_motion_params (reference modules/dense_motion.py:12-13) flattened in, plus the two sizes
+ * the workspace is allocated for.
+ */
+typedef struct eamm_config {
+    int32_t num_channels;            /* 3                                              */
+    int32_t num_kp;                  /* 10                                             */
+    int32_t block_expansion;         /* 64                                             */
+    int32_t max_features;            /* 512                                            */
+    int32_t num_down_blocks;         /* 2                                              */
+    int32_t num_bottleneck_blocks;   /* 6                                              */
+    int32_t estimate_occlusion_map;  /* 0 / 1                                          */
+    int32_t dm_block_expansion;      /* dense_motion_params.block_expansion            */
+    int32_t dm_max_features;         /* dense_motion_params.max_features               */
+    int32_t dm_num_blocks;           /* dense_motion_params.num_blocks                 */
+    int32_t dm_inv_scale;            /* 1 / dense_motion_params.scale_factor (1, 2, 4) */
+    float   kp_variance;             /* dense_motion_params.kp_variance, default 0.01  */
+    int32_t height, width;           /* frame size (multiple of 2^max(down, log2 inv_scale + dm_num_blocks)) */
+    int32_t max_frames;              /* frames per eamm_forward_frames call the workspace holds */
+    int32_t max_sources;             /* source images cached at once (1 for a clip)    */
+} eamm_config;
+
+/* Optional outputs of a forward call; NULL pointers are skipped.  Shapes for n frames, frame
+ * HxW, motion grid hxw = H/inv_scale x W/inv_scale, K = num_kp (reference generator.py:70-95). */
+typedef struct eamm_outputs {
+    float* prediction;       /* [n,3,H,W]      'prediction'      -- required            */
+    float* mask;             /* [n,K+1,h,w]    'mask'                                   */
+    float* sparse_deformed;  /* [n,K+1,3,h,w]  'sparse_deformed'                        */
+    float* occlusion_map;    /* [n,1,h,w]      'occlusion_map'                          */
+    float* deformed;         /* [n,3,H,W]      'deformed'                               */
+    float* deformation;      /* [n,h,w,2]      dense_motion 'deformation' (internal to the reference) */
+    uint8_t* frames_u8;      /* [n,H,W,3] uint8 = round(255*prediction), HWC: the layout demo.py:281,507 saves */
+} eamm_outputs;
+
+int eamm_abi_version(void);
+
+/* Replaces OcclusionAwareGenerator.__init__ (generator.py:14-48) + .cuda() (demo.py:56-57). */
+int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out);
+void eamm_destroy(eamm_ctx* ctx);
+const char* eamm_last_error(const eamm_ctx* ctx);
+
+/*
+ * Replaces generator.load_state_dict(checkpoint['generator']) (demo.py:91, logger.py:58): call
+ * once per state_dict entry with the reference's key (e.g. "bottleneck.r0.conv1.weight") and a
+ * HOST float32 pointer (num_batches_tracked entries may be skipped), then eamm_finalize_weights,
+ * which checks the key set strictly, folds eval-mode BatchNorm (sync_batchnorm/batchnorm.py:48-53)
+ * into the adjacent convolutions and repacks OIHW weights into MFMA tile order on the device.
+ */
+int eamm_load_tensor(eamm_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim);
+int eamm_finalize_weights(eamm_ctx* ctx);
+
+/*
+ * Frame-invariant part of OcclusionAwareGenerator.forward, hoisted out of the per-frame loop
+ * (generator.py:61-63 encoder, dense_motion.py:83 anti-alias down-sampling): caches, for `ns`
+ * source images [ns,3,H,W] on the device, the encoder feature map, the down-sampled source and the
+ * full-resolution source.
+ */
+int eamm_encode_source(eamm_ctx* ctx, const float* source, int ns, void* stream);
+
+/*
+ * Per-frame part of OcclusionAwareGenerator.forward (generator.py:68-95, dense_motion.py:81-113)
+ * for n driving key-point sets.  kp_*_value: [*,K,2]; kp_*_jacobian: [*,K,2,2] or NULL (both or
+ * neither; NULL = the "'jacobian' not in kp_driving" branch, dense_motion.py:55).  kp_source_* hold
+ * `ns` sets matching the cached sources; ns == 1 broadcasts one source to all frames (the clip
+ * loop, demo.py:251-281), otherwise ns == n and frame i uses source i (the module's batch contract).
+ */
+int eamm_forward_frames(eamm_ctx* ctx, int n,
+                        const float* kp_driving_value, const float* kp_driving_jacobian,
+                        const float* kp_source_value, const float* kp_source_jacobian,
+                        const eamm_outputs* outputs, void* stream);
+
+/*
+ * torch.inverse raises on a singular key-point jacobian (dense_motion.py:56) and synchronises to do
+ * so.  The kernels only record the condition; this call synchronises `stream` and returns
+ * EAMM_ERR_NUMERIC if any forward call since the last check met one (outputs are then inf/nan).
+ */
+int eamm_check_numeric(eamm_ctx* ctx, void* stream);
+
+/*
+ * Cached source tensors as one flat device blob, so that a clip's source can be encoded on one
+ * GPU and broadcast to the others (RCCL) instead of re-encoded: export copies the cache of the
+ * `ns` encoded sources into `dst`, import installs such a blob.  Both are stream-ordered copies.
+ */
+size_t eamm_source_cache_bytes(const eamm_ctx* ctx, int ns);
+int eamm_export_source_cache(eamm_ctx* ctx, void* dst, int ns, void* stream);
+int eamm_import_source_cache(eamm_ctx* ctx, const void* src, int ns, void* stream);
+
+/* Algorithmic work of one eamm_forward_frames call of n frames (for roofline accounting). */
+double eamm_flops_per_frame(const eamm_ctx* ctx);
+double eamm_encode_flops(const eamm_ctx* ctx);
+
+/*
+ * Stage timing for roofline accounting (bench.py): while enabled, every eamm_forward_frames call
+ * records HIP events on the caller's stream at its EAMM_NSTAGE+1 stage boundaries (up to 256 calls
+ * between reads).  eamm_profile_read waits for the recorded calls and returns accumulated
+ * milliseconds per stage: 0 key points + motion front end, 1 hourglass encoder, 2 hourglass decoder,
+ * 3 flow head, 4 feature warp, 5 bottleneck (2 x num_bottleneck_blocks 3x3 convolutions), 6 up
+ * blocks, 7 final 7x7 + sigmoid (+ uint8 packing).
+ */
+#define EAMM_NSTAGE 8
+int eamm_profile_enable(eamm_ctx* ctx, int on);
+int eamm_profile_read(eamm_ctx* ctx, double* stage_ms, int nstage, int64_t* calls, int64_t* frames, int reset);
+
+/*
+ * Op-level entry points used by the parity tests (tests/test_gpu_ops.py): each runs ONE kernel of
+ * the path on caller-provided device buffers so it can be compared with the oracle in isolation.
+ */
+
+/* 3x3 / 7x7 convolution on NHWC activations as an fp32-MFMA implicit GEMM.
+ * in0/in1: [B,Hin,Win,C0|C1] (in1 optional: channel concatenation), weight: OIHW host pointer
+ * [Cout,C0+C1,ks,ks], bias host [Cout]; up = 1 runs the conv on the nearest-x2 up-sampled input;
+ * act: 0 none, 1 relu, 2 sigmoid; pool = 1 applies avgpool2x2 after the activation; resid: NHWC
+ * tensor added before the activation; splitk 0 = automatic; tile_n 0 = automatic; out NHWC
+ * [B,H(/2),W(/2),Cout].  iters > 0 additionally times `iters` back-to-back launches with HIP events
+ * on `stream` and stores the average milliseconds in *avg_ms. */
+int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int up,
+                 const float* weight_host, const float* bias_host, int Cout, int ks,
+                 int act, int pool, const float* resid, int splitk, int tile_n, float* out, int iters,
+                 float* avg_ms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAMM_HIP_H_ */

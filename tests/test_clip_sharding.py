@@ -1,0 +1,107 @@
+"""N>1 path on CPU: two gloo processes run eamm_amd.clip.animate_clip with a stand-in backend that
+computes frames with the oracle.  Checks the protocol of the multi-GPU clip pipeline: one broadcast
+of the source cache from rank 0, key points broadcast, contiguous shards, optional gather."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from eamm_amd.clip import animate_clip, shard_bounds
+from eamm_amd.config import tiny_config
+from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict
+from oracle import eamm_oracle as orc
+
+
+class OracleBackend:
+    """CPU stand-in for EngineBackend (tests only): the 'source cache' blob is the encoder feature
+    map + the source itself, frames come from the oracle's decode path."""
+
+    def __init__(self, cfg, sd, batch, size):
+        self.cfg, self.sd, self.batch, self.size = cfg, sd, batch, size
+        self.device = torch.device("cpu")
+        self.blob = None
+        self.calls = []
+
+    def prepare(self, h, w):
+        assert (h, w) == (self.size, self.size)
+
+    def encode(self, src):
+        with torch.no_grad():
+            feat = orc.encode_source(self.sd, self.cfg, src)
+        self.feat_shape = feat.shape
+        self.blob = torch.cat([feat.flatten(), src.flatten()])
+        return self.blob
+
+    def blob_like(self):
+        c = self.cfg
+        hf = self.size >> c["num_down_blocks"]
+        cb = min(c["max_features"], c["block_expansion"] << c["num_down_blocks"])
+        self.feat_shape = (1, cb, hf, hf)
+        return torch.empty(cb * hf * hf + 3 * self.size * self.size)
+
+    def install(self, blob):
+        self.blob = blob
+
+    def run(self, kp_d, kp_s, uint8):
+        n = kp_d["value"].shape[0]
+        self.calls.append(n)
+        nf = int(np.prod(self.feat_shape))
+        src = self.blob[nf:].view(1, 3, self.size, self.size)
+        srcb = src.expand(n, -1, -1, -1)
+        ksb = {k: v.expand(n, *v.shape[1:]) for k, v in kp_s.items()}
+        with torch.no_grad():
+            pred = orc.generator_forward(self.sd, self.cfg, srcb, kp_d, ksb)["prediction"]
+        if uint8:
+            return torch.clamp(torch.round(pred * 255), 0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        return pred
+
+    def finish(self):
+        pass
+
+
+def _worker(rank, world, port, total, batch, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    be = OracleBackend(cfg, sd, batch, 64)
+    if rank == 0:
+        src, kp_s, kp_d = synthetic_source(64, seed=1), synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(total, 10, seed=2)
+    else:
+        src = kp_s = kp_d = None  # only rank 0 holds the clip's inputs
+    local, (a, b) = animate_clip(be, src, kp_s, kp_d, 64, 64, uint8=False)
+    assert (a, b) == shard_bounds(total, world, rank) and local.shape[0] == b - a
+    assert all(n <= batch for n in be.calls) and sum(be.calls) == b - a
+    np.save(os.path.join(tmp, f"shard{rank}.npy"), local.numpy())
+    full, span = animate_clip(be, src, kp_s, kp_d, 64, 64, uint8=True, gather=True)
+    if rank == 0:
+        assert span == (0, total) and full.shape == (total, 64, 64, 3) and full.dtype == torch.uint8
+        np.save(os.path.join(tmp, "gathered.npy"), full.numpy())
+    else:
+        assert full.shape[0] == 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_clip_equals_single_process(tmp_path):
+    total, batch, world = 5, 2, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, total, batch, str(tmp_path)), nprocs=world, join=True)
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    be = OracleBackend(cfg, sd, batch, 64)
+    ref, span = animate_clip(be, synthetic_source(64, seed=1), synthetic_keypoints(1, 10, seed=0),
+                             synthetic_keypoints(total, 10, seed=2), 64, 64)
+    assert span == (0, total)
+    got = np.concatenate([np.load(tmp_path / f"shard{r}.npy") for r in range(world)], axis=0)
+    assert got.shape == tuple(ref.shape)
+    assert np.abs(got - ref.numpy()).max() <= 1e-6  # frames are independent: sharding must not change them
+    u8 = np.load(tmp_path / "gathered.npy")
+    want = np.clip(np.rint(ref.numpy() * 255), 0, 255).astype(np.uint8).transpose(0, 2, 3, 1)
+    assert np.abs(u8.astype(int) - want.astype(int)).max() <= 1

@@ -1,0 +1,186 @@
+"""Whole-path parity on the GPU: eamm_amd.OcclusionAwareGenerator (HIP library behind the reference's
+module interface) against (a) the fixtures captured from the reference, (b) the CPU oracle on the
+same seeded inputs, plus size-independent properties at BASELINE.json's full batch sizes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TOL
+from eamm_amd import EngineBackend, OcclusionAwareGenerator, animate_clip, hot_path_config, tiny_config
+from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict
+from oracle import eamm_oracle as orc
+from test_oracle_golden import inputs_from_fixture, load_case, sample
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+KEYS = ("prediction", "mask", "sparse_deformed", "occlusion_map", "deformed")
+_GEN = {}
+
+
+def generator(cfg_fn):
+    """One module per config for the whole session (weights: seed 1234, like the fixtures)."""
+    if cfg_fn not in _GEN:
+        cfg = cfg_fn()
+        gen = OcclusionAwareGenerator(**cfg)
+        gen.load_state_dict(synthetic_state_dict(cfg, seed=1234), strict=True)
+        _GEN[cfg_fn] = gen.to(DEV).eval()
+    return _GEN[cfg_fn]
+
+
+def cuda(d):
+    return {k: v.to(DEV) for k, v in d.items()}
+
+
+def report(tag, errs):
+    print("\n" + tag + "  " + "  ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+
+
+@pytest.mark.parametrize("name,cfg_fn", [("tiny64_clip3", tiny_config), ("tiny64_batch2", tiny_config),
+                                         ("tiny64_nojac", tiny_config), ("full256_clip2", hot_path_config),
+                                         ("full512_clip1", hot_path_config)])
+def test_module_forward_matches_reference_fixture(name, cfg_fn):
+    """Reference contract forward(source, kp_driving, kp_source) -> dict, against reference outputs."""
+    cfg = cfg_fn()
+    fx = load_case(name)
+    sd, src, kp_d, kp_s, n, per_frame = inputs_from_fixture(fx, cfg)
+    if not per_frame:
+        src = src.expand(n, -1, -1, -1).contiguous()
+        kp_s = {k: v.expand(n, *v.shape[1:]).contiguous() for k, v in kp_s.items()}
+    gen = generator(cfg_fn)
+    out = gen(src.to(DEV), kp_source=cuda(kp_s), kp_driving=cuda(kp_d))  # demo.py:279 argument order
+    assert set(out) == set(KEYS)
+    errs = {}
+    for key in KEYS:
+        got = sample(out[key].cpu(), key, fx)
+        want = torch.from_numpy(fx[key])
+        assert got.shape == want.shape, (key, got.shape, want.shape)
+        errs[key] = float((got - want).abs().max())
+    report(name, errs)
+    for key in KEYS:
+        assert errs[key] <= TOL[key], (name, key, errs[key])
+
+
+def test_internal_flow_matches_fixture():
+    cfg = hot_path_config()
+    fx = load_case("full256_clip2")
+    sd, src, kp_d, kp_s, n, _ = inputs_from_fixture(fx, cfg)
+    gen = generator(hot_path_config)
+    e = gen.encode_source(src.to(DEV))
+    out = e.forward_frames(cuda(kp_d), cuda(kp_s), outputs=("prediction", "deformation"))
+    err = float((out["deformation"].cpu() - torch.from_numpy(fx["deformation"])).abs().max())
+    assert err <= TOL["deformation"], err
+
+
+def test_clip_interface_equals_module_forward_and_oracle():
+    """encode once + batched frames == per-frame module calls == oracle (tiny config, full tensors)."""
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    gen = generator(tiny_config)
+    src, kp_s, kp_d = synthetic_source(64, seed=1), synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(7, 10, seed=2)
+    frames, span = animate_clip(EngineBackend(gen, batch=3), src, kp_s, kp_d, 64, 64)  # 3+3+1: ragged last batch
+    assert span == (0, 7) and frames.shape == (7, 3, 64, 64)
+    ref = np.stack(orc.animate_clip(sd, cfg, src, kp_s, kp_d))  # [T,H,W,3]
+    err = np.abs(frames.cpu().numpy().transpose(0, 2, 3, 1) - ref).max()
+    assert err <= TOL["prediction"], err
+    for t in (0, 6):
+        one = gen(src.to(DEV), kp_source=cuda(kp_s), kp_driving=cuda({k: v[t:t + 1] for k, v in kp_d.items()}))
+        assert float((one["prediction"][0] - frames[t]).abs().max()) <= 1e-5
+    u8, _ = animate_clip(EngineBackend(gen, batch=4), src, kp_s, kp_d, 64, 64, uint8=True)
+    assert u8.dtype == torch.uint8 and u8.shape == (7, 64, 64, 3)
+    want = np.clip(np.rint(ref * 255), 0, 255)
+    assert np.abs(u8.cpu().numpy().astype(np.float32) - want).max() <= 1
+
+
+def test_full_batch16_properties():
+    """BASELINE config 3 size (256x256, 16 frames per launch): properties that need no CPU reference.
+    (a) frames are independent: frame i of a 16-batch == the same key points run alone;
+    (b) permuting the driving frames permutes the outputs; (c) outputs are sigmoid-ranged and finite;
+    (d) driving == source key points with identity motion reproduces the no-motion prediction."""
+    cfg = hot_path_config()
+    gen = generator(hot_path_config)
+    src, kp_s, kp_d = synthetic_source(256, seed=1), synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(16, 10, seed=2)
+    e = gen.encode_source(src.to(DEV), max_frames=16)
+    full = e.forward_frames(cuda(kp_d), cuda(kp_s), outputs=("prediction", "mask"))
+    pred = full["prediction"]
+    assert pred.shape == (16, 3, 256, 256) and torch.isfinite(pred).all()
+    assert float(pred.min()) > 0 and float(pred.max()) < 1 and float(pred.std()) > 0.05
+    assert float((full["mask"].sum(dim=1) - 1).abs().max()) <= 1e-5  # softmax over the K+1 motions
+    for i in (0, 9, 15):
+        alone = e.forward_frames(cuda({k: v[i:i + 1] for k, v in kp_d.items()}), cuda(kp_s))["prediction"]
+        assert float((alone[0] - pred[i]).abs().max()) <= 2e-5  # split-K plans differ with M: not bit-exact
+    perm = torch.randperm(16, generator=torch.Generator().manual_seed(0))
+    shuffled = e.forward_frames(cuda({k: v[perm] for k, v in kp_d.items()}), cuda(kp_s))["prediction"]
+    assert torch.equal(shuffled, pred[perm.to(DEV)])  # same launch geometry -> bit-exact
+    # oracle on two of the sixteen frames (the oracle needs ~0.4 s per frame at this size)
+    sd = synthetic_state_dict(cfg, seed=1234)
+    for i in (3, 12):
+        with torch.no_grad():
+            ref = orc.generator_forward(sd, cfg, src, {k: v[i:i + 1] for k, v in kp_d.items()}, kp_s)["prediction"]
+        assert float((pred[i].cpu() - ref[0]).abs().max()) <= TOL["prediction"]
+
+
+def test_batch8_512_properties():
+    """BASELINE config 5 size (512x512, batch 8): runs, finite, frame-independent."""
+    gen = generator(hot_path_config)
+    src, kp_s, kp_d = synthetic_source(512, seed=1), synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(8, 10, seed=2)
+    e = gen.encode_source(src.to(DEV), max_frames=8)
+    pred = e.forward_frames(cuda(kp_d), cuda(kp_s))["prediction"]
+    assert pred.shape == (8, 3, 512, 512) and torch.isfinite(pred).all()
+    alone = e.forward_frames(cuda({k: v[5:6] for k, v in kp_d.items()}), cuda(kp_s))["prediction"]
+    assert float((alone[0] - pred[5]).abs().max()) <= 2e-5
+
+
+def test_edge_cases_and_errors():
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    gen = generator(tiny_config)
+    src, kp_s = synthetic_source(64, seed=1), synthetic_keypoints(1, 10, seed=0)
+    # key points far outside the frame: all K warps sample zero padding; must match the oracle, no NaN
+    kp_far = {"value": torch.full((1, 10, 2), 7.0), "jacobian": torch.eye(2).expand(1, 10, 2, 2).contiguous()}
+    out = gen(src.to(DEV), kp_source=cuda(kp_s), kp_driving=cuda(kp_far))
+    with torch.no_grad():
+        ref = orc.generator_forward(sd, cfg, src, kp_far, kp_s)
+    for k in KEYS:
+        assert torch.isfinite(out[k]).all()
+        assert float((out[k].cpu() - ref[k]).abs().max()) <= TOL[k], k
+    # singular driving jacobian: the reference raises from torch.inverse (dense_motion.py:56)
+    kp_bad = {"value": torch.zeros(1, 10, 2), "jacobian": torch.zeros(1, 10, 2, 2)}
+    with pytest.raises(RuntimeError):
+        gen(src.to(DEV), kp_source=cuda(kp_s), kp_driving=cuda(kp_bad))
+    # missing key -> KeyError, wrong device -> RuntimeError (SURVEY.md 8b error contract)
+    with pytest.raises(KeyError):
+        gen(src.to(DEV), kp_source=cuda(kp_s), kp_driving={"jacobian": kp_far["jacobian"].to(DEV)})
+    with pytest.raises(RuntimeError):
+        gen(src.to(DEV), kp_source=cuda(kp_s), kp_driving=kp_far)  # CPU tensors
+    # reloading different weights through load_state_dict must take effect (engine re-packs)
+    gen2 = OcclusionAwareGenerator(**cfg).to(DEV).eval()
+    gen2.load_state_dict(synthetic_state_dict(cfg, seed=1234))
+    kp_d = synthetic_keypoints(1, 10, seed=2)
+    a = gen2(src.to(DEV), kp_source=cuda(kp_s), kp_driving=cuda(kp_d))["prediction"].clone()
+    gen2.load_state_dict(synthetic_state_dict(cfg, seed=99))
+    b = gen2(src.to(DEV), kp_source=cuda(kp_s), kp_driving=cuda(kp_d))["prediction"]
+    assert float((a - b).abs().max()) > 1e-3
+    with torch.no_grad():
+        ref = orc.generator_forward(synthetic_state_dict(cfg, seed=99), cfg, src, kp_d, kp_s)["prediction"]
+    assert float((b.cpu() - ref).abs().max()) <= TOL["prediction"]
+
+
+def test_source_cache_export_import_roundtrip():
+    """The multi-GPU broadcast payload: export on one handle, import on another, identical frames."""
+    from eamm_amd import Engine
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    src, kp_s, kp_d = synthetic_source(64, seed=1), synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(4, 10, seed=2)
+    a, b = Engine(cfg, 64, 64, 4, 1, torch.device(DEV)), Engine(cfg, 64, 64, 4, 1, torch.device(DEV))
+    a.load_state_dict(sd)
+    b.load_state_dict(sd)
+    a.encode_source(src.to(DEV))
+    blob = a.export_source_cache(1)
+    assert blob.numel() == a.source_cache_numel(1) == 16 * 16 * 128 + 16 * 16 * 4 + 3 * 64 * 64
+    b.import_source_cache(blob, 1)
+    pa = a.forward_frames(cuda(kp_d), cuda(kp_s))["prediction"]
+    pb = b.forward_frames(cuda(kp_d), cuda(kp_s))["prediction"]
+    assert torch.equal(pa, pb)
+    with pytest.raises(RuntimeError):
+        Engine(cfg, 64, 64, 4, 1, torch.device(DEV)).forward_frames(cuda(kp_d), cuda(kp_s))  # nothing encoded
+    a.close(); b.close()

@@ -1,0 +1,117 @@
+"""Op-level parity on the GPU: the fp32-MFMA implicit-GEMM convolution (every loader / epilogue /
+split-K variant) through the C ABI entry point eamm_op_conv, against torch-CPU fp32 reference ops."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from eamm_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_conv(in0, in1, w, b, ks, up, act, pool, resid):
+    x = in0 if in1 is None else torch.cat([in0, in1], dim=1)
+    if up:
+        x = F.interpolate(x, scale_factor=2)  # nearest, as UpBlock2d (util.py:896)
+    y = F.conv2d(x, w, b, padding=ks // 2)
+    if resid is not None:
+        y = y + resid
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = torch.sigmoid(y)
+    if pool:
+        y = F.avg_pool2d(y, 2)
+    return y
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def run_case(B, H, W, C0, C1, Cout, ks, up=0, act=0, pool=0, resid=False, splitk=0, tile_n=0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    cin = C0 + C1
+    in0 = torch.randn(B, C0, H, W, generator=g)
+    in1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    w = torch.randn(Cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+    b = 0.1 * torch.randn(Cout, generator=g)
+    Ho, Wo = (H << up), (W << up)
+    res = torch.randn(B, Cout, Ho, Wo, generator=g) if resid else None
+    want = ref_conv(in0, in1, w, b, ks, up, act, pool, res)
+    dev = torch.device("cuda:0")
+    d0 = nhwc(in0).to(dev)
+    d1 = nhwc(in1).to(dev) if C1 else None
+    dres = nhwc(res).to(dev) if resid else None
+    out = torch.full((B, Ho >> pool, Wo >> pool, Cout), float("nan"), device=dev)
+    L = _lib.lib()
+    wc, bc = w.contiguous(), b.contiguous()
+    rc = L.eamm_op_conv(0, d0.data_ptr(), C0, d1.data_ptr() if C1 else None, C1, B, H, W, up,
+                        wc.data_ptr(), bc.data_ptr(), Cout, ks, act, pool,
+                        dres.data_ptr() if resid else None, splitk, tile_n, out.data_ptr(), 0, None,
+                        torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, None)
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all(), "output has unwritten / non-finite elements"
+    err = float((got - want).abs().max())
+    scale = max(1.0, float(want.abs().max()))
+    return err, scale
+
+
+CASES = {
+    # name: kwargs                                                       (shapes follow the network's layers)
+    "3x3_tile32":        dict(B=1, H=16, W=16, C0=32, C1=0, Cout=32, ks=3),
+    "3x3_tile64_relu":   dict(B=2, H=16, W=16, C0=64, C1=0, Cout=64, ks=3, act=1),
+    "3x3_tile128_pool":  dict(B=1, H=32, W=32, C0=128, C1=0, Cout=256, ks=3, act=1, pool=1),
+    "3x3_mtail_ntail":   dict(B=1, H=6, W=10, C0=32, C1=0, Cout=96, ks=3, act=1),
+    "3x3_rect_pool":     dict(B=3, H=8, W=12, C0=64, C1=0, Cout=128, ks=3, act=1, pool=1),
+    "3x3_up":            dict(B=2, H=8, W=8, C0=64, C1=0, Cout=32, ks=3, up=1, act=1),
+    "3x3_up_concat":     dict(B=2, H=8, W=8, C0=64, C1=32, Cout=64, ks=3, up=1, act=1),
+    "3x3_resid":         dict(B=1, H=16, W=16, C0=64, C1=0, Cout=64, ks=3, resid=True),
+    "3x3_splitk3_pool":  dict(B=1, H=8, W=8, C0=96, C1=0, Cout=128, ks=3, act=1, pool=1, splitk=3),
+    "3x3_splitk4":       dict(B=1, H=8, W=8, C0=64, C1=0, Cout=64, ks=3, act=1, splitk=4),
+    "3x3_tile64_as_32":  dict(B=1, H=16, W=16, C0=32, C1=0, Cout=64, ks=3, tile_n=32),
+    "3x3_tile128_as_64": dict(B=1, H=16, W=16, C0=32, C1=0, Cout=128, ks=3, tile_n=64),
+    "7x7_head":          dict(B=1, H=16, W=16, C0=32, C1=64, Cout=12, ks=7),
+    "7x7_sigmoid":       dict(B=1, H=32, W=32, C0=32, C1=0, Cout=3, ks=7, act=2),
+    "7x7_first":         dict(B=1, H=32, W=32, C0=32, C1=0, Cout=64, ks=7, act=1),
+    "bottleneck_256":    dict(B=2, H=64, W=64, C0=256, C1=0, Cout=256, ks=3, resid=True),
+    "hg_enc4_autosplit": dict(B=4, H=4, W=4, C0=1024, C1=0, Cout=1024, ks=3, act=1, pool=1),
+    "hg_dec1_autosplit": dict(B=2, H=4, W=4, C0=1024, C1=1024, Cout=512, ks=3, up=1, act=1),
+    "hg_dec0_2x2":       dict(B=1, H=2, W=2, C0=1024, C1=0, Cout=1024, ks=3, up=1, act=1),
+    "up1_like":          dict(B=1, H=64, W=64, C0=128, C1=0, Cout=64, ks=3, up=1, act=1),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_conv_mfma_matches_torch(name):
+    err, scale = run_case(**CASES[name], seed=hash(name) % 1000)
+    # exact-fp32 MFMA (fmaf chain) vs oneDNN: only summation order differs
+    assert err <= 2e-5 * scale, (name, err, scale)
+
+
+def test_conv_linearity_property():
+    """Size-independent property at a full-size layer: conv(a*x) == a*conv(x) for a power of two
+    (bit-exact in fp32) -- catches dropped K chunks / stale accumulators without a CPU reference."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cc = 4, 64, 64, 256
+    x = torch.randn(B, H, W, Cc, generator=g).to(dev)
+    w = (torch.randn(Cc, Cc, 3, 3, generator=g) * (1.0 / (Cc * 9)) ** 0.5).contiguous()
+    b = torch.zeros(Cc)
+    L = _lib.lib()
+    outs = []
+    for scale in (1.0, 4.0):
+        xin = (x * scale).contiguous()
+        out = torch.empty(B, H, W, Cc, device=dev)
+        _lib.check(L.eamm_op_conv(0, xin.data_ptr(), Cc, None, 0, B, H, W, 0, w.data_ptr(), b.data_ptr(), Cc, 3, 0, 0,
+                                  None, 0, 0, out.data_ptr(), 0, None, torch.cuda.current_stream().cuda_stream),
+                   None)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0] * 4.0, outs[1])
+    assert float(outs[0].abs().max()) > 0.5
