@@ -58,7 +58,7 @@ SIGNATURES = {
     "eamm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64), C.c_int]),
     "eamm_op_conv": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                               C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                               C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
 }
 

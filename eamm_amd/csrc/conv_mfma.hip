@@ -1,29 +1,32 @@
-// 3x3 / 7x7 convolution on NHWC fp32 activations as an implicit GEMM on the CDNA4 matrix cores.
+// KHxKW convolution on NHWC fp32 activations as an implicit GEMM on the CDNA4 matrix cores.
 //
 // Replaces every F.conv2d + batch_norm + relu (+ avg_pool2d / nearest-upsample / cat / residual add)
 // group of the reference's DownBlock2d / UpBlock2d / ResBlock2d / SameBlock2d (modules/util.py:858-938)
 // with ONE kernel: eval-mode BatchNorm is folded into the weights at load time, the activation,
-// 2x2 average pool, residual add and the next block's pre-activation are epilogues, the nearest
-// x2 up-sampling and the channel concatenation of the hourglass decoder are address arithmetic in
-// the operand loader (nothing is materialised).
+// 2x2 average pool, residual add and the next block's pre-activation are epilogues, the channel
+// concatenation of the hourglass decoder is address arithmetic in the operand loader, and
+// UpBlock2d's "nearest x2 then 3x3" is evaluated in its exact collapsed form: output pixel
+// (2y+py, 2x+px) only ever sees a 2x2 neighbourhood of the low-resolution input, with the 3x3 taps
+// that land on the same input pixel pre-summed -- four 2x2 "phase" convolutions, 2.25x fewer MACs
+// (PHASE mode; nothing is up-sampled or materialised).
 //
-// GEMM view:  M = B*H*W output pixels, N = Cout, K = taps * Cin, exact fp32 via
-// v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain; gfx950 has no TF32/xf32).
+// GEMM view:  M = B*H*W pixels, N = Cout, K = taps * Cin, exact fp32 via v_mfma_f32_32x32x2_f32
+// (bitwise an fmaf chain; gfx950 has no TF32/xf32).
 //   * block tile BM x BN = (WM*MT*32) x (WN*NT*32), 4 waves, each wave MT x NT MFMA tiles;
 //   * K is walked in chunks of 32 input channels of one filter tap; channel-chunk outer, tap inner,
-//     so the 9 (49) shifted re-reads of an activation line hit L2 back to back;
-//   * both operands are staged global -> VGPR -> LDS (double buffered, one barrier per chunk) as
-//     [row][32+4] so that each lane fetches FOUR consecutive k with one ds_read_b128: lanes 0-31
-//     take k = 8s+{0..3}, lanes 32-63 k = 8s+{4..7}; A and B use the same permutation of K, which
-//     the sum does not care about;
+//     so the shifted re-reads of an activation line hit L2 back to back;
+//   * both operands are staged HBM/L2 -> VGPR -> LDS with raw buffer loads (out-of-range offset =>
+//     hardware zero fill = the zero padding and the M tail, no branches), double buffered, one
+//     barrier per chunk, laid out [row][32+4] so that each lane fetches FOUR consecutive k with one
+//     conflict-free ds_read_b128: lanes 0-31 take k = 8s+{0..3}, lanes 32-63 k = 8s+{4..7}; A and B use
+//     the same permutation of K, which the sum does not care about;
 //   * M is enumerated in 2x2-quad order (m = 4*quad + 2*jy + jx): the four accumulator registers
 //     4g..4g+3 of a lane are then exactly one pooling window, so AvgPool2d(2) is in-register;
-//   * zero padding = predicated loads; M/N tails are masked;
-//   * small-M layers (the deep hourglass levels) use split-K over gridDim with an fp32 slab
-//     reduction kernel that applies the epilogue;
+//   * small-M layers (the deep hourglass levels, small batches) use split-K over gridDim with an fp32
+//     slab reduction kernel that applies the same epilogue;
 //   * blockIdx is remapped so that consecutive logical tiles (same M tile, all N tiles) share an XCD
 //     and therefore an L2.
-#include "kernels.h"
+#include "conv_common.h"
 
 #include <algorithm>
 #include <cstring>
@@ -31,31 +34,14 @@
 
 namespace eamm {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    // bijective "block b runs on XCD b%8" -> contiguous chunk per XCD
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_RELU) return fmaxf(v, 0.f);
-    if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
-    return v;
-}
-
-template <int KS, int MT, int NT, int WM, int WN>
+template <int KH, int KW, int MT, int NT, int WM, int WN, bool PHASE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int BK = CONV_BK, LDK = CONV_LDK;
-    constexpr int T = KS * KS, P = KS / 2;
+    constexpr int T = KH * KW;
     constexpr int A_PER = BM / 32, B_PER = BN / 32;
     static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(!PHASE || (KH == 2 && KW == 2), "phase mode is the collapsed nearest-x2 + 3x3");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [2][BM][LDK]
@@ -70,10 +56,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     const int ntile = L % p.ntiles;
     L /= p.ntiles;
     const int mtile = L % p.mtiles;
-    const int split = L / p.mtiles;
+    L /= p.mtiles;
+    int phase = 0;
+    if (PHASE) {
+        phase = L & 3;
+        L >>= 2;
+    }
+    const int split = L;
     const int mbase = mtile * BM;
     const int c_begin = split * p.chunks_per_split;
     const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+    // tap (ty,tx) reads input pixel (y + ty + oy, x + tx + ox)
+    const int oy = PHASE ? ((phase >> 1) ? 0 : -1) : -(KH / 2);
+    const int ox = PHASE ? ((phase & 1) ? 0 : -1) : -(KW / 2);
 
     // ---- operand loader state: this thread stages rows arow+32j, 16 bytes at column acol
     const int arow = tid >> 3, acol = (tid & 7) * 4;
@@ -83,12 +78,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     for (int j = 0; j < A_PER; ++j) {
         const int m = mbase + arow + 32 * j;
         if (m < p.M) {
-            const int q = m >> 2, jj = m & 3;
-            const int qx = q % Wq, t = q / Wq;
-            const int qy = t % Hq, b = t / Hq;
-            ry[j] = 2 * qy + (jj >> 1);
-            rx[j] = 2 * qx + (jj & 1);
-            rb[j] = b * p.Hin * p.Win;
+            int b;
+            quad_decode(m, Hq, Wq, b, ry[j], rx[j]);
+            rb[j] = b * p.H * p.W;
         } else {
             ry[j] = -(1 << 20);  // never inside the image
             rx[j] = 0;
@@ -104,11 +96,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.in1 ? p.in1 : p.in0), 0, p.in1 ? p.in1_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
+    const int wtile = (phase * p.ntiles + ntile) * p.nchunks;
 
     u32x4 av[A_PER], bv[B_PER];
     auto load_chunk = [&](int ci) {
         const int cc = ci / T, tap = ci - cc * T;
-        const int dy = tap / KS - P, dx = tap % KS - P;
+        const int dy = tap / KW + oy, dx = tap % KW + ox;
         const int c0 = cc * BK;
         const bool first = c0 < p.C0;
         const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
@@ -116,16 +109,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
         const int coff = (first ? c0 : c0 - p.C0) + acol;
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
-            int yy = ry[j] + dy, xx = rx[j] + dx;
+            const int yy = ry[j] + dy, xx = rx[j] + dx;
             const bool ok = ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
-            if (p.up) {
-                yy >>= 1;
-                xx >>= 1;
-            }
-            const unsigned off = ok ? (unsigned)((rb[j] + yy * p.Win + xx) * C + coff) * 4u : OOB;
+            const unsigned off = ok ? (unsigned)((rb[j] + yy * p.W + xx) * C + coff) * 4u : OOB;
             av[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
         }
-        const unsigned woff = (unsigned)((ntile * p.nchunks + ci) * (BN * BK) + tid * 4) * 4u;
+        const unsigned woff = (unsigned)((wtile + ci) * (BN * BK) + tid * 4) * 4u;
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) bv[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, woff + j * 4096u, 0, 0);
     };
@@ -139,12 +128,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     };
 
     f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    static_for<MT>([&](auto ic) {
+        static_for<NT>([&](auto jc) {
+            static_for<16>([&](auto rc) { acc[decltype(ic)::value][decltype(jc)::value][decltype(rc)::value] = 0.f; });
+        });
+    });
 
     auto compute = [&](int st) {
         const float* a_base = As + st * BM * LDK + (wm * MT * 32 + l31) * LDK + half * 4;
@@ -174,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
         int st = 0;
         for (int ci = c_begin; ci < c_end; ++ci) {
             const bool more = ci + 1 < c_end;
-            if (more) load_chunk(ci + 1);  // global loads in flight under the MFMAs
+            if (more) load_chunk(ci + 1);  // buffer loads in flight under the MFMAs
             compute(st);
             if (more) store_chunk(st ^ 1);
             __syncthreads();
@@ -183,99 +171,45 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     }
 
     // ---- epilogue
-    if (p.partial != nullptr) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = ntile * BN + wn * NT * 32 + j * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    p.partial[((size_t)split * p.Mpad + m) * p.Npad + n] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = ntile * BN + wn * NT * 32 + j * 32 + l31;
-            const bool nok = n < p.Cout;
-            const float bias = p.bias[n];
-            float s2 = 0.f, t2 = 0.f;
-            if (p.out2 != nullptr && nok) {
-                s2 = p.s2[n];
-                t2 = p.t2[n];
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int m0 = mbase + wm * MT * 32 + i * 32 + 8 * g + 4 * half;  // first pixel of a quad
-                if (m0 >= p.M || !nok) continue;
-                const int q = m0 >> 2;
-                if (p.pool) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v += apply_act(acc[i][j][4 * g + e] + bias, p.act);
-                    p.out[(size_t)q * p.Cout + n] = 0.25f * v;
-                } else {
-                    const int qx = q % Wq, t = q / Wq;
-                    const int qy = t % Hq, b = t / Hq;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int y = 2 * qy + (e >> 1), x = 2 * qx + (e & 1);
-                        const size_t pix = (size_t)(b * p.H + y) * p.W + x;
-                        float v = acc[i][j][4 * g + e] + bias;
-                        if (p.resid != nullptr) v += p.resid[pix * p.Cout + n];
-                        v = apply_act(v, p.act);
-                        if (p.nchw)
-                            p.out[((size_t)(b * p.Cout + n) * p.H + y) * p.W + x] = v;
-                        else
-                            p.out[pix * p.Cout + n] = v;
-                        if (p.out2 != nullptr) p.out2[pix * p.Cout + n] = fmaxf(fmaf(v, s2, t2), 0.f);
-                    }
-                }
-            }
-        }
+    conv_epilogue<MT, NT, BN>(p, acc, mbase, ntile, wm, wn, l31, half, phase, split);
 }
 
-// Split-K slab reduction + the same epilogue as the fused path (bias, residual, activation, 2x2
-// average pool, NCHW store, next-block pre-activation).
+// Split-K slab reduction + the same epilogue as the fused path.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs p, int splits) {
     const int rows = p.pool ? (p.M >> 2) : p.M;
-    const size_t total = (size_t)rows * p.Cout;
+    const size_t per_phase = (size_t)rows * p.Cout;
+    const size_t total = per_phase * p.nphase;
     const float* __restrict__ partial = p.partial;
+    const size_t slab = (size_t)p.Mpad * p.Npad;
     const int Wq = p.W >> 1, Hq = p.H >> 1;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int n = (int)(idx % p.Cout);
-        const int r = (int)(idx / p.Cout);
-        const float b = p.bias[n];
+        const int phase = (int)(idx / per_phase);
+        const size_t rem = idx - (size_t)phase * per_phase;
+        const int n = (int)(rem % p.Cout);
+        const int r = (int)(rem / p.Cout);
+        const float bias = p.bias[n];
         if (p.pool) {
             float v = 0.f;
             for (int e = 0; e < 4; ++e) {
                 float s = 0.f;
-                for (int sp = 0; sp < splits; ++sp) s += partial[((size_t)sp * p.Mpad + 4 * r + e) * p.Npad + n];
-                v += apply_act(s + b, p.act);
+                for (int sp = 0; sp < splits; ++sp)
+                    s += partial[(size_t)(sp * p.nphase + phase) * slab + (size_t)(4 * r + e) * p.Npad + n];
+                v += apply_act(s + bias, p.act);
             }
             p.out[(size_t)r * p.Cout + n] = 0.25f * v;
         } else {
             float s = 0.f;
-            for (int sp = 0; sp < splits; ++sp) s += partial[((size_t)sp * p.Mpad + r) * p.Npad + n];
-            const int q = r >> 2, e = r & 3;
-            const int qx = q % Wq, t = q / Wq;
-            const int qy = t % Hq, bb = t / Hq;
-            const int y = 2 * qy + (e >> 1), x = 2 * qx + (e & 1);
-            const size_t pix = (size_t)(bb * p.H + y) * p.W + x;
-            float v = s + b;
-            if (p.resid != nullptr) v += p.resid[pix * p.Cout + n];
-            v = apply_act(v, p.act);
-            if (p.nchw)
-                p.out[((size_t)(bb * p.Cout + n) * p.H + y) * p.W + x] = v;
-            else
-                p.out[pix * p.Cout + n] = v;
-            if (p.out2 != nullptr) p.out2[pix * p.Cout + n] = fmaxf(fmaf(v, p.s2[n], p.t2[n]), 0.f);
+            for (int sp = 0; sp < splits; ++sp)
+                s += partial[(size_t)(sp * p.nphase + phase) * slab + (size_t)r * p.Npad + n];
+            int b, y, x;
+            quad_decode(r, Hq, Wq, b, y, x);
+            float s2 = 0.f, t2 = 0.f;
+            if (p.out2 != nullptr) {
+                s2 = p.s2[n];
+                t2 = p.t2[n];
+            }
+            epilogue_store(p, phase, b, y, x, n, s + bias, s2, t2);
         }
     }
 }
@@ -289,17 +223,17 @@ int conv_tile_n(int Cout) {
     return 32;
 }
 
-size_t conv_packed_elems(int ks, int cin_packed, int Cout, int BN) {
+size_t conv_packed_elems(int taps, int cin_packed, int Cout, int BN, int nphase) {
     const int ntiles = (Cout + BN - 1) / BN;
-    return (size_t)ntiles * BN * ks * ks * cin_packed;
+    return (size_t)nphase * ntiles * BN * taps * cin_packed;
 }
 
-void conv_pack_host(const float* w, int Cout, int Cin, int ks, const int* cin_map, int cin_packed, int BN,
-                    float* dst) {
-    const int T = ks * ks, BK = CONV_BK;
+// w: [Cout][Cin][taps] (taps row-major kh*KW+kw) -> dst [ntiles][nchunks][BN][BK]
+static void pack_one(const float* w, int Cout, int Cin, int T, const int* cin_map, int cin_packed, int BN,
+                     bool swizzle, float* dst) {
+    const int BK = CONV_BK;
     const int ntiles = (Cout + BN - 1) / BN;
     const int nchunks = T * (cin_packed / BK);
-    std::memset(dst, 0, sizeof(float) * conv_packed_elems(ks, cin_packed, Cout, BN));
     for (int nt = 0; nt < ntiles; ++nt)
         for (int ci = 0; ci < nchunks; ++ci) {
             const int cc = ci / T, tap = ci % T;
@@ -310,23 +244,71 @@ void conv_pack_host(const float* w, int Cout, int Cin, int ks, const int* cin_ma
                 for (int kl = 0; kl < BK; ++kl) {
                     const int c = cin_map ? cin_map[cc * BK + kl] : cc * BK + kl;
                     if (c < 0 || c >= Cin) continue;
-                    tile[nl * BK + kl] = w[((size_t)o * Cin + c) * T + tap];
+                    // LDS-DMA kernels copy the tile linearly into an XOR-swizzled LDS image: 16-byte slot q of
+                    // row r lives at slot q ^ ((r >> 1) & 7) (conv_mfma_dma.hip)
+                    const int kk = swizzle ? ((((kl >> 2) ^ ((nl >> 1) & 7)) << 2) | (kl & 3)) : kl;
+                    tile[nl * BK + kk] = w[((size_t)o * Cin + c) * T + tap];
                 }
             }
         }
 }
 
+bool conv_dma_tile(int dma_cfg, int* BM, int* BN) {
+    switch (dma_cfg) {
+        case 1: *BM = 256; *BN = 256; return true;   // 8 waves, 64x128 per wave
+        case 2: *BM = 256; *BN = 128; return true;   // 8 waves, 64x64 per wave
+        case 3: *BM = 512; *BN = 64; return true;    // 8 waves, 64x64 per wave
+        default: return false;
+    }
+}
+
+void conv_pack_host(const float* w, int Cout, int Cin, int kh, int kw, const int* cin_map, int cin_packed, int BN,
+                    bool phase, bool swizzle, float* dst) {
+    if (!phase) {
+        std::memset(dst, 0, sizeof(float) * conv_packed_elems(kh * kw, cin_packed, Cout, BN, 1));
+        pack_one(w, Cout, Cin, kh * kw, cin_map, cin_packed, BN, swizzle, dst);
+        return;
+    }
+    // nearest-x2 followed by 3x3 (pad 1): output row 2y+py reads up-sampled rows 2y+py-1..2y+py+1, i.e.
+    // input rows {y-1: ky=0 | y: ky=1,2} for py=0 and {y: ky=0,1 | y+1: ky=2} for py=1 (same along x).
+    // Taps that hit the same input pixel are summed (in double) into a 2x2 filter per phase.
+    const size_t per_phase = conv_packed_elems(4, cin_packed, Cout, BN, 1);
+    std::memset(dst, 0, sizeof(float) * per_phase * 4);
+    std::vector<float> w4((size_t)Cout * Cin * 4);
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        for (size_t oc = 0; oc < (size_t)Cout * Cin; ++oc) {
+            const float* s = w + oc * 9;
+            for (int ty = 0; ty < 2; ++ty)
+                for (int tx = 0; tx < 2; ++tx) {
+                    double acc = 0.0;
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int my = py == 0 ? (ky == 0 ? 0 : 1) : (ky == 2 ? 1 : 0);
+                        if (my != ty) continue;
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int mx = px == 0 ? (kx == 0 ? 0 : 1) : (kx == 2 ? 1 : 0);
+                            if (mx == tx) acc += (double)s[ky * 3 + kx];
+                        }
+                    }
+                    w4[oc * 4 + ty * 2 + tx] = (float)acc;
+                }
+        }
+        pack_one(w4.data(), Cout, Cin, 4, cin_map, cin_packed, BN, swizzle, dst + per_phase * ph);
+    }
+}
+
 ConvPlan conv_plan(const ConvLayer& L, int M, int force_splits) {
     ConvPlan pl;
-    const int BM = 128;
+    const int BM = L.BM;
+    const int nphase = L.phase ? 4 : 1;
     pl.mtiles = (M + BM - 1) / BM;
     pl.ntiles = L.ntiles;
-    const int blocks = pl.mtiles * pl.ntiles;
+    const int blocks = pl.mtiles * pl.ntiles * nphase;
     int splits = 1;
     if (force_splits > 0) {
         splits = force_splits;
     } else if (blocks < 192) {
-        // deep hourglass levels: too few output tiles to fill 256 CUs -> slice K instead
+        // deep hourglass levels / small batches: too few output tiles for 256 CUs -> slice K instead
         splits = (256 + blocks - 1) / blocks;
         splits = std::min(splits, std::max(1, L.nchunks / 8));
     }
@@ -335,16 +317,16 @@ ConvPlan conv_plan(const ConvLayer& L, int M, int force_splits) {
     pl.splits = (L.nchunks + pl.chunks_per_split - 1) / pl.chunks_per_split;
     pl.Mpad = pl.mtiles * BM;
     pl.Npad = pl.ntiles * L.BN;
-    pl.partial_elems = pl.splits > 1 ? (size_t)pl.splits * pl.Mpad * pl.Npad : 0;
+    pl.partial_elems = pl.splits > 1 ? (size_t)pl.splits * nphase * pl.Mpad * pl.Npad : 0;
     return pl;
 }
 
-template <int KS, int MT, int NT, int WM, int WN>
+template <int KH, int KW, int MT, int NT, int WM, int WN, bool PHASE>
 static hipError_t launch_cfg(const ConvArgs& a, int blocks, hipStream_t stream) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * CONV_LDK;
-    auto kern = conv_mfma_kernel<KS, MT, NT, WM, WN>;
-    static bool configured = false;  // per instantiation; the attribute is per-device but all devices share the value
+    auto kern = conv_mfma_kernel<KH, KW, MT, NT, WM, WN, PHASE>;
+    static bool configured = false;  // per instantiation (one process drives one device)
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -355,6 +337,14 @@ static hipError_t launch_cfg(const ConvArgs& a, int blocks, hipStream_t stream) 
     return hipGetLastError();
 }
 
+template <int KH, int KW, bool PHASE>
+static hipError_t launch_tile(int BN, const ConvArgs& a, int blocks, hipStream_t stream) {
+    if (BN == 128) return launch_cfg<KH, KW, 2, 2, 2, 2, PHASE>(a, blocks, stream);
+    if (BN == 64) return launch_cfg<KH, KW, 2, 1, 2, 2, PHASE>(a, blocks, stream);
+    if (BN == 32) return launch_cfg<KH, KW, 1, 1, 4, 1, PHASE>(a, blocks, stream);
+    return hipErrorInvalidValue;
+}
+
 hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream, int force_splits) {
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -362,17 +352,15 @@ hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream,
     a.in1 = io.in1;
     a.C0 = L.C0;
     a.C1 = L.C1;
-    a.Hin = io.Hin;
-    a.Win = io.Win;
-    a.up = io.up;
-    a.H = io.Hin << io.up;
-    a.W = io.Win << io.up;
+    a.H = io.Hin;
+    a.W = io.Win;
+    a.nphase = L.phase ? 4 : 1;
     a.M = io.B * a.H * a.W;
     a.w = L.w;
     {   // buffer-descriptor ranges (32-bit): every tensor the loader touches must stay below 4 GiB
         const size_t px = (size_t)io.B * io.Hin * io.Win;
         const size_t b0 = px * L.C0 * sizeof(float), b1 = px * L.C1 * sizeof(float);
-        const size_t bw = (size_t)L.ntiles * L.nchunks * L.BN * CONV_BK * sizeof(float);
+        const size_t bw = (size_t)a.nphase * L.ntiles * L.nchunks * L.BN * CONV_BK * sizeof(float);
         if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
         a.in0_bytes = (unsigned)b0;
         a.in1_bytes = (unsigned)b1;
@@ -399,22 +387,19 @@ hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream,
     a.t2 = io.t2;
     if ((a.H & 1) || (a.W & 1)) return hipErrorInvalidValue;
     if (pl.splits > 1 && io.partial == nullptr) return hipErrorInvalidValue;
-    const int blocks = pl.mtiles * pl.ntiles * pl.splits;
+    if (L.phase && io.pool) return hipErrorInvalidValue;
+    const int blocks = pl.mtiles * pl.ntiles * a.nphase * pl.splits;
     hipError_t e = hipErrorInvalidValue;
-    if (L.ks == 3) {
-        if (L.BN == 128) e = launch_cfg<3, 2, 2, 2, 2>(a, blocks, stream);
-        else if (L.BN == 64) e = launch_cfg<3, 2, 1, 2, 2>(a, blocks, stream);
-        else if (L.BN == 32) e = launch_cfg<3, 1, 1, 4, 1>(a, blocks, stream);
-    } else if (L.ks == 7) {
-        if (L.BN == 128) e = launch_cfg<7, 2, 2, 2, 2>(a, blocks, stream);
-        else if (L.BN == 64) e = launch_cfg<7, 2, 1, 2, 2>(a, blocks, stream);
-        else if (L.BN == 32) e = launch_cfg<7, 1, 1, 4, 1>(a, blocks, stream);
-    }
+    if (L.dma_cfg > 0) e = conv_dma_launch_kernel(L, a, blocks, stream);
+    else if (L.phase) e = launch_tile<2, 2, true>(L.BN, a, blocks, stream);
+    else if (L.kh == 3 && L.kw == 3) e = launch_tile<3, 3, false>(L.BN, a, blocks, stream);
+    else if (L.kh == 7 && L.kw == 7) e = launch_tile<7, 7, false>(L.BN, a, blocks, stream);
+    else if (L.kh == 7 && L.kw == 1) e = launch_tile<7, 1, false>(L.BN, a, blocks, stream);
     if (e != hipSuccess) return e;
     if (pl.splits > 1) {
         const int rows = io.pool ? (a.M >> 2) : a.M;
-        const size_t total = (size_t)rows * L.Cout;
-        const int rb = (int)std::min<size_t>((total + 255) / 256, 2048);
+        const size_t total = (size_t)rows * L.Cout * a.nphase;
+        const int rb = (int)std::min<size_t>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, stream, a, pl.splits);
         e = hipGetLastError();
     }

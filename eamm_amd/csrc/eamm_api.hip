@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -31,6 +32,13 @@ struct HostTensor {
 };
 
 thread_local std::string g_create_error;
+
+// A convolution layer packed for the register-staged 128 x BN kernel and, where it pays, also for an LDS-DMA
+// big-tile kernel; conv launches pick by problem size (see pick()).
+struct LayerSet {
+    ConvLayer base, dma, big;
+    bool has_dma = false, has_big = false;
+};
 
 }  // namespace
 
@@ -54,9 +62,14 @@ struct eamm_ctx {
 
     // layers
     ConvLayer first, final_conv, head;
-    std::vector<ConvLayer> down, hg_enc, hg_dec, res1, res2, up;
+    std::vector<LayerSet> down, hg_enc, hg_dec, res1, res2, up;
+    int dma_min_m = 1024;       // smallest per-phase M for which an LDS-DMA tile is preferred
+    int big_min_m = 49152;      // ... and for which Cout % 256 == 0 layers use the 256x256 tile (>= 192 M tiles)
+    int dma_cfg_n256 = 2, dma_cfg_n128 = 2, dma_cfg_n64 = 3;
     std::vector<float*> pre_s, pre_t;  // res-block pre-activation scale/shift (norm1)
     float* aa_w = nullptr;
+    float* final_bias = nullptr;   // bias of the final conv, applied by the shift-sum kernel
+    float* final_part = nullptr;   // [F,H,W,32] (dx,co) partial products of the final 7x7 conv
     std::vector<void*> owned;   // every device allocation, freed in destroy
 
     // source cache (exportable): feat [S,hf,wf,Cb], src_small [S,h,w,4], src_full [S,3,H,W]
@@ -137,8 +150,15 @@ struct FoldSpec {
     std::string norm;            // key prefix holding BatchNorm stats, or empty
 };
 
+enum LayerMode { MODE_PLAIN = 0, MODE_PHASE = 1, MODE_ROWSPLIT = 2 };
+
+// MODE_PLAIN: ks x ks convolution.  MODE_PHASE: ks must be 3; the layer consumes the low-resolution input of an
+// UpBlock2d and evaluates "nearest x2 + 3x3" as four 2x2 phase filters.  MODE_ROWSPLIT: ks x 1 convolution with
+// N = (dx, co) -- the horizontal taps become output channels, gathered afterwards by final_shift_sum; the bias is
+// returned in *row_bias instead of being applied by the convolution.
 int build_layer(eamm_ctx* c, const std::vector<FoldSpec>& parts, int ks, int C0_real, int C0_packed, int C1_real,
-                int C1_packed, ConvLayer* L) {
+                int C1_packed, ConvLayer* L, LayerMode mode = MODE_PLAIN, std::vector<float>* row_bias = nullptr,
+                int dma_cfg = 0) {
     // `parts` are stacked along Cout (the flow head stacks mask + occlusion into one convolution)
     const int Cin = C0_real + C1_real;
     const int T = ks * ks;
@@ -185,20 +205,75 @@ int build_layer(eamm_ctx* c, const std::vector<FoldSpec>& parts, int ks, int C0_
     std::vector<int> map(cin_packed, -1);
     for (int i = 0; i < C0_real; ++i) map[i] = i;
     for (int i = 0; i < C1_real; ++i) map[C0_packed + i] = C0_real + i;
-    L->ks = ks;
+    int kh = ks, kw = ks;
+    if (mode == MODE_ROWSPLIT) {
+        // w'[dx*Cout+co][c][dy] = w[co][c][dy][dx]
+        std::vector<float> wr((size_t)ks * Cout * Cin * ks);
+        for (int dx = 0; dx < ks; ++dx)
+            for (int co = 0; co < Cout; ++co)
+                for (int ci = 0; ci < Cin; ++ci)
+                    for (int dy = 0; dy < ks; ++dy)
+                        wr[((size_t)(dx * Cout + co) * Cin + ci) * ks + dy] = wf[((size_t)co * Cin + ci) * T + dy * ks + dx];
+        if (row_bias) *row_bias = bf;
+        wf.swap(wr);
+        Cout = ks * Cout;
+        bf.assign(Cout, 0.f);
+        kw = 1;
+    }
+    if (mode == MODE_PHASE && ks != 3) return fail(c, EAMM_ERR_ARG, "phase mode needs a 3x3 convolution");
+    L->kh = kh;
+    L->kw = kw;
+    L->phase = mode == MODE_PHASE;
     L->C0 = C0_packed;
     L->C1 = C1_packed;
     L->Cout = Cout;
+    L->BM = 128;
     L->BN = conv_tile_n(Cout);
+    L->dma_cfg = dma_cfg;
+    if (dma_cfg > 0 && !conv_dma_tile(dma_cfg, &L->BM, &L->BN)) return fail(c, EAMM_ERR_ARG, "unknown dma tile %d", dma_cfg);
     L->ntiles = (Cout + L->BN - 1) / L->BN;
-    L->nchunks = T * (cin_packed / CONV_BK);
-    std::vector<float> packed(conv_packed_elems(ks, cin_packed, Cout, L->BN));
-    conv_pack_host(wf.data(), Cout, Cin, ks, map.data(), cin_packed, L->BN, packed.data());
+    const int taps = L->phase ? 4 : kh * kw;
+    L->nchunks = taps * (cin_packed / CONV_BK);
+    std::vector<float> packed(conv_packed_elems(taps, cin_packed, Cout, L->BN, L->phase ? 4 : 1));
+    conv_pack_host(wf.data(), Cout, Cin, kh, kw, map.data(), cin_packed, L->BN, L->phase, dma_cfg > 0, packed.data());
     std::vector<float> bias_pad((size_t)L->ntiles * L->BN, 0.f);
     std::copy(bf.begin(), bf.end(), bias_pad.begin());
     int rc = upload(c, &L->w, packed);
     if (rc) return rc;
     return upload(c, &L->bias, bias_pad);
+}
+
+int build_set(eamm_ctx* c, const std::vector<FoldSpec>& parts, int C0_real, int C0_packed, int C1_real, int C1_packed,
+              LayerSet* S, LayerMode mode) {
+    int rc = build_layer(c, parts, 3, C0_real, C0_packed, C1_real, C1_packed, &S->base, mode);
+    if (rc) return rc;
+    const int Cout = S->base.Cout;
+    int cfg = 0;
+    if (Cout % 256 == 0) cfg = c->dma_cfg_n256;
+    else if (Cout % 128 == 0) cfg = c->dma_cfg_n128;
+    else if (Cout == 64) cfg = c->dma_cfg_n64;
+    if (cfg > 0 && c->dma_min_m >= 0) {
+        rc = build_layer(c, parts, 3, C0_real, C0_packed, C1_real, C1_packed, &S->dma, mode, nullptr, cfg);
+        if (rc) return rc;
+        S->has_dma = true;
+        if (Cout % 256 == 0 && cfg != 1 && c->big_min_m >= 0) {
+            rc = build_layer(c, parts, 3, C0_real, C0_packed, C1_real, C1_packed, &S->big, mode, nullptr, 1);
+            if (rc) return rc;
+            S->has_big = true;
+        }
+    }
+    return 0;
+}
+
+// Tile choice per launch (measured on MI355X, profiles/r01_convbench_*): M is the per-phase pixel count.
+const ConvLayer& pick(const eamm_ctx* c, const LayerSet& S, size_t M) {
+    if (S.has_big && M >= (size_t)c->big_min_m) return S.big;
+    return (S.has_dma && M >= (size_t)c->dma_min_m) ? S.dma : S.base;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -289,6 +364,12 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     for (int i = 0; i < c->nd; ++i) c->down_c.push_back(std::min(g.max_features, g.block_expansion << (i + 1)));
     for (int i = 0; i < c->nd; ++i) c->up_c.push_back(std::min(g.max_features, g.block_expansion << (c->nd - i - 1)));
     c->Cb = c->down_c.back();
+    // tuning knobs (defaults measured on MI355X, profiles/): EAMM_DMA_MIN_M < 0 disables the LDS-DMA kernels
+    c->dma_min_m = env_int("EAMM_DMA_MIN_M", c->dma_min_m);
+    c->big_min_m = env_int("EAMM_BIG_MIN_M", c->big_min_m);
+    c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
+    c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);
+    c->dma_cfg_n64 = env_int("EAMM_DMA_CFG_N64", c->dma_cfg_n64);
     *out = c;
     return EAMM_OK;
 }
@@ -341,7 +422,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
     for (int i = 0; i < c->nb; ++i) {
         const std::string p = dm + "hourglass.encoder.down_blocks." + std::to_string(i);
         const int cr = i == 0 ? cin0 : c->enc_c[i - 1], cp = i == 0 ? c->Cp0 : c->enc_c[i - 1];
-        if ((rc = build_layer(c, {{p + ".conv", p + ".norm"}}, 3, cr, cp, 0, 0, &c->hg_enc[i]))) return rc;
+        if ((rc = build_set(c, {{p + ".conv", p + ".norm"}}, cr, cp, 0, 0, &c->hg_enc[i], MODE_PLAIN))) return rc;
     }
     // hourglass decoder: u_i = UpBlock2d_i(cat[u_{i-1}, e_{nb-i}])  (util.py:981-987)
     c->hg_dec.resize(c->nb);
@@ -349,7 +430,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
         const std::string p = dm + "hourglass.decoder.up_blocks." + std::to_string(i);
         const int c0 = i == 0 ? c->enc_c[c->nb - 1] : c->dec_c[i - 1];
         const int c1 = i == 0 ? 0 : c->enc_c[c->nb - 1 - i];
-        if ((rc = build_layer(c, {{p + ".conv", p + ".norm"}}, 3, c0, c0, c1, c1, &c->hg_dec[i]))) return rc;
+        if ((rc = build_set(c, {{p + ".conv", p + ".norm"}}, c0, c0, c1, c1, &c->hg_dec[i], MODE_PHASE))) return rc;
     }
     // flow head: mask (K+1) and occlusion (1) 7x7 convolutions share one launch (dense_motion.py:98,110)
     {
@@ -362,7 +443,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
     c->down.resize(c->nd);
     for (int i = 0; i < c->nd; ++i) {
         const std::string p = "down_blocks." + std::to_string(i);
-        if ((rc = build_layer(c, {{p + ".conv", p + ".norm"}}, 3, c->down_c[i], c->down_c[i], 0, 0, &c->down[i])))
+        if ((rc = build_set(c, {{p + ".conv", p + ".norm"}}, c->down_c[i], c->down_c[i], 0, 0, &c->down[i], MODE_PLAIN)))
             return rc;
     }
     // bottleneck: conv1 absorbs norm2 (conv1 -> norm2 -> relu), norm1 becomes the producer's second output
@@ -373,8 +454,8 @@ int eamm_finalize_weights(eamm_ctx* c) {
     c->pre_t.resize(nr);
     for (int i = 0; i < nr; ++i) {
         const std::string r = "bottleneck.r" + std::to_string(i);
-        if ((rc = build_layer(c, {{r + ".conv1", r + ".norm2"}}, 3, c->Cb, c->Cb, 0, 0, &c->res1[i]))) return rc;
-        if ((rc = build_layer(c, {{r + ".conv2", ""}}, 3, c->Cb, c->Cb, 0, 0, &c->res2[i]))) return rc;
+        if ((rc = build_set(c, {{r + ".conv1", r + ".norm2"}}, c->Cb, c->Cb, 0, 0, &c->res1[i], MODE_PLAIN))) return rc;
+        if ((rc = build_set(c, {{r + ".conv2", ""}}, c->Cb, c->Cb, 0, 0, &c->res2[i], MODE_PLAIN))) return rc;
         const HostTensor *gm = find(c, r + ".norm1.weight"), *bt = find(c, r + ".norm1.bias"),
                          *mu = find(c, r + ".norm1.running_mean"), *vr = find(c, r + ".norm1.running_var");
         if ((int)gm->numel() != c->Cb || (int)bt->numel() != c->Cb || (int)mu->numel() != c->Cb ||
@@ -393,10 +474,16 @@ int eamm_finalize_weights(eamm_ctx* c) {
     for (int i = 0; i < c->nd; ++i) {
         const std::string p = "up_blocks." + std::to_string(i);
         const int ci = i == 0 ? c->Cb : c->up_c[i - 1];
-        if ((rc = build_layer(c, {{p + ".conv", p + ".norm"}}, 3, ci, ci, 0, 0, &c->up[i]))) return rc;
+        if ((rc = build_set(c, {{p + ".conv", p + ".norm"}}, ci, ci, 0, 0, &c->up[i], MODE_PHASE))) return rc;
     }
-    if ((rc = build_layer(c, {{"final", ""}}, 7, c->up_c.back(), c->up_c.back(), 0, 0, &c->final_conv))) return rc;
-    if (c->final_conv.Cout != 3) return fail(c, EAMM_ERR_KEY, "final.weight must have 3 output channels");
+    {   // final 7x7 (Cout = 3): 7x1 MFMA convolution over (dx, co) + horizontal gather
+        std::vector<float> fb;
+        if ((rc = build_layer(c, {{"final", ""}}, 7, c->up_c.back(), c->up_c.back(), 0, 0, &c->final_conv,
+                              MODE_ROWSPLIT, &fb)))
+            return rc;
+        if (c->final_conv.Cout != 21) return fail(c, EAMM_ERR_KEY, "final.weight must have 3 output channels");
+        if ((rc = upload(c, &c->final_bias, fb))) return rc;
+    }
     // anti-alias buffer [3,1,13,13]
     {
         std::vector<float> aa(3 * 169, 0.f);
@@ -435,6 +522,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
     if ((rc = dev_alloc(c, &c->xb, F * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->act, F * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->tmp, F * hwf * c->Cb))) return rc;
+    if ((rc = dev_alloc(c, &c->final_part, F * HW * 32))) return rc;
     c->up_buf.resize(c->nd);
     for (int i = 0; i < c->nd; ++i)
         if ((rc = dev_alloc(c, &c->up_buf[i], F * (hwf << (2 * (i + 1))) * c->up_c[i]))) return rc;
@@ -442,20 +530,25 @@ int eamm_finalize_weights(eamm_ctx* c) {
     // can pick more K slices than the full one); conv_launch also clamps its slice count to the slab.
     {
         size_t need = 0;
-        auto upd = [&](const ConvLayer& L, size_t M) { need = std::max(need, conv_plan(L, (int)M).partial_elems); };
+        auto upd1 = [&](const ConvLayer& L, size_t M) { need = std::max(need, conv_plan(L, (int)M).partial_elems); };
+        auto upd = [&](const LayerSet& S, size_t M) {
+            upd1(S.base, M);
+            if (S.has_dma) upd1(S.dma, M);
+            if (S.has_big) upd1(S.big, M);
+        };
         for (size_t f = 1; f <= S; ++f) {
-            upd(c->first, f * HW);
+            upd1(c->first, f * HW);
             for (int i = 0; i < c->nd; ++i) upd(c->down[i], f * (HW >> (2 * i)));
         }
         for (size_t f = 1; f <= F; ++f) {
             for (int i = 0; i < c->nb; ++i) {
                 upd(c->hg_enc[i], f * (hw >> (2 * i)));
-                upd(c->hg_dec[i], f * (hw >> (2 * (c->nb - 1 - i))));
+                upd(c->hg_dec[i], f * (hw >> (2 * (c->nb - i))));
             }
-            upd(c->head, f * hw);
+            upd1(c->head, f * hw);
             upd(c->res1[0], f * hwf);
-            for (int i = 0; i < c->nd; ++i) upd(c->up[i], f * (hwf << (2 * (i + 1))));
-            upd(c->final_conv, f * HW);
+            for (int i = 0; i < c->nd; ++i) upd(c->up[i], f * (hwf << (2 * i)));
+            upd1(c->final_conv, f * HW);
         }
         c->partial_elems = need;
         if ((rc = dev_alloc(c, &c->partial, c->partial_elems))) return rc;
@@ -469,7 +562,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
         double ff = 0;
         for (int i = 0; i < c->nb; ++i) {
             ff += conv_flops(3, i == 0 ? cin0 : c->enc_c[i - 1], c->enc_c[i], (double)(hw >> (2 * i)));
-            const int ci = c->hg_dec[i].C0 + c->hg_dec[i].C1;
+            const int ci = c->hg_dec[i].base.C0 + c->hg_dec[i].base.C1;
             ff += conv_flops(3, ci, c->dec_c[i], (double)(hw >> (2 * (c->nb - 1 - i))));
         }
         ff += conv_flops(7, c->dec_c.back() + cin0, c->K + 1 + (g.estimate_occlusion_map ? 1 : 0), (double)hw);
@@ -516,7 +609,7 @@ int eamm_encode_source(eamm_ctx* c, const float* source, int ns, void* stream_) 
         d.out = (i == c->nd - 1) ? c->feat : c->enc_tmp[i + 1];
         d.partial = c->partial;
         d.partial_cap = c->partial_elems;
-        HIP_TRY(c, conv_launch(c->down[i], d, s));
+        HIP_TRY(c, conv_launch(pick(c, c->down[i], (size_t)ns * d.Hin * d.Win), d, s));
     }
     c->ns_cached = ns;
     return EAMM_OK;
@@ -567,7 +660,7 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         io.out = c->e_buf[i];
         io.partial = c->partial;
         io.partial_cap = c->partial_elems;
-        HIP_TRY(c, conv_launch(c->hg_enc[i], io, s));
+        HIP_TRY(c, conv_launch(pick(c, c->hg_enc[i], (size_t)n * io.Hin * io.Win), io, s));
     }
     STAGE_MARK(2);
     // hourglass decoder: nearest x2 and the skip concatenation are folded into the operand loader
@@ -578,12 +671,11 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         io.B = n;
         io.Hin = h >> (c->nb - i);
         io.Win = w >> (c->nb - i);
-        io.up = 1;
         io.act = ACT_RELU;
         io.out = c->u_buf[i];
         io.partial = c->partial;
         io.partial_cap = c->partial_elems;
-        HIP_TRY(c, conv_launch(c->hg_dec[i], io, s));
+        HIP_TRY(c, conv_launch(pick(c, c->hg_dec[i], (size_t)n * io.Hin * io.Win), io, s));
     }
     STAGE_MARK(3);
     // mask / occlusion logits, then softmax + flow combine + sigmoid         dense_motion.py:98-111
@@ -628,7 +720,7 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         a.out = c->tmp;
         a.partial = c->partial;
         a.partial_cap = c->partial_elems;
-        HIP_TRY(c, conv_launch(c->res1[i], a, s));
+        HIP_TRY(c, conv_launch(pick(c, c->res1[i], (size_t)n * hf * wf), a, s));
         ConvIO b{};
         b.in0 = c->tmp;
         b.B = n;
@@ -644,7 +736,7 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         }
         b.partial = c->partial;
         b.partial_cap = c->partial_elems;
-        HIP_TRY(c, conv_launch(c->res2[i], b, s));
+        HIP_TRY(c, conv_launch(pick(c, c->res2[i], (size_t)n * hf * wf), b, s));
         std::swap(x, xn);
     }
     STAGE_MARK(6);
@@ -656,12 +748,11 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         io.B = n;
         io.Hin = hf << i;
         io.Win = wf << i;
-        io.up = 1;
         io.act = ACT_RELU;
         io.out = c->up_buf[i];
         io.partial = c->partial;
         io.partial_cap = c->partial_elems;
-        HIP_TRY(c, conv_launch(c->up[i], io, s));
+        HIP_TRY(c, conv_launch(pick(c, c->up[i], (size_t)n * io.Hin * io.Win), io, s));
         cur = c->up_buf[i];
     }
     STAGE_MARK(7);
@@ -672,12 +763,14 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         io.B = n;
         io.Hin = c->H;
         io.Win = c->W;
-        io.act = ACT_SIGMOID;
-        io.nchw = 1;
-        io.out = o->prediction;
+        io.act = ACT_NONE;
+        io.out = c->final_part;
         io.partial = c->partial;
         io.partial_cap = c->partial_elems;
-        HIP_TRY(c, conv_launch(c->final_conv, io, s));
+        ConvLayer fl = c->final_conv;
+        fl.Cout = 32;  // 32-float pixel stride; channels >= 21 have zero weights
+        HIP_TRY(c, conv_launch(fl, io, s));
+        HIP_TRY(c, final_shift_sum_launch(c->final_part, c->final_bias, n, c->H, c->W, o->prediction, s));
     }
     if (o->frames_u8) HIP_TRY(c, to_u8_launch(o->prediction, n, c->H, c->W, o->frames_u8, s));
     STAGE_MARK(8);
@@ -770,23 +863,33 @@ double eamm_flops_per_frame(const eamm_ctx* c) { return c ? c->flops_frame : 0.0
 double eamm_encode_flops(const eamm_ctx* c) { return c ? c->flops_encode : 0.0; }
 
 int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int up,
-                 const float* w_host, const float* b_host, int Cout, int ks, int act, int pool, const float* resid,
-                 int splitk, int tile_n, float* out, int iters, float* avg_ms, void* stream_) {
-    if (!in0 || !w_host || !b_host || !out || (ks != 3 && ks != 7) || C0 % CONV_BK || C1 % CONV_BK)
+                 const float* w_host, const float* b_host, int Cout, int kh, int kw, int act, int pool,
+                 const float* resid, int splitk, int tile_n, float* out, int iters, float* avg_ms, void* stream_) {
+    const bool shape_ok = (kh == 3 && kw == 3) || (kh == 7 && kw == 7) || (kh == 7 && kw == 1);
+    if (!in0 || !w_host || !b_host || !out || !shape_ok || C0 % CONV_BK || C1 % CONV_BK || (up && (kh != 3 || kw != 3)))
         return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: bad argument");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     ConvLayer L;
-    L.ks = ks;
+    L.kh = kh;
+    L.kw = kw;
+    L.phase = up != 0;
     L.C0 = C0;
     L.C1 = C1;
     L.Cout = Cout;
     L.BN = tile_n > 0 ? tile_n : conv_tile_n(Cout);
-    if (L.BN != 32 && L.BN != 64 && L.BN != 128) return fail(nullptr, EAMM_ERR_ARG, "tile_n must be 32/64/128");
+    if (tile_n > 1000) {  // 1000 + id selects an LDS-DMA big-tile configuration
+        L.dma_cfg = tile_n - 1000;
+        if (!conv_dma_tile(L.dma_cfg, &L.BM, &L.BN) || kw == 1 || kh == 7)
+            return fail(nullptr, EAMM_ERR_ARG, "unknown / unsupported dma tile");
+    } else if (L.BN != 32 && L.BN != 64 && L.BN != 128) {
+        return fail(nullptr, EAMM_ERR_ARG, "tile_n must be 32/64/128 or 1000+dma id");
+    }
     L.ntiles = (Cout + L.BN - 1) / L.BN;
-    L.nchunks = ks * ks * ((C0 + C1) / CONV_BK);
-    std::vector<float> packed(conv_packed_elems(ks, C0 + C1, Cout, L.BN));
-    conv_pack_host(w_host, Cout, C0 + C1, ks, nullptr, C0 + C1, L.BN, packed.data());
+    const int taps = L.phase ? 4 : kh * kw;
+    L.nchunks = taps * ((C0 + C1) / CONV_BK);
+    std::vector<float> packed(conv_packed_elems(taps, C0 + C1, Cout, L.BN, L.phase ? 4 : 1));
+    conv_pack_host(w_host, Cout, C0 + C1, kh, kw, nullptr, C0 + C1, L.BN, L.phase, L.dma_cfg > 0, packed.data());
     std::vector<float> bias((size_t)L.ntiles * L.BN, 0.f);
     std::copy(b_host, b_host + Cout, bias.begin());
     int rc = EAMM_OK;
@@ -810,7 +913,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
     OP_TRY(hipMalloc((void**)&L.bias, bias.size() * sizeof(float)));
     OP_TRY(hipMemcpy(L.w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
     OP_TRY(hipMemcpy(L.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
-    const int M = B * (Hin << up) * (Win << up);
+    const int M = B * Hin * Win;
     const ConvPlan pl = conv_plan(L, M, splitk);
     if (pl.partial_elems) OP_TRY(hipMalloc((void**)&partial, pl.partial_elems * sizeof(float)));
     ConvIO io{};
@@ -819,7 +922,6 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
     io.B = B;
     io.Hin = Hin;
     io.Win = Win;
-    io.up = up;
     io.act = act;
     io.pool = pool;
     io.resid = resid;

@@ -13,29 +13,28 @@ constexpr int KP_STRIDE = 8;          // per (frame, keypoint) record: kd.xy, ks
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
 
 // One convolution launch. Activations are NHWC fp32; the GEMM view is
-//   M = B*H*W output pixels (2x2-quad order), N = Cout, K = taps * (C0 + C1).
+//   M = B*H*W pixels (2x2-quad order), N = Cout, K = taps * (C0 + C1).
 struct ConvArgs {
-    const float* in0;      // [B,Hin,Win,C0]
-    const float* in1;      // [B,Hin,Win,C1] second half of a channel concatenation, or null
+    const float* in0;      // [B,H,W,C0]
+    const float* in1;      // [B,H,W,C1] second half of a channel concatenation, or null
     int C0, C1;            // multiples of CONV_BK
     unsigned in0_bytes, in1_bytes, w_bytes;  // buffer-descriptor ranges
-    int Hin, Win;          // stored input size
-    int up;                // 1: convolve the nearest-x2 up-sampled input (H = 2*Hin)
-    int H, W;              // convolution-space size (even)
+    int H, W;              // input size (even); phase mode writes a 2H x 2W output
+    int nphase;            // 1, or 4 = collapsed "nearest x2 + 3x3" (one 2x2 filter per output parity)
     int M;                 // B*H*W
-    const float* w;        // packed [ntiles][nchunks][BN][BK], BatchNorm already folded in
+    const float* w;        // packed [nphase][ntiles][nchunks][BN][BK], BatchNorm already folded in
     const float* bias;     // [ntiles*BN]
     int Cout;              // real output channels (= output stride)
     int nchunks;           // taps * (C0+C1)/BK
     int mtiles, ntiles;
     int chunks_per_split;  // K range of one split-K slice
     int Mpad, Npad;        // partial slab dims
-    float* partial;        // non-null: split-K, raw accumulators to [split][Mpad][Npad]
+    float* partial;        // non-null: split-K, raw accumulators to [split][phase][Mpad][Npad]
     int act;               // Act
     int pool;              // avgpool2x2 after the activation
-    int nchw;              // write out as [B,Cout,H,W] (final image) instead of NHWC
+    int nchw;              // write out as [B,Cout,H,W] instead of NHWC
     const float* resid;    // NHWC, added before the activation
-    float* out;            // NHWC [B,H,W,Cout] (or pooled [B,H/2,W/2,Cout])
+    float* out;            // NHWC [B,H,W,Cout] (pooled: [B,H/2,W/2,Cout]; phase: [B,2H,2W,Cout])
     float* out2;           // optional second output relu(out*s2 + t2): the next res-block's pre-activation
     const float* s2;
     const float* t2;
@@ -43,19 +42,25 @@ struct ConvArgs {
 
 // Packed convolution weights resident on the device.
 struct ConvLayer {
-    int ks = 0, C0 = 0, C1 = 0, Cout = 0;
-    int BN = 0, ntiles = 0, nchunks = 0;
+    int kh = 0, kw = 0, C0 = 0, C1 = 0, Cout = 0;
+    bool phase = false;     // UpBlock2d: nearest x2 + 3x3 as four 2x2 phase filters
+    int BM = 128, BN = 0, ntiles = 0, nchunks = 0;
+    int dma_cfg = 0;        // 0: register-staged 128 x BN kernel; >0: LDS-DMA big-tile kernel (conv_mfma_dma.hip)
     float* w = nullptr;     // device
     float* bias = nullptr;  // device, [ntiles*BN]
-    double flops_per_pixel() const { return 2.0 * ks * ks * (double)(C0 + C1) * Cout; }
 };
 
 int conv_tile_n(int Cout);
-size_t conv_packed_elems(int ks, int cin_packed, int Cout, int BN);
-// Host-side repack: OIHW (BatchNorm folded by the caller) -> [ntiles][nchunks][BN][BK].
-// cin_map[c] = original input channel of packed channel c, or -1 for zero padding.
-void conv_pack_host(const float* w_oihw, int Cout, int Cin, int ks, const int* cin_map, int cin_packed,
-                    int BN, float* dst);
+size_t conv_packed_elems(int taps, int cin_packed, int Cout, int BN, int nphase);
+// Host-side repack: [Cout][Cin][kh*kw] (BatchNorm folded by the caller) -> [nphase][ntiles][nchunks][BN][BK].
+// cin_map[c] = original input channel of packed channel c, or -1 for zero padding.  phase = true takes
+// 3x3 weights and emits the four collapsed 2x2 filters.
+void conv_pack_host(const float* w, int Cout, int Cin, int kh, int kw, const int* cin_map, int cin_packed, int BN,
+                    bool phase, bool swizzle, float* dst);
+// LDS-DMA tile configurations: id -> (BM, BN); returns false for an unknown id.
+bool conv_dma_tile(int dma_cfg, int* BM, int* BN);
+struct ConvArgs;
+hipError_t conv_dma_launch_kernel(const ConvLayer& L, const ConvArgs& a, int blocks, hipStream_t stream);
 
 struct ConvPlan {           // launch geometry of one layer at one problem size
     int mtiles, ntiles, splits, chunks_per_split, Mpad, Npad;
@@ -65,7 +70,7 @@ ConvPlan conv_plan(const ConvLayer& L, int M, int force_splits = 0);
 
 struct ConvIO {
     const float* in0; const float* in1;
-    int B, Hin, Win, up;
+    int B, Hin, Win;
     int act, pool, nchw;
     const float* resid;
     float* out; float* out2; const float* s2; const float* t2;
@@ -93,6 +98,8 @@ hipError_t warp_image_launch(const float* src /*[ns,3,H,W]*/, const float* defor
 hipError_t source_prepare_launch(const float* src /*[ns,3,H,W]*/, const float* aa_w /*[3,13,13] dev*/, int ns, int H,
                                  int W, int inv_scale, int Cpad, float* src_nhwc /*[ns,H,W,Cpad]*/,
                                  float* src_small /*[ns,h,w,4]*/, hipStream_t s);
+hipError_t final_shift_sum_launch(const float* part /*[n,H,W,32]: channel dx*3+co*/, const float* bias /*[3] dev*/,
+                                  int n, int H, int W, float* out /*[n,3,H,W]*/, hipStream_t s);
 hipError_t to_u8_launch(const float* pred /*[n,3,H,W]*/, int n, int H, int W, uint8_t* out /*[n,H,W,3]*/,
                         hipStream_t s);
 

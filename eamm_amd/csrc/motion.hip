@@ -389,6 +389,43 @@ __global__ __launch_bounds__(256) void antialias_down_kernel(const float* __rest
     dst[idx] = make_float4(acc[0], acc[1], acc[2], 0.f);
 }
 
+// Final 7x7 convolution, second half (generator.py:92-93).  The MFMA kernel ran it as a 7x1 (vertical)
+// convolution with N = (dx, co): part[b,y,x',dx*3+co] = sum_{dy,c} in[b,y+dy-3,x',c] * w[co,c,dy,dx].
+// Here the seven horizontal taps are gathered: out[b,co,y,x] = sigmoid(bias[co] + sum_dx part[b,y,x+dx-3,
+// dx*3+co]) (zero outside the row), written NCHW.  One block = one row segment of 128 pixels staged in
+// LDS (row stride 33 dwords: conflict-free for the per-pixel column walk).
+constexpr int FS_TILE = 128, FS_LD = 33;
+__global__ __launch_bounds__(128) void final_shift_sum_kernel(const float* __restrict__ part,
+                                                              const float* __restrict__ bias, int H, int W,
+                                                              float* __restrict__ out) {
+    __shared__ float tile[(FS_TILE + 6) * FS_LD];
+    const int x0 = blockIdx.x * FS_TILE, y = blockIdx.y, b = blockIdx.z;
+    const float4* row = reinterpret_cast<const float4*>(part + ((size_t)(b * H + y) * W) * 32);
+    for (int i = threadIdx.x; i < (FS_TILE + 6) * 8; i += blockDim.x) {
+        const int px = i >> 3, c4 = i & 7;
+        const int x = x0 + px - 3;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)x < (unsigned)W) v = row[(size_t)x * 8 + c4];
+        float* d = tile + px * FS_LD + c4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= W) return;
+    float acc[3] = {bias[0], bias[1], bias[2]};
+#pragma unroll
+    for (int dx = 0; dx < 7; ++dx) {
+        const float* s = tile + (threadIdx.x + dx) * FS_LD + dx * 3;
+        acc[0] += s[0];
+        acc[1] += s[1];
+        acc[2] += s[2];
+    }
+    const size_t plane = (size_t)H * W;
+#pragma unroll
+    for (int co = 0; co < 3; ++co)
+        out[((size_t)b * 3 + co) * plane + (size_t)y * W + x] = 1.f / (1.f + expf(-acc[co]));
+}
+
 // prediction [n,3,H,W] float -> [n,H,W,3] uint8 (img_as_ubyte rounding), the frame format demo.py:507 saves.
 __global__ __launch_bounds__(256) void to_u8_kernel(const float* __restrict__ pred, int n, int H, int W,
                                                     uint8_t* __restrict__ out) {
@@ -459,6 +496,13 @@ hipError_t source_prepare_launch(const float* src, const float* aa_w, int ns, in
     const size_t t2 = (size_t)ns * (H / inv_scale) * (W / inv_scale);
     hipLaunchKernelGGL(antialias_down_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, src, aa_w, ns, H, W,
                        inv_scale, reinterpret_cast<float4*>(src_small));
+    return hipGetLastError();
+}
+
+hipError_t final_shift_sum_launch(const float* part, const float* bias, int n, int H, int W, float* out,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL(final_shift_sum_kernel, dim3((W + FS_TILE - 1) / FS_TILE, H, n), dim3(FS_TILE), 0, s, part,
+                       bias, H, W, out);
     return hipGetLastError();
 }
 

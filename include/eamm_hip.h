@@ -151,15 +151,16 @@ int eamm_profile_read(eamm_ctx* ctx, double* stage_ms, int nstage, int64_t* call
  * the path on caller-provided device buffers so it can be compared with the oracle in isolation.
  */
 
-/* 3x3 / 7x7 convolution on NHWC activations as an fp32-MFMA implicit GEMM.
+/* KHxKW (3x3, 7x7 or 7x1) convolution on NHWC activations as an fp32-MFMA implicit GEMM.
  * in0/in1: [B,Hin,Win,C0|C1] (in1 optional: channel concatenation), weight: OIHW host pointer
- * [Cout,C0+C1,ks,ks], bias host [Cout]; up = 1 runs the conv on the nearest-x2 up-sampled input;
- * act: 0 none, 1 relu, 2 sigmoid; pool = 1 applies avgpool2x2 after the activation; resid: NHWC
- * tensor added before the activation; splitk 0 = automatic; tile_n 0 = automatic; out NHWC
- * [B,H(/2),W(/2),Cout].  iters > 0 additionally times `iters` back-to-back launches with HIP events
- * on `stream` and stores the average milliseconds in *avg_ms. */
+ * [Cout,C0+C1,kh,kw], bias host [Cout]; up = 1 (3x3 only) computes conv3x3(nearest_x2(input)) in its
+ * collapsed four-phase 2x2 form; act: 0 none, 1 relu, 2 sigmoid; pool = 1 applies avgpool2x2 after the
+ * activation; resid: NHWC tensor added before the activation; splitk 0 = automatic; tile_n 0 =
+ * automatic, 32/64/128 = register-staged 128 x tile_n kernel, 1000+id = LDS-DMA big-tile kernel (1: 256x256,
+ * 2: 256x128, 3: 512x64); out NHWC [B,H(/2),W(/2),Cout] with H = Hin << up.  iters > 0 additionally times `iters`
+ * back-to-back launches with HIP events on `stream` and stores the average milliseconds in *avg_ms. */
 int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int up,
-                 const float* weight_host, const float* bias_host, int Cout, int ks,
+                 const float* weight_host, const float* bias_host, int Cout, int kh, int kw,
                  int act, int pool, const float* resid, int splitk, int tile_n, float* out, int iters,
                  float* avg_ms, void* stream);
 

@@ -12,11 +12,11 @@ from eamm_amd import _lib
 pytestmark = pytest.mark.gpu
 
 
-def ref_conv(in0, in1, w, b, ks, up, act, pool, resid):
+def ref_conv(in0, in1, w, b, ks, kw, up, act, pool, resid):
     x = in0 if in1 is None else torch.cat([in0, in1], dim=1)
     if up:
         x = F.interpolate(x, scale_factor=2)  # nearest, as UpBlock2d (util.py:896)
-    y = F.conv2d(x, w, b, padding=ks // 2)
+    y = F.conv2d(x, w, b, padding=(ks // 2, kw // 2))
     if resid is not None:
         y = y + resid
     if act == 1:
@@ -32,16 +32,17 @@ def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
-def run_case(B, H, W, C0, C1, Cout, ks, up=0, act=0, pool=0, resid=False, splitk=0, tile_n=0, seed=0):
+def run_case(B, H, W, C0, C1, Cout, ks, kw=0, up=0, act=0, pool=0, resid=False, splitk=0, tile_n=0, seed=0):
+    kw = kw or ks
     g = torch.Generator().manual_seed(seed)
     cin = C0 + C1
     in0 = torch.randn(B, C0, H, W, generator=g)
     in1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
-    w = torch.randn(Cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+    w = torch.randn(Cout, cin, ks, kw, generator=g) * (2.0 / (cin * ks * kw)) ** 0.5
     b = 0.1 * torch.randn(Cout, generator=g)
     Ho, Wo = (H << up), (W << up)
     res = torch.randn(B, Cout, Ho, Wo, generator=g) if resid else None
-    want = ref_conv(in0, in1, w, b, ks, up, act, pool, res)
+    want = ref_conv(in0, in1, w, b, ks, kw, up, act, pool, res)
     dev = torch.device("cuda:0")
     d0 = nhwc(in0).to(dev)
     d1 = nhwc(in1).to(dev) if C1 else None
@@ -50,7 +51,7 @@ def run_case(B, H, W, C0, C1, Cout, ks, up=0, act=0, pool=0, resid=False, splitk
     L = _lib.lib()
     wc, bc = w.contiguous(), b.contiguous()
     rc = L.eamm_op_conv(0, d0.data_ptr(), C0, d1.data_ptr() if C1 else None, C1, B, H, W, up,
-                        wc.data_ptr(), bc.data_ptr(), Cout, ks, act, pool,
+                        wc.data_ptr(), bc.data_ptr(), Cout, ks, kw, act, pool,
                         dres.data_ptr() if resid else None, splitk, tile_n, out.data_ptr(), 0, None,
                         torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, None)
@@ -76,6 +77,21 @@ CASES = {
     "3x3_splitk4":       dict(B=1, H=8, W=8, C0=64, C1=0, Cout=64, ks=3, act=1, splitk=4),
     "3x3_tile64_as_32":  dict(B=1, H=16, W=16, C0=32, C1=0, Cout=64, ks=3, tile_n=32),
     "3x3_tile128_as_64": dict(B=1, H=16, W=16, C0=32, C1=0, Cout=128, ks=3, tile_n=64),
+    "3x3_up_tile128":    dict(B=1, H=16, W=16, C0=64, C1=0, Cout=128, ks=3, up=1, act=1),
+    "3x3_up_splitk3":    dict(B=1, H=4, W=6, C0=96, C1=32, Cout=64, ks=3, up=1, act=1, splitk=3),
+    "3x3_up_resid":      dict(B=1, H=8, W=8, C0=32, C1=0, Cout=32, ks=3, up=1, resid=True),
+    # LDS-DMA big-tile kernel (tile_n = 1000 + id): 256x256, 256x128, 512x64
+    "dma256_basic":      dict(B=2, H=16, W=16, C0=64, C1=0, Cout=256, ks=3, act=1, tile_n=1001),
+    "dma256_tails_res":  dict(B=1, H=10, W=14, C0=32, C1=0, Cout=272, ks=3, resid=True, tile_n=1001),
+    "dma256_pool":       dict(B=3, H=16, W=16, C0=64, C1=0, Cout=256, ks=3, act=1, pool=1, tile_n=1001),
+    "dma256_up_concat":  dict(B=2, H=8, W=8, C0=64, C1=32, Cout=256, ks=3, up=1, act=1, tile_n=1001),
+    "dma256_splitk3":    dict(B=1, H=8, W=8, C0=96, C1=0, Cout=256, ks=3, act=1, splitk=3, tile_n=1001),
+    "dma256x128":        dict(B=2, H=16, W=16, C0=64, C1=0, Cout=128, ks=3, act=1, tile_n=1002),
+    "dma256x128_up":     dict(B=1, H=16, W=16, C0=64, C1=0, Cout=128, ks=3, up=1, act=1, tile_n=1002),
+    "dma512x64":         dict(B=2, H=16, W=20, C0=32, C1=0, Cout=64, ks=3, act=1, tile_n=1003),
+    "dma512x64_up":      dict(B=1, H=16, W=16, C0=128, C1=0, Cout=64, ks=3, up=1, act=1, tile_n=1003),
+    "dma256_bottleneck": dict(B=4, H=64, W=64, C0=256, C1=0, Cout=256, ks=3, resid=True, tile_n=1001),
+    "7x1_rowsplit":      dict(B=2, H=16, W=16, C0=64, C1=0, Cout=21, ks=7, kw=1),
     "7x7_head":          dict(B=1, H=16, W=16, C0=32, C1=64, Cout=12, ks=7),
     "7x7_sigmoid":       dict(B=1, H=32, W=32, C0=32, C1=0, Cout=3, ks=7, act=2),
     "7x7_first":         dict(B=1, H=32, W=32, C0=32, C1=0, Cout=64, ks=7, act=1),
@@ -108,7 +124,7 @@ def test_conv_linearity_property():
     for scale in (1.0, 4.0):
         xin = (x * scale).contiguous()
         out = torch.empty(B, H, W, Cc, device=dev)
-        _lib.check(L.eamm_op_conv(0, xin.data_ptr(), Cc, None, 0, B, H, W, 0, w.data_ptr(), b.data_ptr(), Cc, 3, 0, 0,
+        _lib.check(L.eamm_op_conv(0, xin.data_ptr(), Cc, None, 0, B, H, W, 0, w.data_ptr(), b.data_ptr(), Cc, 3, 3, 0, 0,
                                   None, 0, 0, out.data_ptr(), 0, None, torch.cuda.current_stream().cuda_stream),
                    None)
         outs.append(out)

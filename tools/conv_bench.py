@@ -11,12 +11,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eamm_amd import _lib  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-# name, Hin, Win, C0, C1, Cout, ks, up, act, pool, resid
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] != "all" else None
+TILES = [int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]   # 0 auto, 1001.. dma tiles
+# name, Hin, Win, C0, C1, Cout, ks(,kw), up, act, pool, resid
 LAYERS = [
     ("bottleneck", 64, 64, 256, 0, 256, 3, 0, 0, 0, 1),
     ("up0", 64, 64, 256, 0, 128, 3, 1, 1, 0, 0),
     ("up1", 128, 128, 128, 0, 64, 3, 1, 1, 0, 0),
-    ("final7x7", 256, 256, 64, 0, 3, 7, 0, 2, 0, 0),
+    ("final7x1", 256, 256, 64, 0, 21, (7, 1), 0, 0, 0, 0),
     ("hg_enc0", 64, 64, 64, 0, 128, 3, 0, 1, 1, 0),
     ("hg_enc1", 32, 32, 128, 0, 256, 3, 0, 1, 1, 0),
     ("hg_enc2", 16, 16, 256, 0, 512, 3, 0, 1, 1, 0),
@@ -37,25 +39,34 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     total = 0.0
     for name, H, W, C0, C1, Cout, ks, up, act, pool, resid in LAYERS:
+        if ONLY and name not in ONLY:
+            continue
+        ks, kw = ks if isinstance(ks, tuple) else (ks, ks)
         g = torch.Generator().manual_seed(1)
         in0 = torch.randn(B, H, W, C0, generator=g).to(dev)
         in1 = torch.randn(B, H, W, C1, generator=g).to(dev) if C1 else None
         cin = C0 + C1
-        w = (torch.randn(Cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5).contiguous()
+        w = (torch.randn(Cout, cin, ks, kw, generator=g) * (2.0 / (cin * ks * kw)) ** 0.5).contiguous()
         b = torch.zeros(Cout)
         Ho, Wo = H << up, W << up
         res = torch.randn(B, Ho, Wo, Cout, generator=g).to(dev) if resid else None
         out = torch.empty(B, Ho >> pool, Wo >> pool, Cout, device=dev)
-        ms = C.c_float()
-        rc = L.eamm_op_conv(0, in0.data_ptr(), C0, in1.data_ptr() if C1 else None, C1, B, H, W, up, w.data_ptr(),
-                            b.data_ptr(), Cout, ks, act, pool, res.data_ptr() if resid else None, 0, 0,
-                            out.data_ptr(), 20, C.byref(ms), st)
-        _lib.check(rc, None)
-        flops = 2.0 * B * Ho * Wo * Cout * cin * ks * ks
-        n = 12 if name == "bottleneck" else 1
-        total += ms.value * n
-        print(f"{name:11s} M={B*Ho*Wo:7d} N={Cout:4d} K={cin*ks*ks:5d}  {ms.value*1e3:8.1f} us  "
-              f"{flops/ms.value/1e9:7.1f} TF/s  ({flops/1e9:6.2f} GF)")
+        flops = 2.0 * B * Ho * Wo * Cout * cin * ks * kw   # reference-algorithmic (un-collapsed) FLOPs
+        for tile in TILES:
+            if tile > 1000 and (ks != 3 or kw != 3):
+                continue
+            if tile > 1000 and {1001: 256, 1002: 128, 1003: 64}[tile] > max(Cout, 64) * 2:
+                continue
+            ms = C.c_float()
+            rc = L.eamm_op_conv(0, in0.data_ptr(), C0, in1.data_ptr() if C1 else None, C1, B, H, W, up, w.data_ptr(),
+                                b.data_ptr(), Cout, ks, kw, act, pool, res.data_ptr() if resid else None, 0, tile,
+                                out.data_ptr(), 20, C.byref(ms), st)
+            _lib.check(rc, None)
+            n = 12 if name == "bottleneck" else 1
+            if tile == TILES[0]:
+                total += ms.value * n
+            print(f"{name:11s} tile={tile:4d} M={B*Ho*Wo:7d} N={Cout:4d} K={cin*ks*kw:5d}  {ms.value*1e3:8.1f} us  "
+                  f"{flops/ms.value/1e9:7.1f} TF/s  ({flops/1e9:6.2f} GF)", flush=True)
     print(f"sum over a step (bottleneck x12): {total:.3f} ms")
 
 
