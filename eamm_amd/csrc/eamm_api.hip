@@ -63,6 +63,9 @@ struct eamm_ctx {
     // layers
     ConvLayer first, final_conv, head;
     std::vector<LayerSet> down, hg_enc, hg_dec, res1, res2, up;
+    std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
+    float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] transformed activations
+    int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd form
     int dma_min_m = 1024;       // smallest per-phase M for which an LDS-DMA tile is preferred
     int big_min_m = 49152;      // ... and for which Cout % 256 == 0 layers use the 256x256 tile (>= 192 M tiles)
     int dma_cfg_n256 = 2, dma_cfg_n128 = 2, dma_cfg_n64 = 3;
@@ -91,10 +94,13 @@ struct eamm_ctx {
     double flops_frame = 0, flops_encode = 0;
 
     // optional stage timing with HIP events on the caller's stream (bench.py roofline leg)
-    static constexpr int NSTAGE = 8;       // front, hg_enc, hg_dec, head, warp, bottleneck, up, final
+    static constexpr int NSTAGE = 9;       // front, hg_enc, hg_dec, head, warp, bneck_transform, bneck_conv, up, final
+    static constexpr int NMARK = 8;        // stage boundaries recorded per call (bottleneck is split from sub-events)
+    static constexpr int NSUB = 64;        // per-launch events inside the bottleneck (4 per res-block + 1)
     static constexpr int PROF_CALLS = 256; // event sets kept before the host must read them
     bool profiling = false;
-    std::vector<hipEvent_t> prof_events;   // PROF_CALLS * (NSTAGE+1)
+    std::vector<hipEvent_t> prof_events;   // PROF_CALLS * (NMARK+1 + NSUB)
+    std::vector<int> prof_sub;             // sub-events used by each recorded call (0: direct form)
     int prof_used = 0;
     double prof_ms[NSTAGE] = {0};
     long prof_calls = 0, prof_frames = 0;
@@ -266,6 +272,35 @@ int build_set(eamm_ctx* c, const std::vector<FoldSpec>& parts, int C0_real, int 
 }
 
 // Tile choice per launch (measured on MI355X, profiles/r01_convbench_*): M is the per-phase pixel count.
+// conv (+ folded BatchNorm) -> Winograd-domain weights U = G g G^T
+int build_wino(eamm_ctx* c, const std::string& conv, const std::string& norm, int C, WinoLayer* L) {
+    const HostTensor *wt = find(c, conv + ".weight"), *bt = find(c, conv + ".bias");
+    if (!wt || !bt || wt->shape.size() != 4 || wt->shape[0] != C || wt->shape[1] != C || wt->shape[2] != 3)
+        return fail(c, EAMM_ERR_KEY, "%s mis-shaped for the Winograd path", conv.c_str());
+    std::vector<float> wf(wt->data), bf(bt->data);
+    if (!norm.empty()) {
+        const HostTensor *g = find(c, norm + ".weight"), *be = find(c, norm + ".bias"),
+                         *mu = find(c, norm + ".running_mean"), *var = find(c, norm + ".running_var");
+        if (!g || !be || !mu || !var) return fail(c, EAMM_ERR_KEY, "BatchNorm entries of %s missing", norm.c_str());
+        for (int o = 0; o < C; ++o) {
+            const double sc = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+            bf[o] = (float)(((double)bt->data[o] - (double)mu->data[o]) * sc + (double)be->data[o]);
+            for (size_t i = 0; i < (size_t)C * 9; ++i) wf[(size_t)o * C * 9 + i] = (float)((double)wt->data[(size_t)o * C * 9 + i] * sc);
+        }
+    }
+    L->Cin = C;
+    L->Cout = C;
+    L->BN = 128;
+    L->ntiles = (C + L->BN - 1) / L->BN;
+    std::vector<float> packed(wino_packed_elems(C, C, L->BN));
+    wino_pack_host(wf.data(), C, C, L->BN, packed.data());
+    std::vector<float> bias_pad((size_t)L->ntiles * L->BN, 0.f);
+    std::copy(bf.begin(), bf.end(), bias_pad.begin());
+    int rc = upload(c, &L->u, packed);
+    if (rc) return rc;
+    return upload(c, &L->bias, bias_pad);
+}
+
 const ConvLayer& pick(const eamm_ctx* c, const LayerSet& S, size_t M) {
     if (S.has_big && M >= (size_t)c->big_min_m) return S.big;
     return (S.has_dma && M >= (size_t)c->dma_min_m) ? S.dma : S.base;
@@ -367,6 +402,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     // tuning knobs (defaults measured on MI355X, profiles/): EAMM_DMA_MIN_M < 0 disables the LDS-DMA kernels
     c->dma_min_m = env_int("EAMM_DMA_MIN_M", c->dma_min_m);
     c->big_min_m = env_int("EAMM_BIG_MIN_M", c->big_min_m);
+    c->wino_min_m = env_int("EAMM_WINO_MIN_M", c->wino_min_m);   // < 0 disables the Winograd bottleneck
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
     c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);
     c->dma_cfg_n64 = env_int("EAMM_DMA_CFG_N64", c->dma_cfg_n64);
@@ -456,6 +492,12 @@ int eamm_finalize_weights(eamm_ctx* c) {
         const std::string r = "bottleneck.r" + std::to_string(i);
         if ((rc = build_set(c, {{r + ".conv1", r + ".norm2"}}, c->Cb, c->Cb, 0, 0, &c->res1[i], MODE_PLAIN))) return rc;
         if ((rc = build_set(c, {{r + ".conv2", ""}}, c->Cb, c->Cb, 0, 0, &c->res2[i], MODE_PLAIN))) return rc;
+        if (c->wino_min_m >= 0 && c->Cb % 64 == 0) {
+            c->wres1.resize(nr);
+            c->wres2.resize(nr);
+            if ((rc = build_wino(c, r + ".conv1", r + ".norm2", c->Cb, &c->wres1[i]))) return rc;
+            if ((rc = build_wino(c, r + ".conv2", "", c->Cb, &c->wres2[i]))) return rc;
+        }
         const HostTensor *gm = find(c, r + ".norm1.weight"), *bt = find(c, r + ".norm1.bias"),
                          *mu = find(c, r + ".norm1.running_mean"), *vr = find(c, r + ".norm1.running_var");
         if ((int)gm->numel() != c->Cb || (int)bt->numel() != c->Cb || (int)mu->numel() != c->Cb ||
@@ -523,6 +565,10 @@ int eamm_finalize_weights(eamm_ctx* c) {
     if ((rc = dev_alloc(c, &c->act, F * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->tmp, F * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->final_part, F * HW * 32))) return rc;
+    if (!c->wres1.empty()) {
+        if (4 * F * hwf * c->Cb * sizeof(float) >= 0xFFFFFFF0ull) c->wres1.clear();   // 32-bit descriptor range
+        else if ((rc = dev_alloc(c, &c->wino_v, 4 * F * hwf * c->Cb))) return rc;
+    }
     c->up_buf.resize(c->nd);
     for (int i = 0; i < c->nd; ++i)
         if ((rc = dev_alloc(c, &c->up_buf[i], F * (hwf << (2 * (i + 1))) * c->up_c[i]))) return rc;
@@ -633,8 +679,9 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
 
     hipEvent_t* ev = nullptr;  // stage boundaries, recorded only while profiling
     if (c->profiling && c->prof_used < eamm_ctx::PROF_CALLS) {
-        ev = c->prof_events.data() + (size_t)c->prof_used * (eamm_ctx::NSTAGE + 1);
+        ev = c->prof_events.data() + (size_t)c->prof_used * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB);
         c->prof_n.push_back(n);
+        c->prof_sub.push_back(0);
         ++c->prof_used;
     }
 #define STAGE_MARK(i)                                  \
@@ -701,16 +748,39 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
                                       hipMemcpyDeviceToDevice, s));
     }
     STAGE_MARK(4);
-    // feature warp x occlusion (+ r0's pre-activation)                         generator.py:79-84
+    // Bottleneck form: Winograd F(2x2,3x3) when there are enough tiles to fill the chip, else direct.
+    const int nr = c->cfg.num_bottleneck_blocks;
+    const bool wino = !c->wres1.empty() && (size_t)n * hf * wf >= (size_t)c->wino_min_m;
+    // feature warp x occlusion (+ r0's pre-activation for the direct form)       generator.py:79-84
     HIP_TRY(c, warp_features_launch(c->feat, c->deformation, occ ? c->occlusion : nullptr, n, ns, hf, wf, c->Cb, h, w,
-                                    c->xa, c->act, c->pre_s[0], c->pre_t[0], s));
+                                    c->xa, wino ? nullptr : c->act, c->pre_s[0], c->pre_t[0], s));
     if (o->deformed)                                                         // generator.py:86
         HIP_TRY(c, warp_image_launch(c->src_full, c->deformation, n, ns, c->H, c->W, h, w, o->deformed, s));
     STAGE_MARK(5);
     // bottleneck                                                               generator.py:89
-    const int nr = c->cfg.num_bottleneck_blocks;
     float *x = c->xa, *xn = c->xb;
-    for (int i = 0; i < nr; ++i) {
+    hipEvent_t* sub = (ev && wino && 4 * nr + 1 <= eamm_ctx::NSUB) ? ev + eamm_ctx::NMARK + 1 : nullptr;
+    int nsub = 0;
+#define SUB_MARK()                                               \
+    do {                                                         \
+        if (sub) HIP_TRY(c, hipEventRecord(sub[nsub++], s));     \
+    } while (0)
+    for (int i = 0; i < nr && wino; ++i) {
+        // conv1(relu(norm1(x))): the pre-activation rides on the input transform; norm2 + relu in the epilogue
+        SUB_MARK();
+        HIP_TRY(c, wino_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, c->wino_v, s));
+        SUB_MARK();
+        HIP_TRY(c, wino_gemm_launch(c->wres1[i], c->wino_v, n, hf, wf, ACT_RELU, nullptr, c->tmp, s));
+        SUB_MARK();
+        HIP_TRY(c, wino_transform_launch(c->tmp, nullptr, nullptr, n, hf, wf, c->Cb, c->wino_v, s));
+        SUB_MARK();
+        HIP_TRY(c, wino_gemm_launch(c->wres2[i], c->wino_v, n, hf, wf, ACT_NONE, x, xn, s));   // out += x
+        std::swap(x, xn);
+    }
+    SUB_MARK();
+#undef SUB_MARK
+    if (sub) c->prof_sub.back() = nsub;
+    for (int i = 0; i < nr && !wino; ++i) {
         ConvIO a{};
         a.in0 = c->act;
         a.B = n;
@@ -782,7 +852,7 @@ int eamm_profile_enable(eamm_ctx* c, int on) {
     if (!c) return EAMM_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (on && c->prof_events.empty()) {
-        c->prof_events.resize((size_t)eamm_ctx::PROF_CALLS * (eamm_ctx::NSTAGE + 1));
+        c->prof_events.resize((size_t)eamm_ctx::PROF_CALLS * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB));
         for (auto& e : c->prof_events) HIP_TRY(c, hipEventCreate(&e));
     }
     c->profiling = on != 0;
@@ -791,19 +861,34 @@ int eamm_profile_enable(eamm_ctx* c, int on) {
 
 int eamm_profile_read(eamm_ctx* c, double* stage_ms, int nstage, int64_t* calls, int64_t* frames, int reset) {
     if (!c || !stage_ms || nstage != eamm_ctx::NSTAGE) return fail(c, EAMM_ERR_ARG, "nstage must be %d", eamm_ctx::NSTAGE);
+    // stage index of each of the NMARK recorded intervals; the bottleneck interval (5) is split below
+    static const int stage_of[eamm_ctx::NMARK] = {0, 1, 2, 3, 4, 6, 7, 8};
     for (int k = 0; k < c->prof_used; ++k) {  // fold finished event sets into the totals
-        hipEvent_t* ev = c->prof_events.data() + (size_t)k * (eamm_ctx::NSTAGE + 1);
-        HIP_TRY(c, hipEventSynchronize(ev[eamm_ctx::NSTAGE]));
-        for (int i = 0; i < eamm_ctx::NSTAGE; ++i) {
+        hipEvent_t* ev = c->prof_events.data() + (size_t)k * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB);
+        HIP_TRY(c, hipEventSynchronize(ev[eamm_ctx::NMARK]));
+        for (int i = 0; i < eamm_ctx::NMARK; ++i) {
             float ms = 0.f;
             HIP_TRY(c, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-            c->prof_ms[i] += ms;
+            c->prof_ms[stage_of[i]] += ms;
+        }
+        const int nsub = c->prof_sub[k];
+        if (nsub > 1) {  // Winograd form: even intervals are input transforms, odd ones the GEMM kernels
+            hipEvent_t* sub = ev + eamm_ctx::NMARK + 1;
+            double tr = 0;
+            for (int i = 0; i + 1 < nsub; i += 2) {
+                float ms = 0.f;
+                HIP_TRY(c, hipEventElapsedTime(&ms, sub[i], sub[i + 1]));
+                tr += ms;
+            }
+            c->prof_ms[5] += tr;
+            c->prof_ms[6] -= tr;
         }
         c->prof_calls += 1;
         c->prof_frames += c->prof_n[k];
     }
     c->prof_used = 0;
     c->prof_n.clear();
+    c->prof_sub.clear();
     for (int i = 0; i < nstage; ++i) stage_ms[i] = c->prof_ms[i];
     if (calls) *calls = c->prof_calls;
     if (frames) *frames = c->prof_frames;
@@ -870,6 +955,55 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: bad argument");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (tile_n == 2000) {  // Winograd F(2x2,3x3): input transform + GEMM
+        if (kh != 3 || kw != 3 || up || pool || C1 || splitk > 1 || C0 % 64 || (Cout & 3))
+            return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported Winograd configuration");
+        WinoLayer W;
+        W.Cin = C0;
+        W.Cout = Cout;
+        W.BN = 128;
+        W.ntiles = (Cout + 127) / 128;
+        std::vector<float> packed(wino_packed_elems(Cout, C0, 128)), bias((size_t)W.ntiles * 128, 0.f);
+        wino_pack_host(w_host, Cout, C0, 128, packed.data());
+        std::copy(b_host, b_host + Cout, bias.begin());
+        float* V = nullptr;
+        int rc = EAMM_OK;
+        auto done = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess) rc = fail(nullptr, EAMM_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+            return e != hipSuccess;
+        };
+        const size_t vel = (size_t)16 * B * (Hin / 2) * (Win / 2) * C0;
+        if (!done(hipMalloc((void**)&W.u, packed.size() * sizeof(float)), "hipMalloc") &&
+            !done(hipMalloc((void**)&W.bias, bias.size() * sizeof(float)), "hipMalloc") &&
+            !done(hipMalloc((void**)&V, vel * sizeof(float)), "hipMalloc") &&
+            !done(hipMemcpy(W.u, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
+            !done(hipMemcpy(W.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")) {
+            auto run = [&]() {
+                hipError_t e = wino_transform_launch(in0, nullptr, nullptr, B, Hin, Win, C0, V, s);
+                if (e != hipSuccess) return e;
+                return wino_gemm_launch(W, V, B, Hin, Win, act, resid, out, s);
+            };
+            if (!done(run(), "winograd launch") && iters > 0 && avg_ms) {
+                hipEvent_t e0, e1;
+                (void)hipEventCreate(&e0);
+                (void)hipEventCreate(&e1);
+                (void)hipEventRecord(e0, s);
+                for (int i = 0; i < iters; ++i) (void)run();
+                (void)hipEventRecord(e1, s);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                *avg_ms = ms / iters;
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+            }
+            done(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
+        if (W.u) (void)hipFree(W.u);
+        if (W.bias) (void)hipFree(W.bias);
+        if (V) (void)hipFree(V);
+        return rc;
+    }
     ConvLayer L;
     L.kh = kh;
     L.kw = kw;

@@ -79,6 +79,20 @@ struct ConvIO {
 };
 hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream, int force_splits = 0);
 
+// ---- Winograd F(2x2,3x3) path for the bottleneck convolutions (conv_winograd.hip)
+struct WinoLayer {
+    int Cin = 0, Cout = 0, BN = 128, ntiles = 0;
+    float* u = nullptr;     // device, packed [ntiles][16*Cin/32][BN][32]
+    float* bias = nullptr;  // device, [ntiles*BN]
+};
+size_t wino_packed_elems(int Cout, int Cin, int BN);
+void wino_pack_host(const float* w_oihw, int Cout, int Cin, int BN, float* dst);
+// V[16][B*H/2*W/2][C] = B^T d B of x (optionally of relu(x*s + t))
+hipError_t wino_transform_launch(const float* x, const float* s, const float* t, int B, int H, int W, int C, float* V,
+                                 hipStream_t stream);
+hipError_t wino_gemm_launch(const WinoLayer& L, const float* V, int B, int H, int W, int act, const float* resid,
+                            float* out, hipStream_t stream);
+
 // ---- motion / warp / image kernels (motion.hip) ---------------------------------------------
 hipError_t kp_prepare_launch(const float* kd_val, const float* kd_jac, const float* ks_val, const float* ks_jac,
                              int n, int ns, int K, float* kp_rec, int* bad_flag, hipStream_t s);

@@ -180,7 +180,7 @@ class Engine:
         self.ns_cached = ns
 
     # -- stage timing (HIP events inside the library, on the stream the kernels run on) -----------------
-    STAGES = ("front", "hg_enc", "hg_dec", "head", "warp", "bottleneck", "up", "final")
+    STAGES = ("front", "hg_enc", "hg_dec", "head", "warp", "bneck_transform", "bneck_conv", "up", "final")
 
     def profile(self, on: bool = True):
         _lib.check(self._L.eamm_profile_enable(self._ctx, int(on)), self._ctx)

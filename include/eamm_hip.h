@@ -136,13 +136,14 @@ double eamm_encode_flops(const eamm_ctx* ctx);
 
 /*
  * Stage timing for roofline accounting (bench.py): while enabled, every eamm_forward_frames call
- * records HIP events on the caller's stream at its EAMM_NSTAGE+1 stage boundaries (up to 256 calls
- * between reads).  eamm_profile_read waits for the recorded calls and returns accumulated
- * milliseconds per stage: 0 key points + motion front end, 1 hourglass encoder, 2 hourglass decoder,
- * 3 flow head, 4 feature warp, 5 bottleneck (2 x num_bottleneck_blocks 3x3 convolutions), 6 up
- * blocks, 7 final 7x7 + sigmoid (+ uint8 packing).
+ * records HIP events on the caller's stream at its stage boundaries and around every bottleneck launch
+ * (up to 256 calls between reads).  eamm_profile_read waits for the recorded calls and returns
+ * accumulated milliseconds per stage: 0 key points + motion front end, 1 hourglass encoder, 2 hourglass
+ * decoder, 3 flow head, 4 feature warp, 5 bottleneck Winograd input transforms (0 in the direct form),
+ * 6 bottleneck convolution kernels (2 x num_bottleneck_blocks launches), 7 up blocks, 8 final 7x7 +
+ * sigmoid (+ uint8 packing).
  */
-#define EAMM_NSTAGE 8
+#define EAMM_NSTAGE 9
 int eamm_profile_enable(eamm_ctx* ctx, int on);
 int eamm_profile_read(eamm_ctx* ctx, double* stage_ms, int nstage, int64_t* calls, int64_t* frames, int reset);
 
@@ -157,7 +158,7 @@ int eamm_profile_read(eamm_ctx* ctx, double* stage_ms, int nstage, int64_t* call
  * collapsed four-phase 2x2 form; act: 0 none, 1 relu, 2 sigmoid; pool = 1 applies avgpool2x2 after the
  * activation; resid: NHWC tensor added before the activation; splitk 0 = automatic; tile_n 0 =
  * automatic, 32/64/128 = register-staged 128 x tile_n kernel, 1000+id = LDS-DMA big-tile kernel (1: 256x256,
- * 2: 256x128, 3: 512x64); out NHWC [B,H(/2),W(/2),Cout] with H = Hin << up.  iters > 0 additionally times `iters`
+ * 2: 256x128, 3: 512x64), 2000 = Winograd F(2x2,3x3) (input transform + GEMM; 3x3, single input, no pool); out NHWC [B,H(/2),W(/2),Cout] with H = Hin << up.  iters > 0 additionally times `iters`
  * back-to-back launches with HIP events on `stream` and stores the average milliseconds in *avg_ms. */
 int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int up,
                  const float* weight_host, const float* bias_host, int Cout, int kh, int kw,

@@ -55,7 +55,9 @@ def main():
         for tile in TILES:
             if tile > 1000 and (ks != 3 or kw != 3):
                 continue
-            if tile > 1000 and {1001: 256, 1002: 128, 1003: 64}[tile] > max(Cout, 64) * 2:
+            if tile == 2000 and (up or pool or C1 or C0 % 64):
+                continue
+            if 1000 < tile < 2000 and {1001: 256, 1002: 128, 1003: 64}[tile] > max(Cout, 64) * 2:
                 continue
             ms = C.c_float()
             rc = L.eamm_op_conv(0, in0.data_ptr(), C0, in1.data_ptr() if C1 else None, C1, B, H, W, up, w.data_ptr(),
