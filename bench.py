@@ -90,13 +90,34 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # EAMM_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs than ranks (ranks then
+    # share devices and collectives are staged through the host) -- used by tests/test_gpu_bench.py only.
+    backend = os.environ.get("EAMM_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    local = local % max(1, ndev) if backend != "nccl" else local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":   # = RCCL on ROCm, one rank per GPU over xGMI
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+
+    def bcast(t):       # device tensor broadcast from rank 0
+        if backend == "nccl":
+            dist.broadcast(t, src=0)
+        else:
+            h = t.cpu()
+            dist.broadcast(h, src=0)
+            t.copy_(h)
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     cfg = hot_path_config()
     sd = synthetic_state_dict(cfg, seed=1234)
@@ -114,7 +135,7 @@ def main():
         blob = eng.export_source_cache(1) if rank == 0 else torch.empty(eng.source_cache_numel(1), device=dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist.broadcast(blob, src=0)
+        bcast(blob)
         torch.cuda.synchronize()
         t_bcast_ms = (time.perf_counter() - t0) * 1e3
         if rank != 0:
@@ -145,9 +166,7 @@ def main():
     eng.profile(False)
     eng.check_numeric()
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = max_over_ranks(dt)
 
     if rank == 0:
         frames = args.steps * B * world

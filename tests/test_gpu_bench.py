@@ -1,0 +1,51 @@
+"""bench.py contract on the GPU box: the JSON line at N=1, and the N=2 code path (two ranks sharing GPU 0, gloo
+collectives staged through the host -- the driver's real N>1 runs use one rank per GPU over RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def run(cmd, env=None):
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env={**os.environ, **(env or {})})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]   # exactly ONE JSON line, printed by rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-frames", "4"])
+    assert REQUIRED <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 3 * 16 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01   # value == frames / timed seconds
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert 0.3 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(sum(d["stage_ms_per_step"].values()) - d["ms_per_step"]) / d["ms_per_step"] < 0.05  # events ~ wall clock
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0
+    assert d["value"] > 30 * c["value"]        # north_star target: >= 30x the CPU reference path
+
+
+def test_bench_two_ranks_share_one_gpu():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+             "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"],
+            env={"EAMM_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and "source_broadcast_ms" in d
+    assert abs(d["value"] - 2 * 3 * 16 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01   # whole-job frames / max time
