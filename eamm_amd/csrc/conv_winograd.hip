@@ -111,19 +111,21 @@ struct WinoArgs {
     float* out;            // NHWC [B,H,W,Cout]
 };
 
-template <int MT, int NT, int WM, int WN>
+// SUB: 32-channel chunks per barrier interval; NST: LDS ring depth in intervals (prefetch distance NST-1, the
+// interval-end wait is a counted vmcnt that leaves the younger intervals' DMA in flight); PE: one DMA piece
+// every PE MFMAs from the start of an interval.
+template <int MT, int NT, int WM, int WN, int SUB, int NST, int PE>
 __global__ __launch_bounds__(WM* WN * 64) void wino_gemm_kernel(const WinoArgs p) {
     constexpr int NW = WM * WN, NTHR = NW * 64;
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32, BK = CONV_BK;
-    constexpr int SUB = 2;                                        // 32-channel chunks per barrier
     constexpr int A_STAGE = SUB * BM * BK, B_STAGE = SUB * BN * BK;  // floats per stage
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;       // DMA instructions per wave per chunk
     constexpr int NPIECE = SUB * (A_INSTR + B_INSTR);
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][A_STAGE] [2][B_STAGE]
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [NST][A_STAGE] [NST][B_STAGE]
     float* const As = smem;
-    float* const Bs = smem + 2 * A_STAGE;
+    float* const Bs = smem + NST * A_STAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -190,8 +192,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wino_gemm_kernel(const WinoArgs p
     const int sw = (l31 >> 1) & 7;
     constexpr int MF = 4 * MT * NT;              // MFMAs per 8-wide K sub-step
     constexpr int TOTAL_MF = SUB * (BK / 8) * MF;  // MFMAs per barrier interval
-    constexpr int PIECE_EVERY = (TOTAL_MF / 2) / NPIECE < 4 ? (TOTAL_MF / 2) / NPIECE : 4;
-    static_assert(PIECE_EVERY >= 1, "DMA pieces must fit in the first half of the interval");
+    constexpr int PIECE_EVERY = PE;
+    static_assert(PIECE_EVERY >= 1 && NPIECE * PIECE_EVERY <= TOTAL_MF, "DMA pieces must fit in the interval");
     auto compute = [&](int st, bool more) {
         f32x4 a[2][MT], b[2][NT];
         auto fetch = [&](int step, int buf) {  // step = sub * 4 + s
@@ -245,23 +247,36 @@ __global__ __launch_bounds__(WM* WN * 64) void wino_gemm_kernel(const WinoArgs p
         });
     };
 
-    // ---- main loop
-    n_sc = 0;
-    n_st = 0;
-    static_for<NPIECE>([&](auto kc) { dma_piece(kc); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int st = 0;
+    // ---- main loop: ring of NST stages, DMA runs D = NST-1 intervals ahead of the MFMAs
+    constexpr int D = NST - 1;
     const int per_xi = cchunks / SUB;  // barrier intervals per transform point
+    for (int k = 0; k < D && k < nsuper; ++k) {
+        n_sc = k;
+        n_st = k;
+        static_for<NPIECE>([&](auto kc) { dma_piece(kc); });
+    }
+    if (D > 1 && nsuper >= D) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NPIECE) : "memory");  // interval 0 has landed
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    int st = 0, st_next = D % NST;
     for (int sc = 0; sc < nsuper; ++sc) {
-        const bool more = sc + 1 < nsuper;
-        n_sc = sc + 1;
-        n_st = st ^ 1;
+        const bool more = sc + D < nsuper;
+        n_sc = sc + D;
+        n_st = st_next;
         compute(st, more);
         if ((sc + 1) % per_xi == 0) fold(sc / per_xi);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // interval sc+1 must have landed; the D-1 younger intervals may stay in flight (while they exist)
+        if (D > 1 && more) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NPIECE) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
-        st ^= 1;
+        st = st + 1 == NST ? 0 : st + 1;
+        st_next = st_next + 1 == NST ? 0 : st_next + 1;
     }
 
     // ---- epilogue: 4 outputs per tile, staged through LDS, 16-byte row accesses
@@ -351,10 +366,29 @@ hipError_t wino_transform_launch(const float* x, const float* s, const float* t,
     return hipGetLastError();
 }
 
-hipError_t wino_gemm_launch(const WinoLayer& L, const float* V, int B, int H, int W, int act, const float* resid,
-                            float* out, hipStream_t stream) {
+template <int SUB, int NST, int PE>
+static hipError_t wino_launch_variant(const WinoArgs& a, hipStream_t stream) {
     constexpr int MT = 1, NT = 2, WM = 4, WN = 2;
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr size_t lds_loop = sizeof(float) * NST * SUB * (BM + BN) * CONV_BK;
+    constexpr size_t lds_epi = sizeof(float) * (WM * 32) * (BN + 4);
+    constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = wino_gemm_kernel<MT, NT, WM, WN, SUB, NST, PE>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles), dim3(WM * WN * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t wino_gemm_launch(const WinoLayer& L, const float* V, int B, int H, int W, int act, const float* resid,
+                            float* out, hipStream_t stream, int variant) {
+    constexpr int BM = 128, BN = 128;
     if (L.BN != BN || (L.Cout & 3) || L.Cin % (2 * CONV_BK) || (H & 1) || (W & 1)) return hipErrorInvalidValue;
     WinoArgs a{};
     a.V = V;
@@ -374,20 +408,16 @@ hipError_t wino_gemm_launch(const WinoLayer& L, const float* V, int B, int H, in
     if (vb >= 0xFFFFFFF0ull || ub >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
     a.v_bytes = (unsigned)vb;
     a.u_bytes = (unsigned)ub;
-    constexpr size_t lds_loop = sizeof(float) * 2 * 2 * (BM + BN) * CONV_BK;
-    constexpr size_t lds_epi = sizeof(float) * (WM * 32) * (BN + 4);
-    constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-    static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = wino_gemm_kernel<MT, NT, WM, WN>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
+    switch (variant) {   // (chunks per barrier, ring depth, MFMAs per DMA piece) -- profiles/r01_wino_variants.txt
+        case 0: return wino_launch_variant<2, 2, 4>(a, stream);
+        case 1: return wino_launch_variant<1, 4, 4>(a, stream);
+        case 2: return wino_launch_variant<1, 5, 4>(a, stream);
+        case 3: return wino_launch_variant<2, 2, 2>(a, stream);
+        case 4: return wino_launch_variant<2, 2, 1>(a, stream);
+        case 5: return wino_launch_variant<1, 3, 4>(a, stream);
+        case 6: return wino_launch_variant<1, 4, 2>(a, stream);
+        default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles), dim3(WM * WN * 64), lds, stream, a);
-    return hipGetLastError();
 }
 
 }  // namespace eamm

@@ -66,6 +66,7 @@ struct eamm_ctx {
     std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
     float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] transformed activations
     int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd form
+    int wino_variant = 0;                  // wino_gemm_kernel pipeline variant (see wino_gemm_launch); in-pipeline all are within noise
     int dma_min_m = 1024;       // smallest per-phase M for which an LDS-DMA tile is preferred
     int big_min_m = 49152;      // ... and for which Cout % 256 == 0 layers use the 256x256 tile (>= 192 M tiles)
     int dma_cfg_n256 = 2, dma_cfg_n128 = 2, dma_cfg_n64 = 3;
@@ -402,7 +403,8 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     // tuning knobs (defaults measured on MI355X, profiles/): EAMM_DMA_MIN_M < 0 disables the LDS-DMA kernels
     c->dma_min_m = env_int("EAMM_DMA_MIN_M", c->dma_min_m);
     c->big_min_m = env_int("EAMM_BIG_MIN_M", c->big_min_m);
-    c->wino_min_m = env_int("EAMM_WINO_MIN_M", c->wino_min_m);   // < 0 disables the Winograd bottleneck
+    c->wino_min_m = env_int("EAMM_WINO_MIN_M", c->wino_min_m);
+    c->wino_variant = env_int("EAMM_WINO_VARIANT", c->wino_variant);   // < 0 disables the Winograd bottleneck
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
     c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);
     c->dma_cfg_n64 = env_int("EAMM_DMA_CFG_N64", c->dma_cfg_n64);
@@ -770,11 +772,11 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         SUB_MARK();
         HIP_TRY(c, wino_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, c->wino_v, s));
         SUB_MARK();
-        HIP_TRY(c, wino_gemm_launch(c->wres1[i], c->wino_v, n, hf, wf, ACT_RELU, nullptr, c->tmp, s));
+        HIP_TRY(c, wino_gemm_launch(c->wres1[i], c->wino_v, n, hf, wf, ACT_RELU, nullptr, c->tmp, s, c->wino_variant));
         SUB_MARK();
         HIP_TRY(c, wino_transform_launch(c->tmp, nullptr, nullptr, n, hf, wf, c->Cb, c->wino_v, s));
         SUB_MARK();
-        HIP_TRY(c, wino_gemm_launch(c->wres2[i], c->wino_v, n, hf, wf, ACT_NONE, x, xn, s));   // out += x
+        HIP_TRY(c, wino_gemm_launch(c->wres2[i], c->wino_v, n, hf, wf, ACT_NONE, x, xn, s, c->wino_variant));   // out += x
         std::swap(x, xn);
     }
     SUB_MARK();
@@ -955,7 +957,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: bad argument");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
-    if (tile_n == 2000) {  // Winograd F(2x2,3x3): input transform + GEMM
+    if (tile_n >= 2000 && tile_n < 2100) {  // Winograd F(2x2,3x3): input transform + GEMM (2000 + kernel variant)
         if (kh != 3 || kw != 3 || up || pool || C1 || splitk > 1 || C0 % 64 || (Cout & 3))
             return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported Winograd configuration");
         WinoLayer W;
@@ -981,7 +983,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
             auto run = [&]() {
                 hipError_t e = wino_transform_launch(in0, nullptr, nullptr, B, Hin, Win, C0, V, s);
                 if (e != hipSuccess) return e;
-                return wino_gemm_launch(W, V, B, Hin, Win, act, resid, out, s);
+                return wino_gemm_launch(W, V, B, Hin, Win, act, resid, out, s, tile_n - 2000);
             };
             if (!done(run(), "winograd launch") && iters > 0 && avg_ms) {
                 hipEvent_t e0, e1;

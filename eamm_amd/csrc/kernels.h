@@ -91,7 +91,7 @@ void wino_pack_host(const float* w_oihw, int Cout, int Cin, int BN, float* dst);
 hipError_t wino_transform_launch(const float* x, const float* s, const float* t, int B, int H, int W, int C, float* V,
                                  hipStream_t stream);
 hipError_t wino_gemm_launch(const WinoLayer& L, const float* V, int B, int H, int W, int act, const float* resid,
-                            float* out, hipStream_t stream);
+                            float* out, hipStream_t stream, int variant = 0);
 
 // ---- motion / warp / image kernels (motion.hip) ---------------------------------------------
 hipError_t kp_prepare_launch(const float* kd_val, const float* kd_jac, const float* ks_val, const float* ks_jac,

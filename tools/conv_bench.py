@@ -55,7 +55,7 @@ def main():
         for tile in TILES:
             if tile > 1000 and (ks != 3 or kw != 3):
                 continue
-            if tile == 2000 and (up or pool or C1 or C0 % 64):
+            if 2000 <= tile < 2100 and (up or pool or C1 or C0 % 64):
                 continue
             if 1000 < tile < 2000 and {1001: 256, 1002: 128, 1003: 64}[tile] > max(Cout, 64) * 2:
                 continue
