@@ -7,6 +7,7 @@ from .config import hot_path_config, tiny_config  # noqa: F401
 from .generator import OcclusionAwareGenerator  # noqa: F401
 from .engine import Engine  # noqa: F401
 from .clip import EngineBackend, animate_clip, shard_bounds  # noqa: F401
+from .keypoints import normalize_kp  # noqa: F401
 
-__all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "shard_bounds",
+__all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "shard_bounds", "normalize_kp",
            "hot_path_config", "tiny_config"]

@@ -75,8 +75,13 @@ def _bcast_kp(kp: Optional[Dict[str, torch.Tensor]], device, src: int, group) ->
 
 def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optional[Dict[str, torch.Tensor]],
                  kp_driving: Optional[Dict[str, torch.Tensor]], height: int, width: int, uint8: bool = False,
-                 group=None, gather: bool = False) -> Tuple[torch.Tensor, Tuple[int, int]]:
+                 group=None, gather: bool = False, kp_driving_initial: Optional[Dict[str, torch.Tensor]] = None,
+                 relative: bool = False, adapt_movement_scale: bool = False
+                 ) -> Tuple[torch.Tensor, Tuple[int, int]]:
     """Animate one clip; returns (frames of this rank's shard, (start, stop)).
+
+    ``kp_driving_initial`` / ``relative`` / ``adapt_movement_scale`` reproduce the reference loop's
+    ``normalize_kp`` call (demo.py:276) for the whole clip at once, before the frames are sharded.
 
     Single process: all T frames.  Under torch.distributed: rank 0 supplies ``source_image`` and the
     key points (other ranks may pass None), every rank returns its contiguous shard; with
@@ -84,6 +89,10 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
     """
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     rank = dist.get_rank(group) if distributed else 0
+    if kp_driving_initial is not None and kp_driving is not None and (relative or adapt_movement_scale):
+        from .keypoints import normalize_kp
+        kp_driving = normalize_kp(kp_source, kp_driving, kp_driving_initial, adapt_movement_scale=adapt_movement_scale,
+                                  use_relative_movement=relative, use_relative_jacobian=relative)
     world = dist.get_world_size(group) if distributed else 1
     backend.prepare(height, width)
     # 1. frame-invariant source tensors: encode once on rank 0, one broadcast

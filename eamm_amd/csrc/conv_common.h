@@ -6,6 +6,20 @@
 
 namespace eamm {
 
+// Opt a kernel into > 64 KiB of dynamic LDS once per (kernel instantiation, device): the attribute belongs to the
+// device's copy of the function, and one process may drive several GPUs (one handle per device).
+template <typename K>
+inline hipError_t ensure_dynamic_lds(K kern, size_t bytes, unsigned long long* done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+    return e;
+}
+
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  Used wherever an
 // accumulator array is indexed, so that no index is ever a run-time value (a failed "#pragma unroll"
 // silently demotes the whole array to scratch memory).

@@ -326,13 +326,8 @@ static hipError_t launch_cfg(const ConvArgs& a, int blocks, hipStream_t stream) 
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * CONV_LDK;
     auto kern = conv_mfma_kernel<KH, KW, MT, NT, WM, WN, PHASE>;
-    static bool configured = false;  // per instantiation (one process drives one device)
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static unsigned long long configured = 0;  // per-device bit mask
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, &configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
     return hipGetLastError();
 }

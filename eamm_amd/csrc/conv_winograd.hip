@@ -375,13 +375,8 @@ static hipError_t wino_launch_variant(const WinoArgs& a, hipStream_t stream) {
     constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = wino_gemm_kernel<MT, NT, WM, WN, SUB, NST, PE>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static unsigned long long configured = 0;  // per-device bit mask
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, &configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles), dim3(WM * WN * 64), lds, stream, a);
     return hipGetLastError();
 }

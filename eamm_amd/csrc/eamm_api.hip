@@ -377,6 +377,16 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
         g.height / div_m < 2 || g.width / div_m < 2)
         return fail(nullptr, EAMM_ERR_ARG, "frame %dx%d not divisible for %d down blocks / %d hourglass levels",
                     g.height, g.width, g.num_down_blocks, g.dm_num_blocks);
+    {   // the kernels address tensors through 32-bit buffer descriptors: every activation must stay below 4 GiB
+        const double hw = (double)g.height * g.width, F = g.max_frames;
+        const double biggest = std::max({F * hw * 32.0,                                  // final-conv partial products
+                                         F * hw * (double)g.block_expansion,             // last up-block output
+                                         4.0 * F * (hw / (1 << (2 * g.num_down_blocks))) *
+                                             std::min(g.max_features, g.block_expansion << g.num_down_blocks)}) * 4.0;
+        if (biggest >= 4294967280.0)
+            return fail(nullptr, EAMM_ERR_ARG, "max_frames=%d at %dx%d needs a %.1f GiB activation tensor; the limit is 4 GiB "
+                        "per tensor -- lower max_frames", g.max_frames, g.height, g.width, biggest / 1073741824.0);
+    }
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice(%d) failed", device);
 
     eamm_ctx* c = new eamm_ctx();
@@ -567,10 +577,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
     if ((rc = dev_alloc(c, &c->act, F * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->tmp, F * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->final_part, F * HW * 32))) return rc;
-    if (!c->wres1.empty()) {
-        if (4 * F * hwf * c->Cb * sizeof(float) >= 0xFFFFFFF0ull) c->wres1.clear();   // 32-bit descriptor range
-        else if ((rc = dev_alloc(c, &c->wino_v, 4 * F * hwf * c->Cb))) return rc;
-    }
+    if (!c->wres1.empty() && (rc = dev_alloc(c, &c->wino_v, 4 * F * hwf * c->Cb))) return rc;
     c->up_buf.resize(c->nd);
     for (int i = 0; i < c->nd; ++i)
         if ((rc = dev_alloc(c, &c->up_buf[i], F * (hwf << (2 * (i + 1))) * c->up_c[i]))) return rc;

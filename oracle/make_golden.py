@@ -108,7 +108,51 @@ def case(OAG, name, cfg, size, n_frames, seed_w, stride, with_jacobian=True, per
     return report
 
 
+def reference_function(path, name, namespace):
+    """Pull ONE function out of a reference file that cannot be imported as a module (demo.py loads dlib
+    models at import time) and compile it as the reference wrote it."""
+    import ast
+    tree = ast.parse(open(path).read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    code = compile(ast.Module(body=[fn], type_ignores=[]), path, "exec")
+    exec(code, namespace)
+    return namespace[name]
+
+
+def normalize_kp_case():
+    """Fixtures for the clip loop's key-point normalisation (demo.py:112-132), all flag combinations."""
+    from scipy.spatial import ConvexHull
+    ref = reference_function(os.path.join(REFERENCE, "demo.py"), "normalize_kp",
+                             {"np": np, "torch": torch, "ConvexHull": ConvexHull})
+    kp_s = synthetic_keypoints(1, 10, seed=0)
+    kp_i = synthetic_keypoints(1, 10, seed=100)
+    kp_d = synthetic_keypoints(5, 10, seed=2)
+    blob = {"kp_source_value": kp_s["value"].numpy(), "kp_source_jacobian": kp_s["jacobian"].numpy(),
+            "kp_initial_value": kp_i["value"].numpy(), "kp_initial_jacobian": kp_i["jacobian"].numpy(),
+            "kp_driving_value": kp_d["value"].numpy(), "kp_driving_jacobian": kp_d["jacobian"].numpy()}
+    for adapt in (0, 1):
+        for rel in (0, 1):
+            for relj in (0, 1):
+                vals, jacs = [], []
+                for t in range(5):   # the reference normalises one frame per call
+                    one = {k: v[t:t + 1].clone() for k, v in kp_d.items()}
+                    out = ref(kp_source={k: v.clone() for k, v in kp_s.items()}, kp_driving=one,
+                              kp_driving_initial={k: v.clone() for k, v in kp_i.items()},
+                              adapt_movement_scale=bool(adapt), use_relative_movement=bool(rel),
+                              use_relative_jacobian=bool(relj))
+                    vals.append(out["value"].numpy())
+                    jacs.append(out["jacobian"].numpy())
+                blob[f"value_a{adapt}r{rel}j{relj}"] = np.concatenate(vals)
+                blob[f"jacobian_a{adapt}r{rel}j{relj}"] = np.concatenate(jacs)
+    np.savez_compressed(os.path.join(GOLDEN, "normalize_kp.npz"), **blob)
+    print("normalize_kp: wrote", len(blob), "arrays")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "normalize_kp":   # add this fixture without touching the others
+        os.makedirs(GOLDEN, exist_ok=True)
+        normalize_kp_case()
+        return
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
     os.makedirs(GOLDEN, exist_ok=True)
@@ -120,6 +164,7 @@ def main():
     summary["tiny64_nojac"] = case(OAG, "tiny64_nojac", tiny, 64, 2, 1234, 1, with_jacobian=False)
     summary["full256_clip2"] = case(OAG, "full256_clip2", full, 256, 2, 1234, 4)
     summary["full512_clip1"] = case(OAG, "full512_clip1", full, 512, 1, 1234, 8)
+    normalize_kp_case()
     with open(os.path.join(GOLDEN, "summary.json"), "w") as f:
         json.dump({"torch": torch.__version__, "cases": summary}, f, indent=1, sort_keys=True)
     for name, rep in summary.items():

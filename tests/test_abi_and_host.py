@@ -57,6 +57,9 @@ def test_create_rejects_bad_config_without_gpu_compute():
     assert b"num_kp" in L.eamm_last_error(None)
     cs = config_struct(tiny_config(), 72, 64, 4, 1)  # 72 not divisible by 4 * 2^3
     assert L.eamm_create(ctypes.byref(cs), 0, ctypes.byref(ctx)) == _lib.ERR_ARG
+    cs = config_struct(hot_path_config(), 512, 512, 256, 1)  # 256 frames of 512x512: a > 4 GiB activation tensor
+    assert L.eamm_create(ctypes.byref(cs), 0, ctypes.byref(ctx)) == _lib.ERR_ARG
+    assert b"4 GiB" in L.eamm_last_error(None)
 
 
 @pytest.mark.parametrize("cfg_fn,nkeys,nparams", [(tiny_config, 112, None), (hot_path_config, 196, 45593205)])
