@@ -36,6 +36,20 @@ class EammOutputs(C.Structure):
     ]
 
 
+class EammKpConfig(C.Structure):
+    _fields_ = [
+        ("num_kp", C.c_int32), ("num_channels", C.c_int32), ("in_features", C.c_int32),
+        ("block_expansion", C.c_int32), ("max_features", C.c_int32), ("num_blocks", C.c_int32),
+        ("temperature", C.c_float), ("estimate_jacobian", C.c_int32), ("single_jacobian_map", C.c_int32),
+        ("inv_scale", C.c_int32), ("pad", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("max_batch", C.c_int32), ("with_predictor", C.c_int32),
+    ]
+
+
+class EammKpOutputs(C.Structure):
+    _fields_ = [("value", C.c_void_p), ("jacobian", C.c_void_p), ("heatmap", C.c_void_p)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol declared in
 # include/eamm_hip.h is exported and bound.
 SIGNATURES = {
@@ -54,6 +68,13 @@ SIGNATURES = {
     "eamm_import_source_cache": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "eamm_flops_per_frame": (C.c_double, [C.c_void_p]),
     "eamm_encode_flops": (C.c_double, [C.c_void_p]),
+    "eamm_kp_create": (C.c_int, [C.POINTER(EammKpConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "eamm_kp_destroy": (None, [C.c_void_p]),
+    "eamm_kp_last_error": (C.c_char_p, [C.c_void_p]),
+    "eamm_kp_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "eamm_kp_finalize_weights": (C.c_int, [C.c_void_p]),
+    "eamm_kp_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(EammKpOutputs), C.c_void_p]),
+    "eamm_kp_detect_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(EammKpOutputs), C.c_void_p]),
     "eamm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "eamm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64), C.c_int]),
@@ -93,7 +114,7 @@ def lib() -> C.CDLL:
     return _lib
 
 
-def check(code: int, ctx=None):
+def check(code: int, ctx=None, kp: bool = False):
     if code != EAMM_OK:
-        msg = lib().eamm_last_error(ctx)
+        msg = (lib().eamm_kp_last_error if kp else lib().eamm_last_error)(ctx)
         raise EammError(code, msg.decode() if msg else "?")

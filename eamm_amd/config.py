@@ -59,3 +59,25 @@ def tiny_config() -> dict:
     """Small generator with the same topology (64x64 frames, 16x16 motion grid)."""
     c = copy.deepcopy(_TINY)
     return {**c["generator_params"], **c["common_params"]}
+
+
+# key-point detectors (N1): reference config/MEAD_emo_video_aug_delta_4_crop_random_crop.yaml:31-41,
+# built as KPDetector(**kp_detector_params, **common_params) / KPDetector_a(**kp_detector_params, **audio_params)
+# (reference demo.py:59-72)
+_KP = {"temperature": 0.1, "block_expansion": 32, "max_features": 1024, "scale_factor": 0.25, "num_blocks": 5}
+
+
+def kp_detector_config() -> dict:
+    return {**_KP, "num_kp": 10, "num_channels": 3, "estimate_jacobian": True}
+
+
+def kp_detector_a_config() -> dict:
+    return {**_KP, "num_kp": 10, "num_channels": 3, "num_channels_a": 3, "estimate_jacobian": True}
+
+
+def tiny_kp_config(audio: bool = False) -> dict:
+    c = {"temperature": 0.1, "block_expansion": 32, "max_features": 128, "scale_factor": 0.25, "num_blocks": 3,
+         "num_kp": 10, "num_channels": 3, "estimate_jacobian": True}
+    if audio:
+        c["num_channels_a"] = 3
+    return c

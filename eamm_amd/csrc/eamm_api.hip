@@ -5,49 +5,13 @@
 //   eamm_forward_frames -- per frame batch: key-point records, motion front end, hourglass, flow head,
 //                          feature warp, bottleneck, up blocks, final 7x7 + sigmoid
 #include "../../include/eamm_hip.h"
-#include "kernels.h"
+#include "api_common.h"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
 
 using namespace eamm;
 
-namespace {
-
-struct HostTensor {
-    std::vector<int64_t> shape;
-    std::vector<float> data;
-    size_t numel() const {
-        size_t n = 1;
-        for (auto s : shape) n *= (size_t)s;
-        return n;
-    }
-};
-
-thread_local std::string g_create_error;
-
-// A convolution layer packed for the register-staged 128 x BN kernel and, where it pays, also for an LDS-DMA
-// big-tile kernel; conv launches pick by problem size (see pick()).
-struct LayerSet {
-    ConvLayer base, dma, big;
-    bool has_dma = false, has_big = false;
-};
-
-}  // namespace
-
-struct eamm_ctx {
+struct eamm_ctx : eamm::CtxBase {
     eamm_config cfg{};
-    int device = 0;
-    std::string err;
-    std::map<std::string, HostTensor> sd;
-    bool finalized = false;
     int ns_cached = 0;
 
     // derived geometry
@@ -67,14 +31,10 @@ struct eamm_ctx {
     float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] transformed activations
     int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd form
     int wino_variant = 0;                  // wino_gemm_kernel pipeline variant (see wino_gemm_launch); in-pipeline all are within noise
-    int dma_min_m = 1024;       // smallest per-phase M for which an LDS-DMA tile is preferred
-    int big_min_m = 49152;      // ... and for which Cout % 256 == 0 layers use the 256x256 tile (>= 192 M tiles)
-    int dma_cfg_n256 = 2, dma_cfg_n128 = 2, dma_cfg_n64 = 3;
     std::vector<float*> pre_s, pre_t;  // res-block pre-activation scale/shift (norm1)
     float* aa_w = nullptr;
     float* final_bias = nullptr;   // bias of the final conv, applied by the shift-sum kernel
     float* final_part = nullptr;   // [F,H,W,32] (dx,co) partial products of the final 7x7 conv
-    std::vector<void*> owned;   // every device allocation, freed in destroy
 
     // source cache (exportable): feat [S,hf,wf,Cb], src_small [S,h,w,4], src_full [S,3,H,W]
     float *feat = nullptr, *src_small = nullptr, *src_full = nullptr;
@@ -110,219 +70,8 @@ struct eamm_ctx {
 
 namespace {
 
-int fail(eamm_ctx* c, int code, const char* fmt, ...) {
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    if (c) c->err = buf;
-    else g_create_error = buf;
-    return code;
-}
-
-#define HIP_TRY(c, expr)                                                                        \
-    do {                                                                                        \
-        hipError_t _e = (expr);                                                                 \
-        if (_e != hipSuccess)                                                                   \
-            return fail((c), EAMM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
-                        __FILE__, __LINE__);                                                    \
-    } while (0)
-
-template <typename T>
-int dev_alloc(eamm_ctx* c, T** p, size_t elems) {
-    void* q = nullptr;
-    HIP_TRY(c, hipMalloc(&q, std::max<size_t>(elems, 1) * sizeof(T)));
-    c->owned.push_back(q);
-    *p = reinterpret_cast<T*>(q);
-    return 0;
-}
-
-int upload(eamm_ctx* c, float** dst, const std::vector<float>& src) {
-    int rc = dev_alloc(c, dst, src.size());
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
-    return 0;
-}
-
-const HostTensor* find(const eamm_ctx* c, const std::string& key) {
-    auto it = c->sd.find(key);
-    return it == c->sd.end() ? nullptr : &it->second;
-}
-
-// conv (+ optional BatchNorm folded behind it) -> packed device layer.
-// y = ((conv(x) + b) - mean) * gamma / sqrt(var + eps) + beta   (sync_batchnorm/batchnorm.py:48-53, eps 1e-5)
-struct FoldSpec {
-    std::string conv;            // key prefix holding .weight / .bias
-    std::string norm;            // key prefix holding BatchNorm stats, or empty
-};
-
-enum LayerMode { MODE_PLAIN = 0, MODE_PHASE = 1, MODE_ROWSPLIT = 2 };
-
-// MODE_PLAIN: ks x ks convolution.  MODE_PHASE: ks must be 3; the layer consumes the low-resolution input of an
-// UpBlock2d and evaluates "nearest x2 + 3x3" as four 2x2 phase filters.  MODE_ROWSPLIT: ks x 1 convolution with
-// N = (dx, co) -- the horizontal taps become output channels, gathered afterwards by final_shift_sum; the bias is
-// returned in *row_bias instead of being applied by the convolution.
-int build_layer(eamm_ctx* c, const std::vector<FoldSpec>& parts, int ks, int C0_real, int C0_packed, int C1_real,
-                int C1_packed, ConvLayer* L, LayerMode mode = MODE_PLAIN, std::vector<float>* row_bias = nullptr,
-                int dma_cfg = 0) {
-    // `parts` are stacked along Cout (the flow head stacks mask + occlusion into one convolution)
-    const int Cin = C0_real + C1_real;
-    const int T = ks * ks;
-    int Cout = 0;
-    for (auto& ps : parts) {
-        const HostTensor* wt = find(c, ps.conv + ".weight");
-        if (!wt || wt->shape.size() != 4 || wt->shape[1] != Cin || wt->shape[2] != ks || wt->shape[3] != ks)
-            return fail(c, EAMM_ERR_KEY, "state_dict entry %s.weight missing or mis-shaped (expected [*,%d,%d,%d])",
-                        ps.conv.c_str(), Cin, ks, ks);
-        Cout += (int)wt->shape[0];
-    }
-    std::vector<float> wf((size_t)Cout * Cin * T), bf(Cout);
-    int o0 = 0;
-    for (auto& ps : parts) {
-        const HostTensor* wt = find(c, ps.conv + ".weight");
-        const HostTensor* bt = find(c, ps.conv + ".bias");
-        const int co = (int)wt->shape[0];
-        if (!bt || (int)bt->numel() != co) return fail(c, EAMM_ERR_KEY, "%s.bias missing or mis-shaped", ps.conv.c_str());
-        const HostTensor *g = nullptr, *be = nullptr, *mu = nullptr, *var = nullptr;
-        if (!ps.norm.empty()) {
-            g = find(c, ps.norm + ".weight");
-            be = find(c, ps.norm + ".bias");
-            mu = find(c, ps.norm + ".running_mean");
-            var = find(c, ps.norm + ".running_var");
-            if (!g || !be || !mu || !var || (int)g->numel() != co || (int)be->numel() != co ||
-                (int)mu->numel() != co || (int)var->numel() != co)
-                return fail(c, EAMM_ERR_KEY, "BatchNorm entries of %s missing or mis-shaped", ps.norm.c_str());
-        }
-        for (int o = 0; o < co; ++o) {
-            double s = 1.0, shift = 0.0, b = bt->data[o];
-            if (g) {
-                s = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
-                b = (b - (double)mu->data[o]) * s + (double)be->data[o];
-            }
-            (void)shift;
-            bf[o0 + o] = (float)b;
-            const float* src = wt->data.data() + (size_t)o * Cin * T;
-            float* dst = wf.data() + (size_t)(o0 + o) * Cin * T;
-            for (size_t i = 0; i < (size_t)Cin * T; ++i) dst[i] = (float)((double)src[i] * s);
-        }
-        o0 += co;
-    }
-    const int cin_packed = C0_packed + C1_packed;
-    std::vector<int> map(cin_packed, -1);
-    for (int i = 0; i < C0_real; ++i) map[i] = i;
-    for (int i = 0; i < C1_real; ++i) map[C0_packed + i] = C0_real + i;
-    int kh = ks, kw = ks;
-    if (mode == MODE_ROWSPLIT) {
-        // w'[dx*Cout+co][c][dy] = w[co][c][dy][dx]
-        std::vector<float> wr((size_t)ks * Cout * Cin * ks);
-        for (int dx = 0; dx < ks; ++dx)
-            for (int co = 0; co < Cout; ++co)
-                for (int ci = 0; ci < Cin; ++ci)
-                    for (int dy = 0; dy < ks; ++dy)
-                        wr[((size_t)(dx * Cout + co) * Cin + ci) * ks + dy] = wf[((size_t)co * Cin + ci) * T + dy * ks + dx];
-        if (row_bias) *row_bias = bf;
-        wf.swap(wr);
-        Cout = ks * Cout;
-        bf.assign(Cout, 0.f);
-        kw = 1;
-    }
-    if (mode == MODE_PHASE && ks != 3) return fail(c, EAMM_ERR_ARG, "phase mode needs a 3x3 convolution");
-    L->kh = kh;
-    L->kw = kw;
-    L->phase = mode == MODE_PHASE;
-    L->C0 = C0_packed;
-    L->C1 = C1_packed;
-    L->Cout = Cout;
-    L->BM = 128;
-    L->BN = conv_tile_n(Cout);
-    L->dma_cfg = dma_cfg;
-    if (dma_cfg > 0 && !conv_dma_tile(dma_cfg, &L->BM, &L->BN)) return fail(c, EAMM_ERR_ARG, "unknown dma tile %d", dma_cfg);
-    L->ntiles = (Cout + L->BN - 1) / L->BN;
-    const int taps = L->phase ? 4 : kh * kw;
-    L->nchunks = taps * (cin_packed / CONV_BK);
-    std::vector<float> packed(conv_packed_elems(taps, cin_packed, Cout, L->BN, L->phase ? 4 : 1));
-    conv_pack_host(wf.data(), Cout, Cin, kh, kw, map.data(), cin_packed, L->BN, L->phase, dma_cfg > 0, packed.data());
-    std::vector<float> bias_pad((size_t)L->ntiles * L->BN, 0.f);
-    std::copy(bf.begin(), bf.end(), bias_pad.begin());
-    int rc = upload(c, &L->w, packed);
-    if (rc) return rc;
-    return upload(c, &L->bias, bias_pad);
-}
-
-int build_set(eamm_ctx* c, const std::vector<FoldSpec>& parts, int C0_real, int C0_packed, int C1_real, int C1_packed,
-              LayerSet* S, LayerMode mode) {
-    int rc = build_layer(c, parts, 3, C0_real, C0_packed, C1_real, C1_packed, &S->base, mode);
-    if (rc) return rc;
-    const int Cout = S->base.Cout;
-    int cfg = 0;
-    if (Cout % 256 == 0) cfg = c->dma_cfg_n256;
-    else if (Cout % 128 == 0) cfg = c->dma_cfg_n128;
-    else if (Cout == 64) cfg = c->dma_cfg_n64;
-    if (cfg > 0 && c->dma_min_m >= 0) {
-        rc = build_layer(c, parts, 3, C0_real, C0_packed, C1_real, C1_packed, &S->dma, mode, nullptr, cfg);
-        if (rc) return rc;
-        S->has_dma = true;
-        if (Cout % 256 == 0 && cfg != 1 && c->big_min_m >= 0) {
-            rc = build_layer(c, parts, 3, C0_real, C0_packed, C1_real, C1_packed, &S->big, mode, nullptr, 1);
-            if (rc) return rc;
-            S->has_big = true;
-        }
-    }
-    return 0;
-}
-
-// Tile choice per launch (measured on MI355X, profiles/r01_convbench_*): M is the per-phase pixel count.
-// conv (+ folded BatchNorm) -> Winograd-domain weights U = G g G^T
-int build_wino(eamm_ctx* c, const std::string& conv, const std::string& norm, int C, WinoLayer* L) {
-    const HostTensor *wt = find(c, conv + ".weight"), *bt = find(c, conv + ".bias");
-    if (!wt || !bt || wt->shape.size() != 4 || wt->shape[0] != C || wt->shape[1] != C || wt->shape[2] != 3)
-        return fail(c, EAMM_ERR_KEY, "%s mis-shaped for the Winograd path", conv.c_str());
-    std::vector<float> wf(wt->data), bf(bt->data);
-    if (!norm.empty()) {
-        const HostTensor *g = find(c, norm + ".weight"), *be = find(c, norm + ".bias"),
-                         *mu = find(c, norm + ".running_mean"), *var = find(c, norm + ".running_var");
-        if (!g || !be || !mu || !var) return fail(c, EAMM_ERR_KEY, "BatchNorm entries of %s missing", norm.c_str());
-        for (int o = 0; o < C; ++o) {
-            const double sc = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
-            bf[o] = (float)(((double)bt->data[o] - (double)mu->data[o]) * sc + (double)be->data[o]);
-            for (size_t i = 0; i < (size_t)C * 9; ++i) wf[(size_t)o * C * 9 + i] = (float)((double)wt->data[(size_t)o * C * 9 + i] * sc);
-        }
-    }
-    L->Cin = C;
-    L->Cout = C;
-    L->BN = 128;
-    L->ntiles = (C + L->BN - 1) / L->BN;
-    std::vector<float> packed(wino_packed_elems(C, C, L->BN));
-    wino_pack_host(wf.data(), C, C, L->BN, packed.data());
-    std::vector<float> bias_pad((size_t)L->ntiles * L->BN, 0.f);
-    std::copy(bf.begin(), bf.end(), bias_pad.begin());
-    int rc = upload(c, &L->u, packed);
-    if (rc) return rc;
-    return upload(c, &L->bias, bias_pad);
-}
-
-const ConvLayer& pick(const eamm_ctx* c, const LayerSet& S, size_t M) {
-    if (S.has_big && M >= (size_t)c->big_min_m) return S.big;
-    return (S.has_dma && M >= (size_t)c->dma_min_m) ? S.dma : S.base;
-}
-
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
-int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
-bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
-
 void expected_keys(const eamm_ctx* c, std::vector<std::string>* keys) {
-    auto block = [&](const std::string& p) {
-        keys->push_back(p + ".conv.weight");
-        keys->push_back(p + ".conv.bias");
-        for (const char* s : {".norm.weight", ".norm.bias", ".norm.running_mean", ".norm.running_var"})
-            keys->push_back(p + s);
-    };
+    auto block = [&](const std::string& p) { block_keys(p, keys); };
     const std::string dm = "dense_motion_network.";
     for (int i = 0; i < c->nb; ++i) block(dm + "hourglass.encoder.down_blocks." + std::to_string(i));
     for (int i = 0; i < c->nb; ++i) block(dm + "hourglass.decoder.up_blocks." + std::to_string(i));
@@ -410,9 +159,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     for (int i = 0; i < c->nd; ++i) c->down_c.push_back(std::min(g.max_features, g.block_expansion << (i + 1)));
     for (int i = 0; i < c->nd; ++i) c->up_c.push_back(std::min(g.max_features, g.block_expansion << (c->nd - i - 1)));
     c->Cb = c->down_c.back();
-    // tuning knobs (defaults measured on MI355X, profiles/): EAMM_DMA_MIN_M < 0 disables the LDS-DMA kernels
-    c->dma_min_m = env_int("EAMM_DMA_MIN_M", c->dma_min_m);
-    c->big_min_m = env_int("EAMM_BIG_MIN_M", c->big_min_m);
+    read_tile_knobs(c);
     c->wino_min_m = env_int("EAMM_WINO_MIN_M", c->wino_min_m);
     c->wino_variant = env_int("EAMM_WINO_VARIANT", c->wino_variant);   // < 0 disables the Winograd bottleneck
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
@@ -424,21 +171,13 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
 
 void eamm_destroy(eamm_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
-    for (void* p : c->owned) (void)hipFree(p);
+    free_owned(c);
     for (auto& e : c->prof_events) (void)hipEventDestroy(e);
     delete c;
 }
 
 int eamm_load_tensor(eamm_ctx* c, const char* key, const float* host, const int64_t* shape, int ndim) {
-    if (!c || !key || !host || ndim < 0 || (ndim > 0 && !shape)) return fail(c, EAMM_ERR_ARG, "null argument");
-    if (c->finalized) return fail(c, EAMM_ERR_STATE, "weights already finalised; create a new handle to reload");
-    HostTensor t;
-    t.shape.assign(shape, shape + ndim);
-    t.data.assign(host, host + t.numel());
-    c->sd[key] = std::move(t);
-    return EAMM_OK;
+    return store_tensor(c, key, host, shape, ndim);
 }
 
 int eamm_finalize_weights(eamm_ctx* c) {
@@ -446,21 +185,10 @@ int eamm_finalize_weights(eamm_ctx* c) {
     if (c->finalized) return fail(c, EAMM_ERR_STATE, "weights already finalised");
     HIP_TRY(c, hipSetDevice(c->device));
     const eamm_config& g = c->cfg;
-    // strict key-set check, like load_state_dict(strict=True) (reference demo.py:91)
     {
         std::vector<std::string> want;
         expected_keys(c, &want);
-        std::string missing, unexpected;
-        for (auto& k : want)
-            if (!c->sd.count(k)) missing += (missing.empty() ? "" : ", ") + k;
-        for (auto& kv : c->sd) {
-            const std::string& k = kv.first;
-            if (k.size() > 20 && k.compare(k.size() - 20, 20, ".num_batches_tracked") == 0) continue;
-            if (std::find(want.begin(), want.end(), k) == want.end()) unexpected += (unexpected.empty() ? "" : ", ") + k;
-        }
-        if (!missing.empty() || !unexpected.empty())
-            return fail(c, EAMM_ERR_KEY, "state_dict mismatch. Missing key(s): [%s]. Unexpected key(s): [%s].",
-                        missing.substr(0, 400).c_str(), unexpected.substr(0, 400).c_str());
+        if (int krc = check_keys(c, want)) return krc;
     }
     const std::string dm = "dense_motion_network.";
     int rc;

@@ -114,6 +114,13 @@ hipError_t source_prepare_launch(const float* src /*[ns,3,H,W]*/, const float* a
                                  float* src_small /*[ns,h,w,4]*/, hipStream_t s);
 hipError_t final_shift_sum_launch(const float* part /*[n,H,W,32]: channel dx*3+co*/, const float* bias /*[3] dev*/,
                                   int n, int H, int W, float* out /*[n,3,H,W]*/, hipStream_t s);
+hipError_t antialias_down_launch(const float* src /*[ns,3,H,W]*/, const float* aa_w, int ns, int H, int W,
+                                 int inv_scale, int Cpad, float* dst /*[ns,h,w,Cpad]: RGB + zeros*/, hipStream_t s);
+hipError_t nchw_to_nhwc_pad_launch(const float* src /*[B,C,H,W]*/, int B, int C, int H, int W, int Cpad,
+                                   float* dst /*[B,H,W,Cpad]*/, hipStream_t s);
+hipError_t kp_head_launch(const float* logits /*[B,h,w,Cs]*/, int B, int K, int njm, int h, int w, int Cs, int pad,
+                          float temperature, float* value /*[B,K,2]*/, float* jacobian /*[B,K,2,2] or null*/,
+                          float* heatmap /*[B,K,h-6+2pad,w-6+2pad] or null*/, hipStream_t s);
 hipError_t to_u8_launch(const float* pred /*[n,3,H,W]*/, int n, int H, int W, uint8_t* out /*[n,H,W,3]*/,
                         hipStream_t s);
 

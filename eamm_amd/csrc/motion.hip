@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void source_to_nhwc_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void antialias_down_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ aa_w, int ns, int H, int W,
-                                                             int inv_scale, float4* __restrict__ dst) {
+                                                             int inv_scale, int c4pad, float4* __restrict__ dst) {
     const int h = H / inv_scale, w = W / inv_scale;
     const size_t plane = (size_t)H * W;
     const size_t total = (size_t)ns * h * w;
@@ -386,7 +386,8 @@ __global__ __launch_bounds__(256) void antialias_down_kernel(const float* __rest
             acc[c] = s;
         }
     }
-    dst[idx] = make_float4(acc[0], acc[1], acc[2], 0.f);
+    dst[idx * c4pad] = make_float4(acc[0], acc[1], acc[2], 0.f);
+    for (int k = 1; k < c4pad; ++k) dst[idx * c4pad + k] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // Final 7x7 convolution, second half (generator.py:92-93).  The MFMA kernel ran it as a 7x1 (vertical)
@@ -495,7 +496,122 @@ hipError_t source_prepare_launch(const float* src, const float* aa_w, int ns, in
     hipLaunchKernelGGL(source_to_nhwc_kernel, dim3(grid_for(t1)), dim3(256), 0, s, src, ns, H, W, Cpad, src_nhwc);
     const size_t t2 = (size_t)ns * (H / inv_scale) * (W / inv_scale);
     hipLaunchKernelGGL(antialias_down_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, src, aa_w, ns, H, W,
-                       inv_scale, reinterpret_cast<float4*>(src_small));
+                       inv_scale, 1, reinterpret_cast<float4*>(src_small));
+    return hipGetLastError();
+}
+
+hipError_t antialias_down_launch(const float* src, const float* aa_w, int ns, int H, int W, int inv_scale, int Cpad,
+                                 float* dst, hipStream_t s) {
+    const size_t t2 = (size_t)ns * (H / inv_scale) * (W / inv_scale);
+    hipLaunchKernelGGL(antialias_down_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, src, aa_w, ns, H, W,
+                       inv_scale, Cpad / 4, reinterpret_cast<float4*>(dst));
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// key-point detector head (reference modules/keypoint_detector.py:77-105 / 180-205)
+// ---------------------------------------------------------------------------------------------
+// [B,C,h,w] feature map -> [B,h,w,Cpad] (zero padded): the layout the MFMA convolutions read.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ src, int B, int C, int HW,
+                                                               int Cpad, float* __restrict__ dst) {
+    const size_t total = (size_t)B * HW * Cpad;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % Cpad);
+        const size_t pix = idx / Cpad;
+        const size_t b = pix / HW, r = pix % HW;
+        dst[idx] = c < C ? src[(b * C + c) * HW + r] : 0.f;
+    }
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    // 256 threads: wave shuffles, then one value per wave through LDS
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float u = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, u) : v + u;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+// One block per (key point k, image b).  logits: [B,h,w,Cs] from the 7x7 "same" MFMA convolution; channel k is
+// the key-point logit, channels K + 4*m + c the jacobian maps.  The reference convolves with padding `pad` (0),
+// i.e. only the interior [off, off+oh) x [off, off+ow), off = 3 - pad, exists: heatmap = softmax(logit /
+// temperature) over that window, value = sum heatmap * grid(oh, ow), jacobian = sum heatmap * jacobian_map.
+__global__ __launch_bounds__(256) void kp_head_kernel(const float* __restrict__ logits, int K, int njm, int h, int w,
+                                                      int Cs, int off, int oh, int ow, float temperature,
+                                                      float* __restrict__ value, float* __restrict__ jacobian,
+                                                      float* __restrict__ heatmap) {
+    __shared__ float red[8];
+    const int k = blockIdx.x, b = blockIdx.y;
+    const int n = oh * ow;
+    const float* base = logits + (size_t)b * h * w * Cs;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / ow + off, x = i % ow + off;
+        m = fmaxf(m, base[(size_t)(y * w + x) * Cs + k] / temperature);
+    }
+    m = block_reduce(m, red, true);
+    float s = 0.f, vx = 0.f, vy = 0.f, j0 = 0.f, j1 = 0.f, j2 = 0.f, j3 = 0.f;
+    const int jm = njm > 0 ? K + 4 * (njm == 1 ? 0 : k) : 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int yy = i / ow, xx = i % ow;
+        const float* px = base + (size_t)((yy + off) * w + xx + off) * Cs;
+        const float e = expf(px[k] / temperature - m);
+        s += e;
+        vx = fmaf(e, grid_coord(xx, ow), vx);
+        vy = fmaf(e, grid_coord(yy, oh), vy);
+        if (njm > 0) {
+            j0 = fmaf(e, px[jm + 0], j0);
+            j1 = fmaf(e, px[jm + 1], j1);
+            j2 = fmaf(e, px[jm + 2], j2);
+            j3 = fmaf(e, px[jm + 3], j3);
+        }
+    }
+    s = block_reduce(s, red, false);
+    vx = block_reduce(vx, red, false);
+    vy = block_reduce(vy, red, false);
+    if (njm > 0) {
+        j0 = block_reduce(j0, red, false);
+        j1 = block_reduce(j1, red, false);
+        j2 = block_reduce(j2, red, false);
+        j3 = block_reduce(j3, red, false);
+    }
+    if (threadIdx.x == 0) {
+        value[((size_t)b * K + k) * 2 + 0] = vx / s;
+        value[((size_t)b * K + k) * 2 + 1] = vy / s;
+        if (njm > 0 && jacobian) {
+            float* jo = jacobian + ((size_t)b * K + k) * 4;
+            jo[0] = j0 / s; jo[1] = j1 / s; jo[2] = j2 / s; jo[3] = j3 / s;
+        }
+    }
+    if (heatmap) {
+        float* ho = heatmap + ((size_t)b * K + k) * n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int y = i / ow + off, x = i % ow + off;
+            ho[i] = expf(base[(size_t)(y * w + x) * Cs + k] / temperature - m) / s;
+        }
+    }
+}
+
+hipError_t nchw_to_nhwc_pad_launch(const float* src, int B, int C, int H, int W, int Cpad, float* dst, hipStream_t s) {
+    const size_t total = (size_t)B * H * W * Cpad;
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, B, C, H * W, Cpad, dst);
+    return hipGetLastError();
+}
+
+hipError_t kp_head_launch(const float* logits, int B, int K, int njm, int h, int w, int Cs, int pad, float temperature,
+                          float* value, float* jacobian, float* heatmap, hipStream_t s) {
+    const int off = 3 - pad, oh = h - 2 * off, ow = w - 2 * off;
+    if (off < 0 || oh < 1 || ow < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kp_head_kernel, dim3(K, B), dim3(256), 0, s, logits, K, njm, h, w, Cs, off, oh, ow, temperature,
+                       value, jacobian, heatmap);
     return hipGetLastError();
 }
 

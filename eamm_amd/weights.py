@@ -102,6 +102,29 @@ def state_dict_spec(cfg):
     return spec
 
 
+def kp_state_dict_spec(cfg):
+    """Checkpoint layout of KPDetector / KPDetector_a (reference keypoint_detector.py:12-37, 115-141): the
+    `predictor` hourglass (unused by KPDetector_a.forward but present in its checkpoint), the 7x7 `kp` and
+    `jacobian` heads and the anti-alias buffer."""
+    spec = []
+    in_features = cfg.get("num_channels_a", cfg["num_channels"])
+    enc, dec, out_filters = hourglass_channels(cfg["block_expansion"], in_features, cfg["num_blocks"], cfg["max_features"])
+    for i, (ci, co) in enumerate(enc):
+        _block(f"predictor.encoder.down_blocks.{i}", ci, co, 3, spec, 2.0)
+    for i, (ci, co) in enumerate(dec):
+        _block(f"predictor.decoder.up_blocks.{i}", ci, co, 3, spec, 2.0)
+    k = cfg["num_kp"]
+    spec.append(("kp.weight", (k, out_filters, 7, 7), "conv_w", 1.0))
+    spec.append(("kp.bias", (k,), "conv_b", None))
+    if cfg.get("estimate_jacobian", False):
+        njm = 1 if cfg.get("single_jacobian_map", False) else k
+        spec.append(("jacobian.weight", (4 * njm, out_filters, 7, 7), "conv_w", 1.0))
+        spec.append(("jacobian.bias", (4 * njm,), "conv_b", None))
+    if cfg.get("scale_factor", 1) != 1:
+        spec.append(("down.weight", (cfg["num_channels"], 1, 13, 13), "aa", None))
+    return spec
+
+
 def antialias_kernel(channels: int, sigma: float = 1.5) -> torch.Tensor:
     """The fixed 13x13 Gaussian buffer of the anti-alias down-sampler.
 
@@ -120,10 +143,10 @@ def antialias_kernel(channels: int, sigma: float = 1.5) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # seeded synthetic weights and inputs (frozen RandomState stream)
 # ----------------------------------------------------------------------------------------------
-def synthetic_state_dict(cfg, seed: int = 1234) -> "OrderedDict[str, torch.Tensor]":
+def synthetic_state_dict(cfg, seed: int = 1234, spec=None) -> "OrderedDict[str, torch.Tensor]":
     rs = np.random.RandomState(seed)
     sd = OrderedDict()
-    for key, shape, kind, gain in state_dict_spec(cfg):
+    for key, shape, kind, gain in (state_dict_spec(cfg) if spec is None else spec):
         if kind == "conv_w":
             fan_in = shape[1] * shape[2] * shape[3]
             v = rs.standard_normal(shape) * math.sqrt(gain / fan_in)

@@ -135,6 +135,47 @@ double eamm_flops_per_frame(const eamm_ctx* ctx);
 double eamm_encode_flops(const eamm_ctx* ctx);
 
 /*
+ * ---- key-point detectors -----------------------------------------------
+ * Constructor arguments of KPDetector / KPDetector_a (reference modules/keypoint_detector.py:12-14, 115-117).
+ * with_predictor = 1: KPDetector -- eamm_kp_detect(image) runs anti-alias down-sampling, the `predictor`
+ * hourglass and the heads (keypoint_detector.py:77-105; once per clip on the source, demo.py:206).
+ * with_predictor = 0: KPDetector_a -- eamm_kp_detect_features(feature_map) runs only the heads on a caller-
+ * provided [B, block_expansion + in_features, H/inv_scale, W/inv_scale] map (keypoint_detector.py:180-205;
+ * once per frame, demo.py:219); `predictor.*` / `down.weight` entries need not be loaded for it.
+ */
+typedef struct eamm_kp_ctx eamm_kp_ctx;
+typedef struct eamm_kp_config {
+    int32_t num_kp;                 /* 10                                                   */
+    int32_t num_channels;           /* 3                                                    */
+    int32_t in_features;            /* hourglass input channels: num_channels (KPDetector) or num_channels_a */
+    int32_t block_expansion;        /* 32                                                   */
+    int32_t max_features;           /* 1024                                                 */
+    int32_t num_blocks;             /* 5                                                    */
+    float   temperature;            /* 0.1                                                  */
+    int32_t estimate_jacobian;      /* 0 / 1                                                */
+    int32_t single_jacobian_map;    /* 0 / 1                                                */
+    int32_t inv_scale;              /* 1 / scale_factor (1, 2, 4)                           */
+    int32_t pad;                    /* padding of the 7x7 heads: 0 (reference default) or 3 */
+    int32_t height, width;          /* image size; feature maps are height/inv_scale x width/inv_scale */
+    int32_t max_batch;
+    int32_t with_predictor;
+} eamm_kp_config;
+
+typedef struct eamm_kp_outputs {    /* 'value' required; NULL pointers are skipped           */
+    float* value;                   /* [B,K,2]     soft-argmax key points, (x, y) in [-1,1] */
+    float* jacobian;                /* [B,K,2,2]                                            */
+    float* heatmap;                 /* [B,K,h-6+2*pad,w-6+2*pad]                            */
+} eamm_kp_outputs;
+
+int eamm_kp_create(const eamm_kp_config* cfg, int device, eamm_kp_ctx** out);
+void eamm_kp_destroy(eamm_kp_ctx* ctx);
+const char* eamm_kp_last_error(const eamm_kp_ctx* ctx);
+int eamm_kp_load_tensor(eamm_kp_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim);
+int eamm_kp_finalize_weights(eamm_kp_ctx* ctx);
+int eamm_kp_detect(eamm_kp_ctx* ctx, const float* image /*[B,3,H,W]*/, int B, const eamm_kp_outputs* out, void* stream);
+int eamm_kp_detect_features(eamm_kp_ctx* ctx, const float* feature_map, int B, const eamm_kp_outputs* out, void* stream);
+
+/*
  * Stage timing for roofline accounting (bench.py): while enabled, every eamm_forward_frames call
  * records HIP events on the caller's stream at its stage boundaries and around every bottleneck launch
  * (up to 256 calls between reads).  eamm_profile_read waits for the recorded calls and returns

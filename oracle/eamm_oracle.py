@@ -86,11 +86,11 @@ def hourglass(x, sd, prefix, num_blocks):
     return out
 
 
-def antialias_down(x, sd, scale):
+def antialias_down(x, sd, scale, key="dense_motion_network.down.weight"):
     """zero-pad 6, depthwise 13x13 Gaussian, keep every (1/scale)-th row/col -- util.py:1044-1052."""
     if scale == 1:
         return x
-    wgt = sd["dense_motion_network.down.weight"].to(x.dtype)
+    wgt = sd[key].to(x.dtype)
     ka = wgt.shape[-1] // 2
     y = F.conv2d(F.pad(x, (ka, ka, ka, ka)), wgt, groups=x.shape[1])
     step = int(1 / scale)
@@ -188,6 +188,38 @@ def generator_forward(sd, cfg, source_image, kp_driving, kp_source):
         outputs["deformed"] = warp_by_flow(source_image, dmo["deformation"])
     outputs["prediction"] = decode(sd, cfg, feat)
     return outputs
+
+
+# ----------------------------------------------------------------------------------------------
+# key-point detectors ("next" row N1) -- reference modules/keypoint_detector.py
+# ----------------------------------------------------------------------------------------------
+def kp_head(sd, cfg, feature_map):
+    """7x7 (pad `pad`) conv -> spatial softmax / temperature -> soft-argmax value; jacobian conv -> heat-map
+    weighted sum -- keypoint_detector.py:77-105 (KPDetector) and :180-205 (KPDetector_a), identical heads."""
+    pad = cfg.get("pad", 0)
+    k = cfg["num_kp"]
+    pred = F.conv2d(feature_map, sd["kp.weight"].to(feature_map.dtype), sd["kp.bias"].to(feature_map.dtype), padding=pad)
+    b, _, hh, ww = pred.shape
+    heat = F.softmax(pred.view(b, k, -1) / cfg["temperature"], dim=2).view(b, k, hh, ww)
+    grid = coordinate_grid(hh, ww, pred.dtype, pred.device)
+    out = {"value": (heat[..., None] * grid[None, None]).sum(dim=(2, 3)), "heatmap": heat}
+    if cfg.get("estimate_jacobian", False):
+        njm = 1 if cfg.get("single_jacobian_map", False) else k
+        jm = F.conv2d(feature_map, sd["jacobian.weight"].to(feature_map.dtype), sd["jacobian.bias"].to(feature_map.dtype),
+                      padding=pad).reshape(b, njm, 4, hh, ww)
+        out["jacobian"] = (heat[:, :, None] * jm).view(b, k, 4, -1).sum(dim=-1).view(b, k, 2, 2)
+    return out
+
+
+def kp_detector_forward(sd, cfg, x):
+    """KPDetector.forward: anti-alias down, hourglass, head -- keypoint_detector.py:77-105."""
+    x = antialias_down(x, sd, cfg.get("scale_factor", 1), key="down.weight")
+    return kp_head(sd, cfg, hourglass(x, sd, "predictor", cfg["num_blocks"]))
+
+
+def kp_detector_a_forward(sd, cfg, feature_map):
+    """KPDetector_a.forward: the head only, on a given (audio-driven) feature map -- keypoint_detector.py:180-205."""
+    return kp_head(sd, cfg, feature_map)
 
 
 def animate_clip(sd, cfg, source_image, kp_source, kp_driving_seq):

@@ -148,10 +148,58 @@ def normalize_kp_case():
     print("normalize_kp: wrote", len(blob), "arrays")
 
 
+def kp_detector_cases():
+    """Fixtures for the key-point detectors (modules/keypoint_detector.py): the reference modules driven with
+    seeded weights; the oracle must reproduce them; fp32-vs-fp64 noise floor recorded."""
+    from eamm_amd.config import kp_detector_a_config, kp_detector_config, tiny_kp_config
+    from eamm_amd.weights import kp_state_dict_spec
+    import_reference()
+    from modules.keypoint_detector import KPDetector, KPDetector_a  # type: ignore
+    report = {}
+    for name, cfg, size, audio in (("kp_tiny64", tiny_kp_config(), 64, False), ("kp_full256", kp_detector_config(), 256, False),
+                                   ("kpa_tiny", tiny_kp_config(audio=True), 64, True),
+                                   ("kpa_full", kp_detector_a_config(), 256, True)):
+        sd = synthetic_state_dict(cfg, seed=77, spec=kp_state_dict_spec(cfg))
+        mod = (KPDetector_a if audio else KPDetector)(**cfg).eval()
+        mod.load_state_dict(sd, strict=True)
+        b = 2
+        if audio:   # feature map [B, block_expansion + num_channels_a, h, w] as AT_net2 produces it (35 x 64 x 64)
+            rs = np.random.RandomState(5)
+            hh = size // 4
+            x = torch.from_numpy(rs.standard_normal((b, cfg["block_expansion"] + cfg["num_channels_a"], hh, hh)).astype(np.float32))
+            fwd = orc.kp_detector_a_forward
+        else:
+            x = synthetic_source(size, seed=3, batch=b)
+            fwd = orc.kp_detector_forward
+        with torch.no_grad():
+            ref = mod(x)
+            mine = fwd(sd, cfg, x)
+            sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+            ref64 = fwd(sd64, cfg, x.double())
+        blob = {"weight_seed": np.int64(77), "size": np.int64(size), "batch": np.int64(b)}
+        if audio:
+            blob["feature_map"] = x.numpy()
+        report[name] = {}
+        for k in ("value", "jacobian", "heatmap"):
+            d = float((mine[k] - ref[k]).abs().max())
+            floor = float((ref[k].double() - ref64[k]).abs().max())
+            report[name][k] = {"oracle_vs_reference": d, "fp32_vs_fp64_floor": floor, "stats": stats(ref[k])}
+            assert d <= max(2e-6, 2 * floor), (name, k, d, floor)
+            blob[k] = ref[k].numpy()
+            blob[k + "_floor"] = np.float64(floor)
+        np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **blob)
+        print(name, {k: (f"{v['oracle_vs_reference']:.1e}", f"{v['fp32_vs_fp64_floor']:.1e}") for k, v in report[name].items()})
+    with open(os.path.join(GOLDEN, "summary_kp.json"), "w") as f:
+        json.dump(report, f, indent=1, sort_keys=True)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "normalize_kp":   # add this fixture without touching the others
         os.makedirs(GOLDEN, exist_ok=True)
         normalize_kp_case()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "kp":
+        kp_detector_cases()
         return
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -165,6 +213,7 @@ def main():
     summary["full256_clip2"] = case(OAG, "full256_clip2", full, 256, 2, 1234, 4)
     summary["full512_clip1"] = case(OAG, "full512_clip1", full, 512, 1, 1234, 8)
     normalize_kp_case()
+    kp_detector_cases()
     with open(os.path.join(GOLDEN, "summary.json"), "w") as f:
         json.dump({"torch": torch.__version__, "cases": summary}, f, indent=1, sort_keys=True)
     for name, rep in summary.items():

@@ -1,0 +1,100 @@
+"""Key-point detectors: oracle vs fixtures captured from the reference's KPDetector /
+KPDetector_a (CPU), and the HIP modules vs the same fixtures and the oracle (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from eamm_amd import KPDetector, KPDetector_a, kp_detector_a_config, kp_detector_config, tiny_kp_config
+from eamm_amd.weights import kp_state_dict_spec, synthetic_source, synthetic_state_dict
+from oracle import eamm_oracle as orc
+
+# stated tolerances (max abs); the reference's own fp32-vs-fp64 floor is <= 3.6e-6 / 8.4e-6 / 4.5e-6
+TOL_KP = {"value": 5e-5, "jacobian": 1e-4, "heatmap": 5e-5}
+CASES = [("kp_tiny64", lambda: tiny_kp_config(), False), ("kp_full256", kp_detector_config, False),
+         ("kpa_tiny", lambda: tiny_kp_config(audio=True), True), ("kpa_full", kp_detector_a_config, True)]
+
+
+def load(name, cfg, audio):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    fx = {k: z[k] for k in z.files}
+    sd = synthetic_state_dict(cfg, seed=int(fx["weight_seed"]), spec=kp_state_dict_spec(cfg))
+    x = torch.from_numpy(fx["feature_map"]) if audio else synthetic_source(int(fx["size"]), seed=3, batch=int(fx["batch"]))
+    return fx, sd, x
+
+
+@pytest.mark.parametrize("name,cfg_fn,audio", CASES)
+def test_oracle_matches_reference_fixture(name, cfg_fn, audio):
+    cfg = cfg_fn()
+    fx, sd, x = load(name, cfg, audio)
+    with torch.no_grad():
+        out = (orc.kp_detector_a_forward if audio else orc.kp_detector_forward)(sd, cfg, x)
+    for k in ("value", "jacobian", "heatmap"):
+        err = float((out[k] - torch.from_numpy(fx[k])).abs().max())
+        assert err <= max(2e-6, 2 * float(fx[k + "_floor"])), (name, k, err)
+    # soft-argmax of a spatial softmax: heat-maps sum to one, values stay inside the [-1,1] grid
+    assert torch.allclose(out["heatmap"].sum(dim=(2, 3)), torch.ones(x.shape[0], cfg["num_kp"]), atol=1e-5)
+    assert float(out["value"].abs().max()) <= 1.0
+
+
+def test_module_layout_and_errors():
+    cfg = kp_detector_config()
+    m = KPDetector(**cfg)
+    spec = kp_state_dict_spec(cfg)
+    sd = m.state_dict()
+    assert sorted(sd) == sorted(k for k, *_ in spec) and all(tuple(sd[k].shape) == tuple(s) for k, s, *_ in spec)
+    # reference init of the jacobian head: zero weights, identity bias (keypoint_detector.py:27-28)
+    assert float(m.jacobian.weight.abs().max()) == 0 and m.jacobian.bias[:4].tolist() == [1, 0, 0, 1]
+    a = KPDetector_a(**kp_detector_a_config())
+    assert sorted(a.state_dict()) == sorted(sd)           # same checkpoint layout, predictor included
+    m.eval()
+    with pytest.raises(RuntimeError, match="GPU"):        # no CPU fallback
+        m(torch.zeros(1, 3, 256, 256))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cfg_fn,audio", CASES)
+def test_hip_modules_match_reference_fixture(name, cfg_fn, audio):
+    cfg = cfg_fn()
+    fx, sd, x = load(name, cfg, audio)
+    mod = (KPDetector_a if audio else KPDetector)(**cfg)
+    mod.load_state_dict(sd, strict=True)
+    mod = mod.to("cuda:0").eval()
+    out = mod(x.to("cuda:0"))
+    assert set(out) == {"value", "jacobian", "heatmap"}
+    errs = {k: float((out[k].cpu() - torch.from_numpy(fx[k])).abs().max()) for k in out}
+    print("\n" + name + "  " + "  ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    for k, e in errs.items():
+        assert out[k].shape == fx[k].shape and e <= TOL_KP[k], (name, k, e)
+    # batch of one == row of the batch (split-K plans may differ with M: tolerance, not bit-exactness)
+    one = mod(x[1:2].to("cuda:0"))
+    assert float((one["value"][0] - out["value"][1]).abs().max()) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_kp_detector_feeds_generator_contract():
+    """demo.py:206,219,279: kp_source = kp_detector(source); kp_driving = kp_detector_a(feature map); both dicts go
+    straight into the generator (extra 'heatmap' key ignored)."""
+    from eamm_amd import OcclusionAwareGenerator, tiny_config
+    gcfg = tiny_config()
+    gen = OcclusionAwareGenerator(**gcfg)
+    gen.load_state_dict(synthetic_state_dict(gcfg, seed=1234))
+    gen = gen.cuda().eval()
+    kcfg, acfg = tiny_kp_config(), tiny_kp_config(audio=True)
+    kp = KPDetector(**kcfg)
+    kp.load_state_dict(synthetic_state_dict(kcfg, seed=77, spec=kp_state_dict_spec(kcfg)))
+    kpa = KPDetector_a(**acfg)
+    kpa.load_state_dict(synthetic_state_dict(acfg, seed=78, spec=kp_state_dict_spec(acfg)))
+    kp, kpa = kp.cuda().eval(), kpa.cuda().eval()
+    src = synthetic_source(64, seed=1).cuda()
+    fmap = torch.randn(1, 35, 16, 16, generator=torch.Generator().manual_seed(0)).cuda()
+    kp_source, kp_driving = kp(src), kpa(fmap)
+    out = gen(src, kp_source=kp_source, kp_driving=kp_driving)
+    assert out["prediction"].shape == (1, 3, 64, 64) and torch.isfinite(out["prediction"]).all()
+    sd_g = synthetic_state_dict(gcfg, seed=1234)
+    with torch.no_grad():
+        ref = orc.generator_forward(sd_g, gcfg, src.cpu(), {k: v.cpu() for k, v in kp_driving.items() if k != "heatmap"},
+                                    {k: v.cpu() for k, v in kp_source.items() if k != "heatmap"})
+    assert float((out["prediction"].cpu() - ref["prediction"]).abs().max()) <= 1e-4
