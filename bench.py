@@ -39,6 +39,10 @@ from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_st
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
 HBM_PEAK_GBS = 8000.0
+# FETCH_SIZE (KB) * 2 + WRITE_SIZE (KB) of the dominant kernel, profiles/r01_rocprofv3_pmc_{fetch,write}_*.txt
+TRAFFIC_WINO = int((180579.8 * 2 + 65536.0) * 1024)     # wino_gemm_kernel: V is read by both N tiles (algorithmic 339-406 MB)
+TRAFFIC_DIRECT = int((75139.8 * 2 + 65536.0) * 1024)    # conv_mfma_dma_kernel 256x256 (algorithmic 204 MB)
+TRAFFIC_SRC = "profiles/r01_rocprofv3_pmc_{fetch,write}_bottleneck_{winograd,conv_256x256tile}.txt"
 
 
 def cpu_baseline(cfg, sd, size, frames):
@@ -202,7 +206,12 @@ def main():
                          "kernel": ("wino_gemm_kernel<1,2,4,2> (bottleneck 3x3 256->256 @64x64 in Winograd F(2x2,3x3) form)"
                                     if wino else "conv_mfma_dma_kernel<3,3,...> (bottleneck 3x3 256->256 @64x64, direct)"),
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
+                         # note in MI355X_MICROARCH.md, + WRITE_SIZE) -- measured once with tools/gpu_profile.sh at this
+                         # workload (batch 16, 256x256) and committed under profiles/; not re-measured by this run
+                         "traffic": (TRAFFIC_WINO if wino else TRAFFIC_DIRECT) if (B == 16 and S == 256) else None,
+                         "traffic_unit": "bytes/launch", "traffic_source": TRAFFIC_SRC,
                          "avg_launch_ms": round(ms_conv, 4), "executed_gflop_per_launch": round(exec_flop / 1e9, 2),
                          "achieved_algorithmic": round(algo, 2),
                          "frac_algorithmic": round(algo / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -59,6 +59,18 @@ __device__ __forceinline__ void quad_decode(int m, int Hq, int Wq, int& b, int& 
     x = 2 * qx + (jj & 1);
 }
 
+// pixel m -> (b, y, x) in the launch's enumeration: 2x2 quads (pooling windows / Winograd tiles) or raster
+__device__ __forceinline__ void pix_decode(const ConvArgs& p, int m, int& b, int& y, int& x) {
+    if (p.linear) {
+        x = m % p.W;
+        const int t = m / p.W;
+        y = t % p.H;
+        b = t / p.H;
+    } else {
+        quad_decode(m, p.H >> 1, p.W >> 1, b, y, x);
+    }
+}
+
 // one output element through the epilogue (shared by the fused path and the split-K reduction)
 __device__ __forceinline__ void epilogue_store(const ConvArgs& p, int phase, int b, int y, int x, int n, float v,
                                                float s2, float t2) {
@@ -92,7 +104,6 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, Acc& acc, f
     constexpr int BN = WN * NT * 32, R = WM * 32, LDO = BN + 4, NTHR = WM * WN * 64;
     constexpr int C4 = BN / 4, PER = R * C4 / NTHR;
     static_assert((R * C4) % NTHR == 0, "tile must split evenly over the threads");
-    const int Wq = p.W >> 1, Hq = p.H >> 1;
     const int OH = p.nphase == 4 ? 2 * p.H : p.H, OW = p.nphase == 4 ? 2 * p.W : p.W;
     static_for<MT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -117,7 +128,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, Acc& acc, f
             if (m < p.M && n < p.Cout) {
                 float4 v = *reinterpret_cast<const float4*>(smem + row * LDO + c4 * 4);
                 int b, y, x;
-                quad_decode(m, Hq, Wq, b, y, x);
+                pix_decode(p, m, b, y, x);
                 if (p.nphase == 4) {
                     y = 2 * y + (phase >> 1);
                     x = 2 * x + (phase & 1);
@@ -159,7 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, Acc& acc, int m
                 static_for<16>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     const int m = mbase + wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    slab[(size_t)m * p.Npad + n] = acc[i][j][r];
+                    if (m < p.M) slab[(size_t)m * p.Npad + n] = acc[i][j][r];  // rows past M are never reduced
                 });
             });
         });
@@ -188,6 +199,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, Acc& acc, int m
                             v += apply_act(acc[i][j][4 * g + e] + bias, p.act);
                         });
                         p.out[(size_t)(m0 >> 2) * p.Cout + n] = 0.25f * v;
+                    } else if (p.linear) {
+                        static_for<4>([&](auto ec) {
+                            constexpr int e = decltype(ec)::value;
+                            if (m0 + e < p.M) {
+                                int b, y, x;
+                                pix_decode(p, m0 + e, b, y, x);
+                                epilogue_store(p, phase, b, y, x, n, acc[i][j][4 * g + e] + bias, s2, t2);
+                            }
+                        });
                     } else {
                         int b, y, x;
                         quad_decode(m0, Hq, Wq, b, y, x);

@@ -72,14 +72,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
 
     // ---- operand loader state: this thread stages rows arow+32j, 16 bytes at column acol
     const int arow = tid >> 3, acol = (tid & 7) * 4;
-    const int Wq = p.W >> 1, Hq = p.H >> 1;
     int ry[A_PER], rx[A_PER], rb[A_PER];
 #pragma unroll
     for (int j = 0; j < A_PER; ++j) {
         const int m = mbase + arow + 32 * j;
         if (m < p.M) {
             int b;
-            quad_decode(m, Hq, Wq, b, ry[j], rx[j]);
+            pix_decode(p, m, b, ry[j], rx[j]);
             rb[j] = b * p.H * p.W;
         } else {
             ry[j] = -(1 << 20);  // never inside the image
@@ -181,7 +180,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs p, in
     const size_t total = per_phase * p.nphase;
     const float* __restrict__ partial = p.partial;
     const size_t slab = (size_t)p.Mpad * p.Npad;
-    const int Wq = p.W >> 1, Hq = p.H >> 1;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int phase = (int)(idx / per_phase);
@@ -203,7 +201,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs p, in
             for (int sp = 0; sp < splits; ++sp)
                 s += partial[(size_t)(sp * p.nphase + phase) * slab + (size_t)r * p.Npad + n];
             int b, y, x;
-            quad_decode(r, Hq, Wq, b, y, x);
+            pix_decode(p, r, b, y, x);
             float s2 = 0.f, t2 = 0.f;
             if (p.out2 != nullptr) {
                 s2 = p.s2[n];
@@ -380,7 +378,8 @@ hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream,
     a.out2 = io.out2;
     a.s2 = io.s2;
     a.t2 = io.t2;
-    if ((a.H & 1) || (a.W & 1)) return hipErrorInvalidValue;
+    a.linear = ((a.H | a.W) & 1) ? 1 : 0;                   // odd side: raster order (2x2 quads need even sides)
+    if (a.linear && io.pool) return hipErrorInvalidValue;   // AvgPool2d(2) windows are the quads
     if (pl.splits > 1 && io.partial == nullptr) return hipErrorInvalidValue;
     if (L.phase && io.pool) return hipErrorInvalidValue;
     const int blocks = pl.mtiles * pl.ntiles * a.nphase * pl.splits;

@@ -61,7 +61,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_dma_kernel(const ConvAr
 
     // ---- A loader: DMA instruction j of this wave fills rows (wave*A_INSTR + j)*8 .. +8; lane -> row
     // rbase + lane/8, physical slot lane%8, i.e. channel slot (lane%8) ^ swz(row) of that pixel.
-    const int Wq = p.W >> 1, Hq = p.H >> 1;
     int ry[A_INSTR], rx[A_INSTR], rb[A_INSTR], rq[A_INSTR];
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_dma_kernel(const ConvAr
         const int m = mbase + row;
         if (m < p.M) {
             int b;
-            quad_decode(m, Hq, Wq, b, ry[j], rx[j]);
+            pix_decode(p, m, b, ry[j], rx[j]);
             rb[j] = b * p.H * p.W;
         } else {
             ry[j] = -(1 << 20);

@@ -122,8 +122,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
         return fail(nullptr, EAMM_ERR_ARG, "need at least one down block and one bottleneck block");
     if (g.max_frames < 1 || g.max_sources < 1) return fail(nullptr, EAMM_ERR_ARG, "max_frames / max_sources < 1");
     const int div_g = 1 << g.num_down_blocks, div_m = g.dm_inv_scale << g.dm_num_blocks;
-    if (g.height % div_g || g.width % div_g || g.height % div_m || g.width % div_m ||
-        g.height / div_m < 2 || g.width / div_m < 2)
+    if (g.height % div_g || g.width % div_g || g.height % div_m || g.width % div_m)
         return fail(nullptr, EAMM_ERR_ARG, "frame %dx%d not divisible for %d down blocks / %d hourglass levels",
                     g.height, g.width, g.num_down_blocks, g.dm_num_blocks);
     {   // the kernels address tensors through 32-bit buffer descriptors: every activation must stay below 4 GiB

@@ -73,8 +73,7 @@ int eamm_kp_create(const eamm_kp_config* cfg, int device, eamm_kp_ctx** out) {
     if (!(g.temperature > 0.f)) return fail(nullptr, EAMM_ERR_ARG, "temperature must be positive");
     if (g.max_batch < 1) return fail(nullptr, EAMM_ERR_ARG, "max_batch < 1");
     const int div = g.inv_scale << (g.with_predictor ? g.num_blocks : 0);
-    if (g.height % div || g.width % div || g.height / g.inv_scale < 8 || g.width / g.inv_scale < 8 ||
-        (g.with_predictor && (g.height / div < 2 || g.width / div < 2)))
+    if (g.height % div || g.width % div || g.height / g.inv_scale < 8 || g.width / g.inv_scale < 8)
         return fail(nullptr, EAMM_ERR_ARG, "frame %dx%d not divisible for scale 1/%d and %d hourglass levels", g.height,
                     g.width, g.inv_scale, g.num_blocks);
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice(%d) failed", device);

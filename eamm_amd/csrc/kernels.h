@@ -20,6 +20,7 @@ struct ConvArgs {
     int C0, C1;            // multiples of CONV_BK
     unsigned in0_bytes, in1_bytes, w_bytes;  // buffer-descriptor ranges
     int H, W;              // input size (even); phase mode writes a 2H x 2W output
+    int linear;            // 1: pixels enumerated in raster order (odd H or W; never with pool) instead of 2x2 quads
     int nphase;            // 1, or 4 = collapsed "nearest x2 + 3x3" (one 2x2 filter per output parity)
     int M;                 // B*H*W
     const float* w;        // packed [nphase][ntiles][nchunks][BN][BK], BatchNorm already folded in

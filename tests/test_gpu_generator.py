@@ -165,6 +165,44 @@ def test_edge_cases_and_errors():
     assert float((b.cpu() - ref).abs().max()) <= TOL["prediction"]
 
 
+VARIANTS = {
+    # name: (config overrides, dense_motion overrides, H, W)
+    "rect_64x96": ({}, {}, 64, 96),
+    "scale_half": ({}, {"scale_factor": 0.5}, 64, 64),          # motion grid 32x32 vs feature map 16x16: flow is resized
+    "scale_one": ({"num_down_blocks": 1}, {"scale_factor": 1, "num_blocks": 2}, 32, 32),   # no anti-alias buffer at all
+    "no_occlusion": ({"estimate_occlusion_map": False}, {}, 64, 64),
+    "three_down": ({"num_down_blocks": 3, "max_features": 256}, {}, 64, 64),   # feature map 8x8 vs motion grid 16x16
+}
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_constructor_variants_match_oracle(name):
+    """Constructor variants of the reference module beyond the shipped YAML (generator.py:14-48, dense_motion.py:12-30):
+    rectangular frames, other scale factors (flow / occlusion bilinear resize, generator.py:52-56,82-83), no
+    occlusion head -- each against the CPU oracle on the same seeded weights."""
+    over, dm_over, H, W = VARIANTS[name]
+    cfg = tiny_config()
+    cfg.update(over)
+    cfg["dense_motion_params"] = {**cfg["dense_motion_params"], **dm_over}
+    sd = synthetic_state_dict(cfg, seed=4321)
+    gen = OcclusionAwareGenerator(**cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    n = 2
+    rs = np.random.RandomState(9)
+    src = torch.from_numpy(rs.uniform(0, 1, (n, 3, H, W)).astype(np.float32))
+    kp_s, kp_d = synthetic_keypoints(n, 10, seed=0), synthetic_keypoints(n, 10, seed=2)
+    out = gen(src.to(DEV), kp_source=cuda(kp_s), kp_driving=cuda(kp_d))
+    with torch.no_grad():
+        ref = orc.generator_forward(sd, cfg, src, kp_d, kp_s)
+    keys = [k for k in KEYS if k in ref]
+    assert set(out) == set(keys)
+    errs = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in keys}
+    report(name, errs)
+    for k in keys:
+        assert out[k].shape == ref[k].shape and errs[k] <= TOL[k], (name, k, errs[k])
+
+
 def test_source_cache_export_import_roundtrip():
     """The multi-GPU broadcast payload: export on one handle, import on another, identical frames."""
     from eamm_amd import Engine

@@ -77,6 +77,10 @@ CASES = {
     "3x3_splitk4":       dict(B=1, H=8, W=8, C0=64, C1=0, Cout=64, ks=3, act=1, splitk=4),
     "3x3_tile64_as_32":  dict(B=1, H=16, W=16, C0=32, C1=0, Cout=64, ks=3, tile_n=32),
     "3x3_tile128_as_64": dict(B=1, H=16, W=16, C0=32, C1=0, Cout=128, ks=3, tile_n=64),
+    "3x3_odd_linear":    dict(B=2, H=5, W=7, C0=32, C1=0, Cout=64, ks=3, act=1),
+    "3x3_up_odd_2x3":    dict(B=1, H=2, W=3, C0=64, C1=0, Cout=128, ks=3, up=1, act=1),
+    "3x3_up_odd_split":  dict(B=3, H=3, W=3, C0=96, C1=32, Cout=32, ks=3, up=1, resid=True, splitk=2),
+    "dma_odd_linear":    dict(B=2, H=9, W=15, C0=32, C1=0, Cout=128, ks=3, resid=True, tile_n=1002),
     "3x3_up_tile128":    dict(B=1, H=16, W=16, C0=64, C1=0, Cout=128, ks=3, up=1, act=1),
     "3x3_up_splitk3":    dict(B=1, H=4, W=6, C0=96, C1=32, Cout=64, ks=3, up=1, act=1, splitk=3),
     "3x3_up_resid":      dict(B=1, H=8, W=8, C0=32, C1=0, Cout=32, ks=3, up=1, resid=True),
