@@ -99,8 +99,12 @@ def main():
     backend = os.environ.get("EAMM_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     local = local % max(1, ndev) if backend != "nccl" else local
-    if world > 1:
+    # EAMM_BENCH_FORCE_DIST=1 runs the collective code path even with one rank (a 1-GPU box can then check that
+    # RCCL initialises and that broadcast / barrier / all-reduce work in this environment)
+    use_dist = world > 1 or os.environ.get("EAMM_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":   # = RCCL on ROCm, one rank per GPU over xGMI
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -135,7 +139,7 @@ def main():
     t_bcast_ms = None
     if rank == 0:
         eng.encode_source(synthetic_source(S, seed=1).to(dev))
-    if world > 1:
+    if use_dist:
         blob = eng.export_source_cache(1) if rank == 0 else torch.empty(eng.source_cache_numel(1), device=dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -152,7 +156,7 @@ def main():
         return eng.forward_frames(kp_d, kp_s, outputs=("prediction",))
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,7 +173,7 @@ def main():
     prof = eng.profile_read(reset=True)
     eng.profile(False)
     eng.check_numeric()
-    if world > 1:
+    if use_dist:
         dt = max_over_ranks(dt)
 
     if rank == 0:
@@ -229,7 +233,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

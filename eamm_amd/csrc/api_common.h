@@ -33,7 +33,8 @@ thread_local std::string g_create_error;
 // big-tile kernel; conv launches pick by problem size (see pick()).
 struct LayerSet {
     ConvLayer base, dma, big;
-    bool has_dma = false, has_big = false;
+    PatchLayer patch;           // UpBlock2d layers only: spatial-patch kernel (conv_mfma_patch.hip)
+    bool has_dma = false, has_big = false, has_patch = false;
 };
 
 
@@ -49,6 +50,7 @@ struct CtxBase {
     int dma_min_m = 1024;       // smallest per-phase M for which an LDS-DMA tile is preferred
     int big_min_m = 49152;      // ... and for which Cout % 256 == 0 layers use the 256x256 tile (>= 192 M tiles)
     int dma_cfg_n256 = 2, dma_cfg_n128 = 2, dma_cfg_n64 = 3;
+    int patch_min_blocks = 192; // fewest workgroups for which UpBlock2d layers use the spatial-patch kernel (< 0: never)
 };
 
 int fail(CtxBase* c, int code, const char* fmt, ...) {
@@ -191,6 +193,38 @@ int build_layer(CtxBase* c, const std::vector<FoldSpec>& parts, int ks, int C0_r
     return upload(c, &L->bias, bias_pad);
 }
 
+// UpBlock2d conv + BatchNorm -> spatial-patch packing (same fold as build_layer, phase filters pre-summed on the host)
+int build_patch(CtxBase* c, const std::string& conv, const std::string& norm, int C0_real, int C0_packed, int C1_real,
+                int C1_packed, PatchLayer* P) {
+    const int Cin = C0_real + C1_real;
+    const HostTensor *wt = find(c, conv + ".weight"), *bt = find(c, conv + ".bias");
+    const HostTensor *g = find(c, norm + ".weight"), *be = find(c, norm + ".bias"), *mu = find(c, norm + ".running_mean"),
+                     *var = find(c, norm + ".running_var");
+    if (!wt || !bt || !g || !be || !mu || !var || wt->shape.size() != 4 || wt->shape[1] != Cin || wt->shape[2] != 3)
+        return fail(c, EAMM_ERR_KEY, "%s mis-shaped for the patch kernel", conv.c_str());
+    const int Cout = (int)wt->shape[0];
+    std::vector<float> wf(wt->data), bf(Cout);
+    for (int o = 0; o < Cout; ++o) {
+        const double sc = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+        bf[o] = (float)(((double)bt->data[o] - (double)mu->data[o]) * sc + (double)be->data[o]);
+        for (size_t i = 0; i < (size_t)Cin * 9; ++i) wf[(size_t)o * Cin * 9 + i] = (float)((double)wt->data[(size_t)o * Cin * 9 + i] * sc);
+    }
+    const int cin_packed = C0_packed + C1_packed;
+    std::vector<int> map(cin_packed, -1);
+    for (int i = 0; i < C0_real; ++i) map[i] = i;
+    for (int i = 0; i < C1_real; ++i) map[C0_packed + i] = C0_real + i;
+    P->C0 = C0_packed;
+    P->C1 = C1_packed;
+    P->Cout = Cout;
+    std::vector<float> packed(patch_packed_elems(cin_packed, Cout));
+    patch_pack_host(wf.data(), Cout, Cin, map.data(), cin_packed, packed.data());
+    std::vector<float> bias_pad((size_t)((Cout + 63) / 64) * 64, 0.f);
+    std::copy(bf.begin(), bf.end(), bias_pad.begin());
+    int rc = upload(c, &P->w, packed);
+    if (rc) return rc;
+    return upload(c, &P->bias, bias_pad);
+}
+
 int build_set(CtxBase* c, const std::vector<FoldSpec>& parts, int C0_real, int C0_packed, int C1_real, int C1_packed,
               LayerSet* S, LayerMode mode) {
     int rc = build_layer(c, parts, 3, C0_real, C0_packed, C1_real, C1_packed, &S->base, mode);
@@ -210,8 +244,15 @@ int build_set(CtxBase* c, const std::vector<FoldSpec>& parts, int C0_real, int C
             S->has_big = true;
         }
     }
+    if (mode == MODE_PHASE && parts.size() == 1 && !parts[0].norm.empty() && (Cout & 3) == 0 && c->patch_min_blocks >= 0) {
+        rc = build_patch(c, parts[0].conv, parts[0].norm, C0_real, C0_packed, C1_real, C1_packed, &S->patch);
+        if (rc) return rc;
+        S->has_patch = true;
+    }
     return 0;
 }
+
+
 
 // Tile choice per launch (measured on MI355X, profiles/r01_convbench_*): M is the per-phase pixel count.
 // conv (+ folded BatchNorm) -> Winograd-domain weights U = G g G^T
@@ -248,6 +289,19 @@ const ConvLayer& pick(const CtxBase* c, const LayerSet& S, size_t M) {
     return (S.has_dma && M >= (size_t)c->dma_min_m) ? S.dma : S.base;
 }
 
+// UpBlock2d launch: the spatial-patch kernel when its 16x16-pixel tiles fill the chip, else the im2col-style kernels
+int launch_up(CtxBase* c, const LayerSet& S, const ConvIO& io, hipStream_t s) {
+    if (S.has_patch) {
+        const int blocks = ((io.Hin + 15) / 16) * ((io.Win + 15) / 16) * io.B * ((S.patch.Cout + 63) / 64);
+        if (blocks >= c->patch_min_blocks && io.Hin >= 16 && io.Win >= 16 && io.act == ACT_RELU && !io.resid && !io.out2 && !io.pool && !io.nchw) {
+            HIP_TRY(c, patch_phase_launch(S.patch, io.in0, io.in1, io.B, io.Hin, io.Win, io.act, io.out, s));
+            return EAMM_OK;
+        }
+    }
+    HIP_TRY(c, conv_launch(pick(c, S, (size_t)io.B * io.Hin * io.Win), io, s));
+    return EAMM_OK;
+}
+
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -265,6 +319,7 @@ inline void read_tile_knobs(CtxBase* c) {
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
     c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);
     c->dma_cfg_n64 = env_int("EAMM_DMA_CFG_N64", c->dma_cfg_n64);
+    c->patch_min_blocks = env_int("EAMM_PATCH_MIN_BLOCKS", c->patch_min_blocks);
 }
 
 inline void free_owned(CtxBase* c) {

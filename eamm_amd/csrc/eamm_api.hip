@@ -458,7 +458,7 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         io.out = c->u_buf[i];
         io.partial = c->partial;
         io.partial_cap = c->partial_elems;
-        HIP_TRY(c, conv_launch(pick(c, c->hg_dec[i], (size_t)n * io.Hin * io.Win), io, s));
+        if (int urc = launch_up(c, c->hg_dec[i], io, s)) return urc;
     }
     STAGE_MARK(3);
     // mask / occlusion logits, then softmax + flow combine + sigmoid         dense_motion.py:98-111
@@ -558,7 +558,7 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         io.out = c->up_buf[i];
         io.partial = c->partial;
         io.partial_cap = c->partial_elems;
-        HIP_TRY(c, conv_launch(pick(c, c->up[i], (size_t)n * io.Hin * io.Win), io, s));
+        if (int urc = launch_up(c, c->up[i], io, s)) return urc;
         cur = c->up_buf[i];
     }
     STAGE_MARK(7);
@@ -691,6 +691,46 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: bad argument");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (tile_n == 3000) {  // spatial-patch kernel for the collapsed up-convolution
+        if (kh != 3 || kw != 3 || !up || pool || resid || splitk > 1 || (Cout & 3))
+            return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported patch-kernel configuration");
+        PatchLayer P;
+        P.C0 = C0;
+        P.C1 = C1;
+        P.Cout = Cout;
+        std::vector<float> packed(patch_packed_elems(C0 + C1, Cout)), bias((size_t)((Cout + 63) / 64) * 64, 0.f);
+        patch_pack_host(w_host, Cout, C0 + C1, nullptr, C0 + C1, packed.data());
+        std::copy(b_host, b_host + Cout, bias.begin());
+        int rc = EAMM_OK;
+        auto bad = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess) rc = fail(nullptr, EAMM_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+            return e != hipSuccess;
+        };
+        if (!bad(hipMalloc((void**)&P.w, packed.size() * sizeof(float)), "hipMalloc") &&
+            !bad(hipMalloc((void**)&P.bias, bias.size() * sizeof(float)), "hipMalloc") &&
+            !bad(hipMemcpy(P.w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
+            !bad(hipMemcpy(P.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")) {
+            auto run = [&]() { return patch_phase_launch(P, in0, in1, B, Hin, Win, act, out, s); };
+            if (!bad(run(), "patch launch") && iters > 0 && avg_ms) {
+                hipEvent_t e0, e1;
+                (void)hipEventCreate(&e0);
+                (void)hipEventCreate(&e1);
+                (void)hipEventRecord(e0, s);
+                for (int i = 0; i < iters; ++i) (void)run();
+                (void)hipEventRecord(e1, s);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                *avg_ms = ms / iters;
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+            }
+            bad(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
+        if (P.w) (void)hipFree(P.w);
+        if (P.bias) (void)hipFree(P.bias);
+        return rc;
+    }
     if (tile_n >= 2000 && tile_n < 2100) {  // Winograd F(2x2,3x3): input transform + GEMM (2000 + kernel variant)
         if (kh != 3 || kw != 3 || up || pool || C1 || splitk > 1 || C0 % 64 || (Cout & 3))
             return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported Winograd configuration");

@@ -220,7 +220,7 @@ int eamm_kp_detect(eamm_kp_ctx* c, const float* image, int B, const eamm_kp_outp
         io.out = c->u_buf[i];
         io.partial = c->partial;
         io.partial_cap = c->partial_elems;
-        HIP_TRY(c, conv_launch(pick(c, c->hg_dec[i], (size_t)B * io.Hin * io.Win), io, s));
+        if (int urc = launch_up(c, c->hg_dec[i], io, s)) return urc;
     }
     return run_head(c, c->u_buf[c->nb - 1], c->x_in, B, o, s);   // keypoint_detector.py:83-103
 }

@@ -80,6 +80,17 @@ struct ConvIO {
 };
 hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream, int force_splits = 0);
 
+// ---- spatial-patch (halo in LDS) kernel for the collapsed UpBlock2d convolution (conv_mfma_patch.hip)
+struct PatchLayer {
+    int C0 = 0, C1 = 0, Cout = 0;
+    float* w = nullptr;     // device, packed [ntile][cchunk][phase][tap][64][32]
+    float* bias = nullptr;  // device, [ntiles*64]
+};
+size_t patch_packed_elems(int Cin_packed, int Cout);
+void patch_pack_host(const float* w_oihw_3x3, int Cout, int Cin, const int* cin_map, int cin_packed, float* dst);
+hipError_t patch_phase_launch(const PatchLayer& L, const float* in0, const float* in1, int B, int H, int W, int act,
+                              float* out, hipStream_t stream);
+
 // ---- Winograd F(2x2,3x3) path for the bottleneck convolutions (conv_winograd.hip)
 struct WinoLayer {
     int Cin = 0, Cout = 0, BN = 128, ntiles = 0;

@@ -49,3 +49,15 @@ def test_bench_two_ranks_share_one_gpu():
             env={"EAMM_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and "source_broadcast_ms" in d
     assert abs(d["value"] - 2 * 3 * 16 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01   # whole-job frames / max time
+
+
+def test_bench_rccl_path_single_rank():
+    """The real backend (nccl = RCCL) with a one-rank group: init with device_id, broadcast of the source cache,
+    barrier + all-reduce(MAX) around the timed region -- the calls the driver's N>1 runs make."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-frames", "0"],
+            env={"EAMM_BENCH_FORCE_DIST": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
+                 "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    assert d["n_gpus"] == 1 and "source_broadcast_ms" in d and d["value"] > 0

@@ -57,6 +57,8 @@ def main():
                 continue
             if 2000 <= tile < 2100 and (up or pool or C1 or C0 % 64):
                 continue
+            if tile == 3000 and (not up or resid):
+                continue
             if 1000 < tile < 2000 and {1001: 256, 1002: 128, 1003: 64}[tile] > max(Cout, 64) * 2:
                 continue
             ms = C.c_float()
