@@ -203,6 +203,32 @@ def test_constructor_variants_match_oracle(name):
         assert out[k].shape == ref[k].shape and errs[k] <= TOL[k], (name, k, errs[k])
 
 
+def test_module_forward_source_cache():
+    """forward() skips the source encoder only for the very same, unmodified tensor object; an in-place change or a
+    different tensor re-encodes (results must track the data, as in the reference which always re-encodes)."""
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    gen = OcclusionAwareGenerator(**cfg)
+    gen.load_state_dict(sd)
+    gen = gen.to(DEV).eval()
+    kp_s, kp_d = cuda(synthetic_keypoints(1, 10, seed=0)), cuda(synthetic_keypoints(1, 10, seed=2))
+    src = synthetic_source(64, seed=1).to(DEV)
+    a = gen(src, kp_source=kp_s, kp_driving=kp_d)["prediction"].clone()
+    b = gen(src, kp_source=kp_s, kp_driving=kp_d)["prediction"]          # cached encoder
+    assert torch.equal(a, b)
+    src.mul_(0.5)                                                          # in-place edit of the same object
+    c = gen(src, kp_source=kp_s, kp_driving=kp_d)["prediction"]
+    with torch.no_grad():
+        ref = orc.generator_forward(sd, cfg, src.cpu(), {k: v.cpu() for k, v in kp_d.items()}, {k: v.cpu() for k, v in kp_s.items()})
+    assert float((c.cpu() - ref["prediction"]).abs().max()) <= TOL["prediction"] and float((a - c).abs().max()) > 1e-3
+    other = synthetic_source(64, seed=5).to(DEV)                           # a different tensor
+    d = gen(other, kp_source=kp_s, kp_driving=kp_d)["prediction"]
+    assert float((d - c).abs().max()) > 1e-3
+    gen.encode_source(src)                                                 # clip API use in between invalidates
+    e = gen(other, kp_source=kp_s, kp_driving=kp_d)["prediction"]
+    assert torch.equal(d, e)
+
+
 def test_forward_frames_is_graph_capturable():
     """eamm_forward_frames enqueues only kernels / stream-ordered copies on the caller's stream (no hidden
     synchronisation or allocation), so the launch sequence can be captured into a HIP graph and replayed bit-exactly."""
