@@ -33,6 +33,8 @@ struct eamm_ctx : eamm::CtxBase {
     int wino_variant = 0;                  // wino_gemm_kernel pipeline variant (see wino_gemm_launch); in-pipeline all are within noise
     std::vector<float*> pre_s, pre_t;  // res-block pre-activation scale/shift (norm1)
     float* aa_w = nullptr;
+    float* head_bias = nullptr;    // mask / occlusion biases when the head runs row-split (applied by the head kernel)
+    int head_nc = 0;               // > 0: head is a 7x1 convolution over (dx, co), co < head_nc
     float* final_bias = nullptr;   // bias of the final conv, applied by the shift-sum kernel
     float* final_part = nullptr;   // [F,H,W,32] (dx,co) partial products of the final 7x7 conv
 
@@ -211,7 +213,18 @@ int eamm_finalize_weights(eamm_ctx* c) {
     {
         std::vector<FoldSpec> parts = {{dm + "mask", ""}};
         if (g.estimate_occlusion_map) parts.push_back({dm + "occlusion", ""});
-        if ((rc = build_layer(c, parts, 7, c->dec_c.back(), c->dec_c.back(), cin0, c->Cp0, &c->head))) return rc;
+        const int nc = c->K + 1 + (g.estimate_occlusion_map ? 1 : 0);
+        if (7 * nc <= 128 && env_int("EAMM_HEAD_ROWSPLIT", 1)) {
+            // 7x1 MFMA convolution with N = (dx, co) + horizontal gather in the head kernel: pads N to 7*nc (84) of
+            // 128 instead of nc (12) of 32 -> 2.3x fewer executed MACs
+            std::vector<float> hb;
+            if ((rc = build_layer(c, parts, 7, c->dec_c.back(), c->dec_c.back(), cin0, c->Cp0, &c->head, MODE_ROWSPLIT, &hb)))
+                return rc;
+            if ((rc = upload(c, &c->head_bias, hb))) return rc;
+            c->head_nc = nc;
+        } else if ((rc = build_layer(c, parts, 7, c->dec_c.back(), c->dec_c.back(), cin0, c->Cp0, &c->head))) {
+            return rc;
+        }
     }
     // generator encoder
     if ((rc = build_layer(c, {{"first.conv", "first.norm"}}, 7, 3, c->Csrc, 0, 0, &c->first))) return rc;
@@ -296,7 +309,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
         if ((rc = dev_alloc(c, &c->e_buf[i], F * (hw >> (2 * (i + 1))) * c->enc_c[i]))) return rc;
         if ((rc = dev_alloc(c, &c->u_buf[i], F * (hw >> (2 * (c->nb - 1 - i))) * c->dec_c[i]))) return rc;
     }
-    if ((rc = dev_alloc(c, &c->logits, F * hw * 32))) return rc;
+    if ((rc = dev_alloc(c, &c->logits, F * hw * (c->head_nc ? 128 : 32)))) return rc;
     if ((rc = dev_alloc(c, &c->deformation, F * hw * 2))) return rc;
     if ((rc = dev_alloc(c, &c->occlusion, F * hw))) return rc;
     if ((rc = dev_alloc(c, &c->xa, F * hwf * c->Cb))) return rc;
@@ -474,11 +487,18 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         io.partial = c->partial;
         io.partial_cap = c->partial_elems;
         ConvLayer head = c->head;
-        head.Cout = 32;  // logits are written with a 32-float pixel stride; channels >= K+2 have zero weights
-        HIP_TRY(c, conv_launch(head, io, s));
         float* defo = c->deformation;
-        HIP_TRY(c, motion_head_launch(c->logits, c->kp_rec, n, K, h, w, occ ? 1 : 0, defo, c->occlusion, o->mask,
-                                      o->occlusion_map, s));
+        if (c->head_nc) {
+            head.Cout = 128;  // partial products written with a 128-float pixel stride (7*nc used)
+            HIP_TRY(c, conv_launch(head, io, s));
+            HIP_TRY(c, motion_head_rowsplit_launch(c->logits, 128, c->head_nc, c->head_bias, c->kp_rec, n, K, h, w,
+                                                   occ ? 1 : 0, defo, c->occlusion, o->mask, o->occlusion_map, s));
+        } else {
+            head.Cout = 32;  // logits are written with a 32-float pixel stride; channels >= K+2 have zero weights
+            HIP_TRY(c, conv_launch(head, io, s));
+            HIP_TRY(c, motion_head_launch(c->logits, c->kp_rec, n, K, h, w, occ ? 1 : 0, defo, c->occlusion, o->mask,
+                                          o->occlusion_map, s));
+        }
         if (o->deformation)
             HIP_TRY(c, hipMemcpyAsync(o->deformation, defo, (size_t)n * h * w * 2 * sizeof(float),
                                       hipMemcpyDeviceToDevice, s));

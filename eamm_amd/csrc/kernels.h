@@ -115,6 +115,10 @@ hipError_t motion_head_launch(const float* logits /*[n,h,w,32]*/, const float* k
                               int has_occ, float* deformation /*[n,h,w,2]*/, float* occlusion /*[n,h,w]*/,
                               float* mask_out /*[n,K+1,h,w] or null*/, float* occ_out /*[n,1,h,w] or null*/,
                               hipStream_t s);
+hipError_t motion_head_rowsplit_launch(const float* part /*[n,h,w,PS]: channel dx*NC+co*/, int PS, int NC,
+                                       const float* bias /*[NC] dev*/, const float* kp_rec, int n, int K, int h, int w,
+                                       int has_occ, float* deformation, float* occlusion, float* mask_out,
+                                       float* occ_out, hipStream_t s);
 hipError_t warp_features_launch(const float* feat /*[ns,hf,wf,C]*/, const float* deformation /*[n,h,w,2]*/,
                                 const float* occlusion /*[n,h,w] or null*/, int n, int ns, int hf, int wf, int C,
                                 int h, int w, float* out, float* out2, const float* s2, const float* t2,

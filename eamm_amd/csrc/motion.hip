@@ -160,24 +160,18 @@ __global__ __launch_bounds__(256) void motion_front_kernel(const float* __restri
 // [n,h,w,32] (channels 0..K mask, K+1 occlusion, rest padding).
 // ---------------------------------------------------------------------------------------------
 constexpr int HEAD_MAXK = 31;
-__global__ __launch_bounds__(256) void motion_head_kernel(const float* __restrict__ logits,
-                                                          const float* __restrict__ rec_all, int K, int h, int w,
-                                                          int has_occ, float* __restrict__ deformation,
-                                                          float* __restrict__ occlusion, float* __restrict__ mask_out,
-                                                          float* __restrict__ occ_out) {
-    const int f = blockIdx.y;
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pi >= h * w) return;
+
+// l[0..K] mask logits, l[K+1] occlusion logit of pixel pi of frame f -> softmax, flow, sigmoid, outputs
+__device__ __forceinline__ void head_finish(float (&l)[32], const float* __restrict__ rec, int K, int h, int w, int f,
+                                            int pi, int has_occ, float* __restrict__ deformation,
+                                            float* __restrict__ occlusion, float* __restrict__ mask_out,
+                                            float* __restrict__ occ_out) {
     const int y = pi / w, x = pi - y * w;
     const float gx = grid_coord(x, w), gy = grid_coord(y, h);
-    const float* rec = rec_all + (size_t)f * K * KP_STRIDE;
-    const float4* lg4 = reinterpret_cast<const float4*>(logits + ((size_t)f * h * w + pi) * 32);
-    float l[32];
+    float ov = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float4 v = lg4[i];
-        l[4 * i + 0] = v.x; l[4 * i + 1] = v.y; l[4 * i + 2] = v.z; l[4 * i + 3] = v.w;
-    }
+    for (int k = 1; k < 32; ++k)
+        if (k == K + 1) ov = l[k];
     float mx = l[0];
 #pragma unroll
     for (int k = 1; k < 32; ++k)
@@ -203,14 +197,68 @@ __global__ __launch_bounds__(256) void motion_head_kernel(const float* __restric
         }
     reinterpret_cast<float2*>(deformation)[(size_t)f * plane + pi] = make_float2(dx, dy);
     if (has_occ) {
-        float ov = 0.f;
-#pragma unroll
-        for (int k = 1; k < 32; ++k)
-            if (k == K + 1) ov = l[k];
         const float o = 1.f / (1.f + expf(-ov));
         occlusion[(size_t)f * plane + pi] = o;
         if (occ_out) occ_out[(size_t)f * plane + pi] = o;
     }
+}
+
+__global__ __launch_bounds__(256) void motion_head_kernel(const float* __restrict__ logits,
+                                                          const float* __restrict__ rec_all, int K, int h, int w,
+                                                          int has_occ, float* __restrict__ deformation,
+                                                          float* __restrict__ occlusion, float* __restrict__ mask_out,
+                                                          float* __restrict__ occ_out) {
+    const int f = blockIdx.y;
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= h * w) return;
+    const float4* lg4 = reinterpret_cast<const float4*>(logits + ((size_t)f * h * w + pi) * 32);
+    float l[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 v = lg4[i];
+        l[4 * i + 0] = v.x; l[4 * i + 1] = v.y; l[4 * i + 2] = v.z; l[4 * i + 3] = v.w;
+    }
+    head_finish(l, rec_all + (size_t)f * K * KP_STRIDE, K, h, w, f, pi, has_occ, deformation, occlusion, mask_out,
+                occ_out);
+}
+
+// Row-split form: the 7x7 head ran as a 7x1 (vertical) MFMA convolution with N = (dx, co), co < NC = K+1(+1):
+// part[f,y,x',dx*NC+co] (pixel stride PS floats).  One block = 64 pixels of one row; the 70 x 7*NC partial products
+// are staged in LDS (odd row stride: conflict-free column walks), then each thread gathers its 7 horizontal taps,
+// adds the bias and finishes as above.
+constexpr int HR_TILE = 64;
+__global__ __launch_bounds__(HR_TILE) void motion_head_rowsplit_kernel(const float* __restrict__ part, int PS, int NC,
+                                                                       const float* __restrict__ bias,
+                                                                       const float* __restrict__ rec_all, int K, int h,
+                                                                       int w, int has_occ,
+                                                                       float* __restrict__ deformation,
+                                                                       float* __restrict__ occlusion,
+                                                                       float* __restrict__ mask_out,
+                                                                       float* __restrict__ occ_out) {
+    extern __shared__ float tile[];   // [(HR_TILE + 6)][7*NC | 1]
+    const int NV = 7 * NC, LD = NV | 1;
+    const int x0 = blockIdx.x * HR_TILE, y = blockIdx.y, f = blockIdx.z;
+    const float* row = part + ((size_t)(f * h + y) * w) * PS;
+    for (int i = threadIdx.x; i < (HR_TILE + 6) * NV; i += blockDim.x) {
+        const int px = i / NV, c = i - px * NV;
+        const int x = x0 + px - 3;
+        tile[px * LD + c] = (unsigned)x < (unsigned)w ? row[(size_t)x * PS + c] : 0.f;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= w) return;
+    float l[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        float v = 0.f;
+        if (k < NC) {
+            v = bias[k];
+            for (int dx = 0; dx < 7; ++dx) v += tile[(threadIdx.x + dx) * LD + dx * NC + k];
+        }
+        l[k] = v;
+    }
+    head_finish(l, rec_all + (size_t)f * K * KP_STRIDE, K, h, w, f, y * w + x, has_occ, deformation, occlusion,
+                mask_out, occ_out);
 }
 
 // flow / occlusion at feature-map pixel (y,x): direct read when the motion grid matches the feature
@@ -470,6 +518,16 @@ hipError_t motion_head_launch(const float* logits, const float* kp_rec, int n, i
     if (K > HEAD_MAXK - 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(motion_head_kernel, dim3((h * w + 255) / 256, n), dim3(256), 0, s, logits, kp_rec, K, h, w,
                        has_occ, deformation, occlusion, mask_out, occ_out);
+    return hipGetLastError();
+}
+
+hipError_t motion_head_rowsplit_launch(const float* part, int PS, int NC, const float* bias, const float* kp_rec, int n,
+                                       int K, int h, int w, int has_occ, float* deformation, float* occlusion,
+                                       float* mask_out, float* occ_out, hipStream_t s) {
+    if (K > HEAD_MAXK - 1 || NC > 32) return hipErrorInvalidValue;
+    const size_t lds = sizeof(float) * (HR_TILE + 6) * ((7 * NC) | 1);
+    hipLaunchKernelGGL(motion_head_rowsplit_kernel, dim3((w + HR_TILE - 1) / HR_TILE, h, n), dim3(HR_TILE), lds, s, part,
+                       PS, NC, bias, kp_rec, K, h, w, has_occ, deformation, occlusion, mask_out, occ_out);
     return hipGetLastError();
 }
 
