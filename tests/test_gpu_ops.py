@@ -1,8 +1,5 @@
 """Op-level parity on the GPU: the fp32-MFMA implicit-GEMM convolution (every loader / epilogue /
 split-K variant) through the C ABI entry point eamm_op_conv, against torch-CPU fp32 reference ops."""
-import ctypes as C
-
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
