@@ -222,6 +222,12 @@ def main():
                          "algorithmic_gflop_per_launch": round(algo_flop / 1e9, 2),
                          "avg_input_transform_ms": round(ms_tr, 4),
                          "whole_path_tflops_algorithmic": round(fps / world * eng.flops_per_frame / 1e12, 2)},
+            # the HBM-bound kernel of the path (north_star: ">= 60 % of HBM roofline on the warp"): feature warp x occlusion,
+            # algorithmic bytes per frame = feature map read + written once + flow + occlusion (8.438 MB at 256^2)
+            "roofline_warp": (lambda by, ms: {"bound": "hbm", "kernel": "warp_features_kernel", "achieved": round(by / (ms * 1e-3) / 1e9, 1),
+                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                              "algorithmic_bytes_per_launch": int(by), "avg_launch_ms": round(ms, 4)})(
+                B * (2 * hf * hf * cb + 3 * (S // 4) * (S // 4)) * 4.0, prof["ms"]["warp"] / calls),
             "stage_ms_per_step": {k: round(v / calls, 4) for k, v in prof["ms"].items()},
             "stage_sum_ms": round(total_ms / calls, 4),
         }

@@ -298,12 +298,14 @@ __global__ __launch_bounds__(256) void warp_features_kernel(const float* __restr
                                                             float* __restrict__ out, float* __restrict__ out2,
                                                             const float* __restrict__ s2,
                                                             const float* __restrict__ t2) {
-    const int c4n = C >> 2;
-    const size_t total = (size_t)n * hf * wf * c4n;
+    // one thread = one pixel x TWO 4-channel groups (c4 and c4 + c4n/2): the flow / bilinear setup is shared and
+    // eight 16-byte gathers are in flight per thread; a wave still covers contiguous 1 KiB runs of each half
+    const int c4n = C >> 2, half_n = c4n >> 1;
+    const size_t total = (size_t)n * hf * wf * half_n;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % c4n);
-        const size_t pix = idx / c4n;
+        const int c4 = (int)(idx % half_n);
+        const size_t pix = idx / half_n;
         const int x = (int)(pix % wf);
         const int y = (int)((pix / wf) % hf);
         const int f = (int)(pix / ((size_t)wf * hf));
@@ -314,37 +316,37 @@ __global__ __launch_bounds__(256) void warp_features_kernel(const float* __restr
         const float4* src = reinterpret_cast<const float4*>(feat + (size_t)((ns == 1) ? 0 : f) * hf * wf * C) + c4;
         const bool x0ok = (unsigned)b.x0 < (unsigned)wf, x1ok = (unsigned)(b.x0 + 1) < (unsigned)wf;
         const bool y0ok = (unsigned)b.y0 < (unsigned)hf, y1ok = (unsigned)(b.y0 + 1) < (unsigned)hf;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y0ok && x0ok) {
-            const float4 v = src[(size_t)(b.y0 * wf + b.x0) * c4n];
-            acc.x = fmaf(v.x, b.wnw, acc.x); acc.y = fmaf(v.y, b.wnw, acc.y);
-            acc.z = fmaf(v.z, b.wnw, acc.z); acc.w = fmaf(v.w, b.wnw, acc.w);
-        }
-        if (y0ok && x1ok) {
-            const float4 v = src[(size_t)(b.y0 * wf + b.x0 + 1) * c4n];
-            acc.x = fmaf(v.x, b.wne, acc.x); acc.y = fmaf(v.y, b.wne, acc.y);
-            acc.z = fmaf(v.z, b.wne, acc.z); acc.w = fmaf(v.w, b.wne, acc.w);
-        }
-        if (y1ok && x0ok) {
-            const float4 v = src[(size_t)((b.y0 + 1) * wf + b.x0) * c4n];
-            acc.x = fmaf(v.x, b.wsw, acc.x); acc.y = fmaf(v.y, b.wsw, acc.y);
-            acc.z = fmaf(v.z, b.wsw, acc.z); acc.w = fmaf(v.w, b.wsw, acc.w);
-        }
-        if (y1ok && x1ok) {
-            const float4 v = src[(size_t)((b.y0 + 1) * wf + b.x0 + 1) * c4n];
-            acc.x = fmaf(v.x, b.wse, acc.x); acc.y = fmaf(v.y, b.wse, acc.y);
-            acc.z = fmaf(v.z, b.wse, acc.z); acc.w = fmaf(v.w, b.wse, acc.w);
-        }
-        acc.x *= o; acc.y *= o; acc.z *= o; acc.w *= o;
-        reinterpret_cast<float4*>(out)[idx] = acc;
-        if (out2) {
-            const float4 s = reinterpret_cast<const float4*>(s2)[c4];
-            const float4 t = reinterpret_cast<const float4*>(t2)[c4];
-            float4 a;
-            a.x = fmaxf(fmaf(acc.x, s.x, t.x), 0.f); a.y = fmaxf(fmaf(acc.y, s.y, t.y), 0.f);
-            a.z = fmaxf(fmaf(acc.z, s.z, t.z), 0.f);
-            a.w = fmaxf(fmaf(acc.w, s.w, t.w), 0.f);
-            reinterpret_cast<float4*>(out2)[idx] = a;
+        const float wgt[4] = {(y0ok && x0ok) ? b.wnw : 0.f, (y0ok && x1ok) ? b.wne : 0.f, (y1ok && x0ok) ? b.wsw : 0.f,
+                              (y1ok && x1ok) ? b.wse : 0.f};
+        // clamp the corner coordinates so every load is in range; out-of-range corners carry weight 0
+        const int xa = min(max(b.x0, 0), wf - 1), xb = min(max(b.x0 + 1, 0), wf - 1);
+        const int ya = min(max(b.y0, 0), hf - 1), yb = min(max(b.y0 + 1, 0), hf - 1);
+        const size_t off[4] = {(size_t)(ya * wf + xa) * c4n, (size_t)(ya * wf + xb) * c4n, (size_t)(yb * wf + xa) * c4n,
+                               (size_t)(yb * wf + xb) * c4n};
+        float4 v[2][4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[g][k] = src[off[k] + g * half_n];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {   // same accumulation order as before: nw, ne, sw, se
+                acc.x = fmaf(v[g][k].x, wgt[k], acc.x); acc.y = fmaf(v[g][k].y, wgt[k], acc.y);
+                acc.z = fmaf(v[g][k].z, wgt[k], acc.z); acc.w = fmaf(v[g][k].w, wgt[k], acc.w);
+            }
+            acc.x *= o; acc.y *= o; acc.z *= o; acc.w *= o;
+            const size_t oidx = pix * c4n + c4 + g * half_n;
+            reinterpret_cast<float4*>(out)[oidx] = acc;
+            if (out2) {
+                const float4 s = reinterpret_cast<const float4*>(s2)[c4 + g * half_n];
+                const float4 t = reinterpret_cast<const float4*>(t2)[c4 + g * half_n];
+                float4 a;
+                a.x = fmaxf(fmaf(acc.x, s.x, t.x), 0.f); a.y = fmaxf(fmaf(acc.y, s.y, t.y), 0.f);
+                a.z = fmaxf(fmaf(acc.z, s.z, t.z), 0.f); a.w = fmaxf(fmaf(acc.w, s.w, t.w), 0.f);
+                reinterpret_cast<float4*>(out2)[oidx] = a;
+            }
         }
     }
 }
@@ -534,7 +536,8 @@ hipError_t motion_head_rowsplit_launch(const float* part, int PS, int NC, const 
 hipError_t warp_features_launch(const float* feat, const float* deformation, const float* occlusion, int n, int ns,
                                 int hf, int wf, int C, int h, int w, float* out, float* out2, const float* s2,
                                 const float* t2, hipStream_t s) {
-    const size_t total = (size_t)n * hf * wf * (C / 4);
+    if (C % 8) return hipErrorInvalidValue;
+    const size_t total = (size_t)n * hf * wf * (C / 8);
     hipLaunchKernelGGL(warp_features_kernel, dim3(grid_for(total, 1 << 20)), dim3(256), 0, s, feat, deformation,
                        occlusion, n, ns, hf, wf, C, h, w, out, out2, s2, t2);
     return hipGetLastError();

@@ -35,6 +35,8 @@ def test_bench_single_gpu_line():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert 0.3 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(sum(d["stage_ms_per_step"].values()) - d["ms_per_step"]) / d["ms_per_step"] < 0.05  # events ~ wall clock
+    w = d["roofline_warp"]
+    assert w["bound"] == "hbm" and w["unit"] == "GB/s" and w["peak"] == 8000.0 and 0.2 < w["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0
     assert d["value"] > 30 * c["value"]        # north_star target: >= 30x the CPU reference path
