@@ -42,6 +42,7 @@ HBM_PEAK_GBS = 8000.0
 # FETCH_SIZE (KB) * 2 + WRITE_SIZE (KB) of the dominant kernel, profiles/r01_rocprofv3_pmc_{fetch,write}_*.txt
 TRAFFIC_WINO = int((180579.8 * 2 + 65536.0) * 1024)     # wino_gemm_kernel: V is read by both N tiles (algorithmic 339-406 MB)
 TRAFFIC_DIRECT = int((75139.8 * 2 + 65536.0) * 1024)    # conv_mfma_dma_kernel 256x256 (algorithmic 204 MB)
+TRAFFIC_WINO4 = None     # wino4_gemm_kernel: filled in from the PMC passes under profiles/
 TRAFFIC_SRC = "profiles/r01_rocprofv3_pmc_{fetch,write}_bottleneck_{winograd,conv_256x256tile}.txt"
 
 
@@ -189,9 +190,10 @@ def main():
         cb = min(cfg["max_features"], cfg["block_expansion"] << cfg["num_down_blocks"])
         calls = max(1, prof["calls"])
         launches = 2 * cfg["num_bottleneck_blocks"] * calls
-        wino = prof["ms"]["bneck_transform"] > 0
+        form = eng.bottleneck_form(B)          # 0 direct, 2 Winograd F(2x2,3x3), 4 Winograd F(4x4,3x3)
+        wino = form != 0
         algo_flop = 2.0 * (B * hf * hf) * cb * (9 * cb)
-        exec_flop = algo_flop * (16.0 / 36.0) if wino else algo_flop
+        exec_flop = algo_flop * {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0}[form]
         ms_conv = prof["ms"]["bneck_conv"] / launches if prof["calls"] else float("nan")
         ms_tr = prof["ms"]["bneck_transform"] / launches if prof["calls"] else 0.0
         achieved = exec_flop / (ms_conv * 1e-3) / 1e12
@@ -207,14 +209,15 @@ def main():
                        "frames_per_step_per_gpu": B, "parallelism": f"frame-sharded x{world}",
                        "flops_per_frame": round(eng.flops_per_frame / 1e9, 3)},
             "roofline": {"bound": "mfma",
-                         "kernel": ("wino_gemm_kernel<1,2,4,2> (bottleneck 3x3 256->256 @64x64 in Winograd F(2x2,3x3) form)"
-                                    if wino else "conv_mfma_dma_kernel<3,3,...> (bottleneck 3x3 256->256 @64x64, direct)"),
+                         "kernel": {4: "wino4_gemm_kernel<2,4,2,...> (bottleneck 3x3 256->256 @64x64 in Winograd F(4x4,3x3) form)",
+                                    2: "wino_gemm_kernel<1,2,4,2> (bottleneck 3x3 256->256 @64x64 in Winograd F(2x2,3x3) form)",
+                                    0: "conv_mfma_dma_kernel<3,3,...> (bottleneck 3x3 256->256 @64x64, direct)"}[form],
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                          # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
                          # note in MI355X_MICROARCH.md, + WRITE_SIZE) -- measured once with tools/gpu_profile.sh at this
                          # workload (batch 16, 256x256) and committed under profiles/; not re-measured by this run
-                         "traffic": (TRAFFIC_WINO if wino else TRAFFIC_DIRECT) if (B == 16 and S == 256) else None,
+                         "traffic": {4: TRAFFIC_WINO4, 2: TRAFFIC_WINO, 0: TRAFFIC_DIRECT}[form] if (B == 16 and S == 256) else None,
                          "traffic_unit": "bytes/launch", "traffic_source": TRAFFIC_SRC,
                          "avg_launch_ms": round(ms_conv, 4), "executed_gflop_per_launch": round(exec_flop / 1e9, 2),
                          "achieved_algorithmic": round(algo, 2),

@@ -67,6 +67,7 @@ SIGNATURES = {
     "eamm_export_source_cache": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "eamm_import_source_cache": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "eamm_flops_per_frame": (C.c_double, [C.c_void_p]),
+    "eamm_bottleneck_form": (C.c_int, [C.c_void_p, C.c_int]),
     "eamm_encode_flops": (C.c_double, [C.c_void_p]),
     "eamm_kp_create": (C.c_int, [C.POINTER(EammKpConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "eamm_kp_destroy": (None, [C.c_void_p]),

@@ -256,7 +256,7 @@ int build_set(CtxBase* c, const std::vector<FoldSpec>& parts, int C0_real, int C
 
 // Tile choice per launch (measured on MI355X, profiles/r01_convbench_*): M is the per-phase pixel count.
 // conv (+ folded BatchNorm) -> Winograd-domain weights U = G g G^T
-int build_wino(CtxBase* c, const std::string& conv, const std::string& norm, int C, WinoLayer* L) {
+int build_wino(CtxBase* c, const std::string& conv, const std::string& norm, int C, WinoLayer* L, int tile = 2) {
     const HostTensor *wt = find(c, conv + ".weight"), *bt = find(c, conv + ".bias");
     if (!wt || !bt || wt->shape.size() != 4 || wt->shape[0] != C || wt->shape[1] != C || wt->shape[2] != 3)
         return fail(c, EAMM_ERR_KEY, "%s mis-shaped for the Winograd path", conv.c_str());
@@ -273,10 +273,14 @@ int build_wino(CtxBase* c, const std::string& conv, const std::string& norm, int
     }
     L->Cin = C;
     L->Cout = C;
-    L->BN = 128;
+    L->tile = tile;
+    L->BN = tile == 4 ? 64 : 128;
     L->ntiles = (C + L->BN - 1) / L->BN;
-    std::vector<float> packed(wino_packed_elems(C, C, L->BN));
-    wino_pack_host(wf.data(), C, C, L->BN, packed.data());
+    std::vector<float> packed(tile == 4 ? wino4_packed_elems(C, C, L->BN) : wino_packed_elems(C, C, L->BN));
+    if (tile == 4)
+        wino4_pack_host(wf.data(), C, C, L->BN, packed.data());
+    else
+        wino_pack_host(wf.data(), C, C, L->BN, packed.data());
     std::vector<float> bias_pad((size_t)L->ntiles * L->BN, 0.f);
     std::copy(bf.begin(), bf.end(), bias_pad.begin());
     int rc = upload(c, &L->u, packed);

@@ -1,0 +1,468 @@
+// Winograd F(4x4, 3x3) form of the 3x3 / pad 1 convolution for the bottleneck ResBlock2d stack
+// (reference modules/util.py:858-880, generator.py:89): 36 multiplies per 16 outputs and input channel instead of
+// 144 (direct) or 64 (F(2x2,3x3), conv_winograd.hip) -- 4x fewer MFMA passes than the direct form, still plain fp32
+// arithmetic (v_mfma_f32_16x16x4_f32 + fp32 VALU), only the summation order / rounding differs (measured at the
+// prediction: tools/wino_numerics.py).
+//
+//   Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A        d: 6x6 input patch (stride 4), Y: 4x4 outputs
+//
+// Interpolation points {0, +-1, +-2, inf} (Lavin & Gray):
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+//
+// Two kernels per convolution, as in the F(2x2) form:
+//  1. wino4_input_transform_kernel (HBM-bound): V[xi][tile][c], xi = 6i + j, optionally applying the ResBlock
+//     pre-activation relu(x*s + t) to in-range pixels first.  V is 2.25x the activation (F(2x2): 4x).
+//  2. wino4_gemm_kernel (MFMA-bound): for each xi the GEMM M_xi[tile, o] = sum_c V_xi[tile, c] U_xi[c, o]; when a xi
+//     is finished its accumulator is folded along x into Z[q] += A^T[q][j] M_xi, and after the six xi of a row i
+//     along y into the sixteen output accumulators Y[p][q] += A^T[p][i] Z[q] -- the transformed products never leave
+//     the registers.  The sixteen outputs bound the tile a CU can hold (16 outputs x 64x64 tile x 4 B = half the
+//     register file), so a wave owns a 16 x 32 tile of (Winograd tile, output channel) and uses the 16x16x4 MFMA;
+//     the LDS image, swizzle and LDS-DMA pipeline are those of conv_mfma_dma.hip / conv_winograd.hip.
+//
+// U = G g G^T is computed in double on the host from the BatchNorm-folded weights and rounded once.
+#include "conv_common.h"
+
+#include <algorithm>
+
+namespace eamm {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------
+// input transform
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 y) {
+    return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), fmaf(a, x.w, y.w));
+}
+__device__ __forceinline__ float4 f4_sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4_add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// (B^T d) for six values in place
+__device__ __forceinline__ void bt6(float4& d0, float4& d1, float4& d2, float4& d3, float4& d4, float4& d5) {
+    const float4 s12 = f4_add4(d1, d2), m12 = f4_sub4(d1, d2);
+    const float4 s34 = f4_add4(d3, d4), m43 = f4_sub4(d4, d3);
+    const float4 m31 = f4_sub4(d3, d1), m42 = f4_sub4(d4, d2);
+    const float4 t0 = f4_fma(4.f, d0, f4_fma(-5.f, d2, d4));
+    const float4 t1 = f4_fma(-4.f, s12, s34);
+    const float4 t2 = f4_fma(4.f, m12, m43);
+    const float4 t3 = f4_fma(2.f, m31, m42);
+    const float4 t4 = f4_fma(-2.f, m31, m42);
+    const float4 t5 = f4_fma(4.f, d1, f4_fma(-5.f, d3, d5));
+    d0 = t0; d1 = t1; d2 = t2; d3 = t3; d4 = t4; d5 = t5;
+}
+
+__global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ s,
+                                                                    const float* __restrict__ t, int B, int H, int W,
+                                                                    int C, float* __restrict__ V) {
+    const int c4n = C >> 2;
+    const int Hq = H >> 2, Wq = W >> 2;
+    const size_t Mq = (size_t)B * Hq * Wq;
+    const size_t total = Mq * c4n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const size_t q = idx / c4n;
+        const int qx = (int)(q % Wq);
+        const int qy = (int)((q / Wq) % Hq);
+        const int b = (int)(q / ((size_t)Wq * Hq));
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s != nullptr) {
+            sc = reinterpret_cast<const float4*>(s)[c4];
+            sh = reinterpret_cast<const float4*>(t)[c4];
+        }
+        const float4* img = reinterpret_cast<const float4*>(x) + (size_t)b * H * W * c4n + c4;
+        float4 d[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int yy = 4 * qy - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int xx = 4 * qx - 1 + j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                    v = img[(size_t)(yy * W + xx) * c4n];
+                    if (s != nullptr) {  // zero padding applies to the ACTIVATED tensor: only in-range pixels
+                        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+                        v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+                        v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+                    }
+                }
+                d[i][j] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);   // along y
+        float4* out = reinterpret_cast<float4*>(V) + q * c4n + c4;
+        const size_t plane = Mq * c4n;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);                              // along x
+#pragma unroll
+            for (int j = 0; j < 6; ++j) out[(size_t)(i * 6 + j) * plane] = d[i][j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GEMM over the 36 transform points + in-register output transform
+// ---------------------------------------------------------------------------------------------------------
+struct Wino4Args {
+    const float* V;        // [36][Mq][C]
+    const float* U;        // packed [ntiles][36 * C/32][BN][32] (swizzled), xi outer / channel chunk inner
+    const float* bias;     // [ntiles*BN]
+    unsigned v_bytes, u_bytes;
+    int Mq, C, Cout;       // tiles (= pixels / 16), input channels, output channels
+    int H, W;              // output image size (4*Hq, 4*Wq)
+    int mtiles, ntiles;
+    int act;
+    const float* resid;    // NHWC [B,H,W,Cout]
+    float* out;            // NHWC [B,H,W,Cout]
+};
+
+__constant__ float WINO4_AT[4][8] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f},
+                                     {0.f, 1.f, -1.f, 2.f, -2.f, 0.f, 0.f, 0.f},
+                                     {0.f, 1.f, 1.f, 4.f, 4.f, 0.f, 0.f, 0.f},
+                                     {0.f, 1.f, -1.f, 8.f, -8.f, 1.f, 0.f, 0.f}};
+
+// A wave owns 16 Winograd tiles x NT*16 output channels; WM x WN waves per block.  SUB: 32-channel chunks per
+// barrier interval; NST: LDS ring depth in intervals; PE: one DMA piece every PE MFMAs from the start of an interval.
+template <int NT, int WM, int WN, int SUB, int NST, int PE, int DBG = 0>
+__global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args p) {
+    constexpr int NW = WM * WN, NTHR = NW * 64;
+    constexpr int BM = WM * 16, BN = WN * NT * 16, BK = CONV_BK;
+    constexpr int A_STAGE = SUB * BM * BK, B_STAGE = SUB * BN * BK;  // floats per stage
+    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;       // DMA instructions per wave per chunk
+    constexpr int NPIECE = SUB * (A_INSTR + B_INSTR);
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
+    static_assert(BK == 32, "two 16-wide K steps per chunk");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [NST][A_STAGE] [NST][B_STAGE]
+    float* const As = smem;
+    float* const Bs = smem + NST * A_STAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = L % p.ntiles;
+    const int mtile = L / p.ntiles;
+    const int mbase = mtile * BM;
+    const int cchunks = p.C / BK;             // channel chunks per transform point
+    const int nsuper = 36 * cchunks / SUB;    // barrier intervals
+
+    unsigned arow_off[A_INSTR];
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+        const int row = (wave * A_INSTR + j) * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((row >> 1) & 7);
+        const int m = mbase + row;
+        arow_off[j] = m < p.Mq ? (unsigned)(m * p.C + slot * 4) * 4u : 0xFFFFFFF0u;
+    }
+    const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, p.v_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, p.u_bytes, 0x00020000);
+    const unsigned plane_bytes = (unsigned)p.Mq * (unsigned)p.C * 4u;
+
+    int n_sc = 0, n_st = 0;
+    auto dma_piece = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int sub = k / (A_INSTR + B_INSTR), r = k % (A_INSTR + B_INSTR);
+        const int ci = n_sc * SUB + sub;              // chunk index: xi * cchunks + cc
+        const int xi = ci / cchunks, cc = ci - xi * cchunks;
+        if constexpr (r < A_INSTR) {
+            const unsigned off = arow_off[r] + (unsigned)xi * plane_bytes + (unsigned)(cc * BK * 4);
+            const unsigned o2 = arow_off[r] == 0xFFFFFFF0u ? 0xFFFFFFF0u : off;   // M tail: always out of range
+            float* dst = As + n_st * A_STAGE + sub * (BM * BK) + (wave * A_INSTR + r) * (8 * BK);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_ptr_t)dst, 16, o2, 0, 0, 0);
+        } else {
+            constexpr int j = r - A_INSTR;
+            const unsigned off =
+                (unsigned)(((ntile * 36 * cchunks + ci) * BN + (wave * B_INSTR + j) * 8) * BK + lane * 4) * 4u;
+            float* dst = Bs + n_st * B_STAGE + sub * (BN * BK) + (wave * B_INSTR + j) * (8 * BK);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+        }
+    };
+
+    f32x4_t acc[NT];        // M_xi of the transform point in flight
+    f32x4_t Z[4][NT];       // row i folded along x
+    f32x4_t Y[16][NT];      // the sixteen outputs of each tile, p = 4*py + px
+    static_for<NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        static_for<4>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            acc[j][r] = 0.f;
+            static_for<4>([&](auto qc) { Z[decltype(qc)::value][j][r] = 0.f; });
+            static_for<16>([&](auto pc) { Y[decltype(pc)::value][j][r] = 0.f; });
+        });
+    });
+
+    const int sw = (r16 >> 1) & 7;
+    constexpr int STEPS = SUB * 2;               // 16-wide K steps per barrier interval
+    constexpr int MF = 4 * NT;                   // MFMAs per step
+    constexpr int TOTAL_MF = STEPS * MF;
+    static_assert(PE >= 1 && NPIECE * PE <= TOTAL_MF, "DMA pieces must fit in the interval");
+    auto compute = [&](int st, bool more) {
+        f32x4_t a[2], b[2][NT];
+        auto fetch = [&](int step, int buf) {
+            const int sub = step >> 1, s = step & 1;
+            const int slot = ((4 * s + g) ^ sw) << 2;
+            const float* a_base = As + st * A_STAGE + sub * (BM * BK) + (wm * 16 + r16) * BK + slot;
+            const float* b_base = Bs + st * B_STAGE + sub * (BN * BK) + (wn * NT * 16 + r16) * BK + slot;
+            a[buf] = *reinterpret_cast<const f32x4_t*>(a_base);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[buf][j] = *reinterpret_cast<const f32x4_t*>(b_base + j * 16 * BK);
+        };
+        fetch(0, 0);
+        static_for<STEPS>([&](auto sc) {
+            constexpr int step = decltype(sc)::value;
+            if constexpr (step + 1 < STEPS) fetch(step + 1, (step + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<MF>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int t = q / NT, j = q % NT;
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[step & 1][t], b[step & 1][j][t], acc[j], 0, 0, 0);
+                constexpr int gi = step * MF + q;
+                if constexpr (gi % PE == PE - 1 && gi / PE < NPIECE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && DBG != 1 && !(DBG == 2 && ((gi / PE) & 1))) dma_piece(std::integral_constant<int, gi / PE>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        });
+    };
+
+    auto fold_x = [&](int j) {   // Z[q] += A^T[q][j] * M_ij
+        const float c0 = WINO4_AT[0][j], c1 = WINO4_AT[1][j], c2 = WINO4_AT[2][j], c3 = WINO4_AT[3][j];
+        static_for<NT>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            static_for<4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const float m = acc[jj][r];
+                Z[0][jj][r] = fmaf(c0, m, Z[0][jj][r]);
+                Z[1][jj][r] = fmaf(c1, m, Z[1][jj][r]);
+                Z[2][jj][r] = fmaf(c2, m, Z[2][jj][r]);
+                Z[3][jj][r] = fmaf(c3, m, Z[3][jj][r]);
+                acc[jj][r] = 0.f;
+            });
+        });
+    };
+    auto fold_y = [&](int i) {   // Y[p][q] += A^T[p][i] * Z[q]
+        const float c0 = WINO4_AT[0][i], c1 = WINO4_AT[1][i], c2 = WINO4_AT[2][i], c3 = WINO4_AT[3][i];
+        static_for<NT>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                static_for<4>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const float z = Z[q][jj][r];
+                    Y[0 + q][jj][r] = fmaf(c0, z, Y[0 + q][jj][r]);
+                    Y[4 + q][jj][r] = fmaf(c1, z, Y[4 + q][jj][r]);
+                    Y[8 + q][jj][r] = fmaf(c2, z, Y[8 + q][jj][r]);
+                    Y[12 + q][jj][r] = fmaf(c3, z, Y[12 + q][jj][r]);
+                    Z[q][jj][r] = 0.f;
+                });
+            });
+        });
+    };
+
+    // ---- main loop: ring of NST stages, DMA runs D = NST-1 intervals ahead of the MFMAs
+    constexpr int D = NST - 1;
+    const int per_xi = cchunks / SUB;  // barrier intervals per transform point
+    for (int k = 0; k < D && k < nsuper; ++k) {
+        n_sc = k;
+        n_st = k;
+        static_for<NPIECE>([&](auto kc) { dma_piece(kc); });
+    }
+    if (D > 1 && nsuper >= D) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NPIECE) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    int st = 0, st_next = D % NST;
+    int xi_left = per_xi, xj = 0, xrow = 0;
+    for (int sc = 0; sc < nsuper; ++sc) {
+        const bool more = sc + D < nsuper;
+        n_sc = sc + D;
+        n_st = st_next;
+        compute(st, more);
+        if (--xi_left == 0) {
+            xi_left = per_xi;
+            fold_x(xj);
+            if (++xj == 6) {
+                xj = 0;
+                fold_y(xrow++);
+            }
+        }
+        if (D > 1 && more) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NPIECE) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        st = st + 1 == NST ? 0 : st + 1;
+        st_next = st_next + 1 == NST ? 0 : st_next + 1;
+    }
+
+    // ---- epilogue: one output row py (four pixels) per round, staged through LDS, 16-byte row accesses.
+    // A thread keeps the same (channel group, px) and walks BM / PER tiles; their output offsets are decoded once
+    // (py only adds a row stride) and out-of-range tiles / channels get an offset the buffer descriptor rejects,
+    // so the rounds are branch-free.
+    constexpr int LDO = BN + 4, C4 = BN / 4, RPP = NTHR / (4 * C4), PER = BM / RPP;
+    static_assert(NTHR % (4 * C4) == 0 && BM % RPP == 0, "tile must split evenly over the threads");
+    const int Hq = p.H >> 2, Wq = p.W >> 2;
+    float bias[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bias[j] = p.bias[ntile * BN + wn * NT * 16 + j * 16 + r16];
+    const int e_c4 = tid % C4, e_px = (tid / C4) & 3, e_row0 = tid / (4 * C4);
+    const int e_n = ntile * BN + e_c4 * 4;
+    unsigned e_off[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int m = mbase + e_row0 + k * RPP;
+        const int qx = m % Wq, tq = m / Wq;
+        const int qy = tq % Hq, bb = tq / Hq;
+        const unsigned o = (unsigned)(((bb * p.H + 4 * qy) * p.W + 4 * qx + e_px) * p.Cout + e_n) * 4u;
+        e_off[k] = (m < p.Mq && e_n < p.Cout) ? o : 0xFFFFFFF0u;
+    }
+    const unsigned out_bytes = (unsigned)p.Mq * 16u * (unsigned)p.Cout * 4u;
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, p.resid != nullptr ? out_bytes : 0u, 0x00020000);
+    const float lo = p.act == ACT_RELU ? 0.f : -INFINITY;
+    const unsigned row_bytes = (unsigned)p.W * (unsigned)p.Cout * 4u;
+    const float* e_src = smem + (e_px * BM + e_row0) * LDO + e_c4 * 4;
+    static_for<4>([&](auto pyc) {
+        constexpr int py = decltype(pyc)::value;
+        if (py) __syncthreads();
+        static_for<4>([&](auto pxc) {
+            constexpr int px = decltype(pxc)::value;
+            static_for<NT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                float* dst = smem + (px * BM + wm * 16 + 4 * g) * LDO + wn * NT * 16 + j * 16 + r16;
+                static_for<4>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    dst[r * LDO] = Y[py * 4 + px][j][r] + bias[j];
+                });
+            });
+        });
+        __syncthreads();
+        const unsigned soff = py * row_bytes;
+        u32x4 rr[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsr, e_off[k], soff, 0);  // 0 if no residual
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            f32x4_t v = *reinterpret_cast<const f32x4_t*>(e_src + k * RPP * LDO);
+            const f32x4_t r4 = __builtin_bit_cast(f32x4_t, rr[k]);
+            v = v + r4;
+            v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rso, e_off[k], soff, 0);
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+// U[xi][o][c] = (G g G^T)[xi]; w: [Cout][Cin][3][3] (BN folded).  Packed [ntiles][36*Cin/32][BN][32],
+// chunk = xi*(Cin/32) + cc, 16-byte slots XOR-swizzled like conv_mfma_dma.
+void wino4_pack_host(const float* w, int Cout, int Cin, int BN, float* dst) {
+    static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+    const int BK = CONV_BK, cch = Cin / BK;
+    const int ntiles = (Cout + BN - 1) / BN;
+    const size_t total = (size_t)ntiles * 36 * cch * BN * BK;
+    for (size_t i = 0; i < total; ++i) dst[i] = 0.f;
+    for (int o = 0; o < Cout; ++o) {
+        const int nt = o / BN, nl = o % BN;
+        for (int c = 0; c < Cin; ++c) {
+            const float* gw = w + ((size_t)o * Cin + c) * 9;
+            double tmp[6][3];
+            for (int i = 0; i < 6; ++i)
+                for (int k = 0; k < 3; ++k)
+                    tmp[i][k] = G[i][0] * gw[0 * 3 + k] + G[i][1] * gw[1 * 3 + k] + G[i][2] * gw[2 * 3 + k];
+            const int cc = c / BK, kl = c % BK;
+            const int kk = ((((kl >> 2) ^ ((nl >> 1) & 7)) << 2) | (kl & 3));
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    const double u = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+                    const int xi = i * 6 + j;
+                    dst[(((size_t)nt * 36 * cch + (size_t)xi * cch + cc) * BN + nl) * BK + kk] = (float)u;
+                }
+        }
+    }
+}
+
+size_t wino4_packed_elems(int Cout, int Cin, int BN) {
+    return (size_t)((Cout + BN - 1) / BN) * 36 * (Cin / CONV_BK) * BN * CONV_BK;
+}
+
+hipError_t wino4_transform_launch(const float* x, const float* s, const float* t, int B, int H, int W, int C, float* V,
+                                  hipStream_t stream) {
+    if ((H & 3) || (W & 3) || (C & 3)) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * (H / 4) * (W / 4) * (C / 4);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)1 << 20);
+    hipLaunchKernelGGL(wino4_input_transform_kernel, dim3(blocks), dim3(256), 0, stream, x, s, t, B, H, W, C, V);
+    return hipGetLastError();
+}
+
+template <int SUB, int NST, int PE, int DBG = 0>
+static hipError_t wino4_launch_variant(const Wino4Args& a, hipStream_t stream) {
+    constexpr int NT = 2, WM = 4, WN = 2;
+    constexpr int BM = WM * 16, BN = WN * NT * 16;
+    constexpr size_t lds_loop = sizeof(float) * NST * SUB * (BM + BN) * CONV_BK;
+    constexpr size_t lds_epi = sizeof(float) * 4 * BM * (BN + 4);
+    constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = wino4_gemm_kernel<NT, WM, WN, SUB, NST, PE, DBG>;
+    static unsigned long long configured = 0;  // per-device bit mask
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, &configured); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles), dim3(WM * WN * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, int W, int act, const float* resid,
+                             float* out, hipStream_t stream, int variant) {
+    constexpr int BM = 64, BN = 64;
+    if (L.tile != 4 || L.BN != BN || (L.Cout & 3) || L.Cin % (2 * CONV_BK) || (H & 3) || (W & 3))
+        return hipErrorInvalidValue;
+    Wino4Args a{};
+    a.V = V;
+    a.U = L.u;
+    a.bias = L.bias;
+    a.Mq = B * (H / 4) * (W / 4);
+    a.C = L.Cin;
+    a.Cout = L.Cout;
+    a.H = H;
+    a.W = W;
+    a.mtiles = (a.Mq + BM - 1) / BM;
+    a.ntiles = L.ntiles;
+    a.act = act;
+    a.resid = resid;
+    a.out = out;
+    const size_t vb = (size_t)36 * a.Mq * a.C * sizeof(float), ub = wino4_packed_elems(L.Cout, L.Cin, BN) * sizeof(float);
+    if (vb >= 0xFFFFFFF0ull || ub >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    a.v_bytes = (unsigned)vb;
+    a.u_bytes = (unsigned)ub;
+    const bool sub4 = L.Cin % (4 * CONV_BK) == 0;
+    switch (variant) {   // (chunks per barrier, ring depth, MFMAs per DMA piece)
+        case 0: return sub4 ? wino4_launch_variant<4, 2, 4>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream);
+        case 1: return wino4_launch_variant<2, 2, 4>(a, stream);
+        case 2: return wino4_launch_variant<2, 3, 4>(a, stream);
+        case 3: return sub4 ? wino4_launch_variant<4, 2, 8>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream);
+        case 4: return wino4_launch_variant<2, 4, 4>(a, stream);
+        case 10: return wino4_launch_variant<4, 2, 4, 1>(a, stream);
+        case 11: return wino4_launch_variant<4, 2, 4, 2>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace eamm

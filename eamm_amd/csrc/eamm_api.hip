@@ -28,7 +28,10 @@ struct eamm_ctx : eamm::CtxBase {
     ConvLayer first, final_conv, head;
     std::vector<LayerSet> down, hg_enc, hg_dec, res1, res2, up;
     std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
-    float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] transformed activations
+    std::vector<WinoLayer> w4res1, w4res2; // Winograd F(4x4,3x3) packing (bottleneck maps with sides divisible by 4)
+    int wino_tile = 4;                     // preferred output tile (EAMM_WINO_TILE): 4 -> F(4x4) where it applies, 2 -> F(2x2)
+    int wino4_variant = 0;                 // wino4_gemm_kernel pipeline variant
+    float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] (F(2x2)) or [36][F*hf*wf/16][Cb] transformed activations
     int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd form
     int wino_variant = 0;                  // wino_gemm_kernel pipeline variant (see wino_gemm_launch); in-pipeline all are within noise
     std::vector<float*> pre_s, pre_t;  // res-block pre-activation scale/shift (norm1)
@@ -163,6 +166,8 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     read_tile_knobs(c);
     c->wino_min_m = env_int("EAMM_WINO_MIN_M", c->wino_min_m);
     c->wino_variant = env_int("EAMM_WINO_VARIANT", c->wino_variant);   // < 0 disables the Winograd bottleneck
+    c->wino_tile = env_int("EAMM_WINO_TILE", c->wino_tile);
+    c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
     c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);
     c->dma_cfg_n64 = env_int("EAMM_DMA_CFG_N64", c->dma_cfg_n64);
@@ -249,6 +254,12 @@ int eamm_finalize_weights(eamm_ctx* c) {
             c->wres2.resize(nr);
             if ((rc = build_wino(c, r + ".conv1", r + ".norm2", c->Cb, &c->wres1[i]))) return rc;
             if ((rc = build_wino(c, r + ".conv2", "", c->Cb, &c->wres2[i]))) return rc;
+            if (c->wino_tile == 4) {
+                c->w4res1.resize(nr);
+                c->w4res2.resize(nr);
+                if ((rc = build_wino(c, r + ".conv1", r + ".norm2", c->Cb, &c->w4res1[i], 4))) return rc;
+                if ((rc = build_wino(c, r + ".conv2", "", c->Cb, &c->w4res2[i], 4))) return rc;
+            }
         }
         const HostTensor *gm = find(c, r + ".norm1.weight"), *bt = find(c, r + ".norm1.bias"),
                          *mu = find(c, r + ".norm1.running_mean"), *vr = find(c, r + ".norm1.running_var");
@@ -410,6 +421,13 @@ int eamm_encode_source(eamm_ctx* c, const float* source, int ns, void* stream_) 
     return EAMM_OK;
 }
 
+// 0 = direct, 2 = Winograd F(2x2,3x3), 4 = Winograd F(4x4,3x3) for a call of n frames
+static int bottleneck_form(const eamm_ctx* c, int n) {
+    const int hf = c->hf, wf = c->wf;
+    if (c->wres1.empty() || (size_t)n * hf * wf < (size_t)c->wino_min_m) return 0;
+    return (!c->w4res1.empty() && hf % 4 == 0 && wf % 4 == 0) ? 4 : 2;
+}
+
 int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd_jac, const float* ks_val,
                         const float* ks_jac, const eamm_outputs* o, void* stream_) {
     if (!c || !kd_val || !ks_val || !o || !o->prediction) return fail(c, EAMM_ERR_ARG, "null argument");
@@ -506,7 +524,8 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     STAGE_MARK(4);
     // Bottleneck form: Winograd F(2x2,3x3) when there are enough tiles to fill the chip, else direct.
     const int nr = c->cfg.num_bottleneck_blocks;
-    const bool wino = !c->wres1.empty() && (size_t)n * hf * wf >= (size_t)c->wino_min_m;
+    const int form = bottleneck_form(c, n);
+    const bool wino = form != 0;
     // feature warp x occlusion (+ r0's pre-activation for the direct form)       generator.py:79-84
     HIP_TRY(c, warp_features_launch(c->feat, c->deformation, occ ? c->occlusion : nullptr, n, ns, hf, wf, c->Cb, h, w,
                                     c->xa, wino ? nullptr : c->act, c->pre_s[0], c->pre_t[0], s));
@@ -521,16 +540,27 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     do {                                                         \
         if (sub) HIP_TRY(c, hipEventRecord(sub[nsub++], s));     \
     } while (0)
+    const bool wino4 = form == 4;
     for (int i = 0; i < nr && wino; ++i) {
         // conv1(relu(norm1(x))): the pre-activation rides on the input transform; norm2 + relu in the epilogue
         SUB_MARK();
-        HIP_TRY(c, wino_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, c->wino_v, s));
-        SUB_MARK();
-        HIP_TRY(c, wino_gemm_launch(c->wres1[i], c->wino_v, n, hf, wf, ACT_RELU, nullptr, c->tmp, s, c->wino_variant));
-        SUB_MARK();
-        HIP_TRY(c, wino_transform_launch(c->tmp, nullptr, nullptr, n, hf, wf, c->Cb, c->wino_v, s));
-        SUB_MARK();
-        HIP_TRY(c, wino_gemm_launch(c->wres2[i], c->wino_v, n, hf, wf, ACT_NONE, x, xn, s, c->wino_variant));   // out += x
+        if (wino4) {
+            HIP_TRY(c, wino4_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, c->wino_v, s));
+            SUB_MARK();
+            HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], c->wino_v, n, hf, wf, ACT_RELU, nullptr, c->tmp, s, c->wino4_variant));
+            SUB_MARK();
+            HIP_TRY(c, wino4_transform_launch(c->tmp, nullptr, nullptr, n, hf, wf, c->Cb, c->wino_v, s));
+            SUB_MARK();
+            HIP_TRY(c, wino4_gemm_launch(c->w4res2[i], c->wino_v, n, hf, wf, ACT_NONE, x, xn, s, c->wino4_variant));   // out += x
+        } else {
+            HIP_TRY(c, wino_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, c->wino_v, s));
+            SUB_MARK();
+            HIP_TRY(c, wino_gemm_launch(c->wres1[i], c->wino_v, n, hf, wf, ACT_RELU, nullptr, c->tmp, s, c->wino_variant));
+            SUB_MARK();
+            HIP_TRY(c, wino_transform_launch(c->tmp, nullptr, nullptr, n, hf, wf, c->Cb, c->wino_v, s));
+            SUB_MARK();
+            HIP_TRY(c, wino_gemm_launch(c->wres2[i], c->wino_v, n, hf, wf, ACT_NONE, x, xn, s, c->wino_variant));   // out += x
+        }
         std::swap(x, xn);
     }
     SUB_MARK();
@@ -701,6 +731,8 @@ int eamm_import_source_cache(eamm_ctx* c, const void* src, int ns, void* stream_
 }
 
 double eamm_flops_per_frame(const eamm_ctx* c) { return c ? c->flops_frame : 0.0; }
+
+int eamm_bottleneck_form(const eamm_ctx* c, int n) { return (c && n > 0) ? bottleneck_form(c, n) : EAMM_ERR_ARG; }
 double eamm_encode_flops(const eamm_ctx* c) { return c ? c->flops_encode : 0.0; }
 
 int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int up,
@@ -751,16 +783,23 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         if (P.bias) (void)hipFree(P.bias);
         return rc;
     }
-    if (tile_n >= 2000 && tile_n < 2100) {  // Winograd F(2x2,3x3): input transform + GEMM (2000 + kernel variant)
-        if (kh != 3 || kw != 3 || up || pool || C1 || splitk > 1 || C0 % 64 || (Cout & 3))
+    if (tile_n >= 2000 && tile_n < 2200) {  // Winograd: input transform + GEMM; 2000 + variant F(2x2,3x3), 2100 + variant F(4x4,3x3)
+        const bool w4 = tile_n >= 2100;
+        if (kh != 3 || kw != 3 || up || pool || C1 || splitk > 1 || C0 % 64 || (Cout & 3) ||
+            (w4 && ((Hin & 3) || (Win & 3))))
             return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported Winograd configuration");
         WinoLayer W;
         W.Cin = C0;
         W.Cout = Cout;
-        W.BN = 128;
-        W.ntiles = (Cout + 127) / 128;
-        std::vector<float> packed(wino_packed_elems(Cout, C0, 128)), bias((size_t)W.ntiles * 128, 0.f);
-        wino_pack_host(w_host, Cout, C0, 128, packed.data());
+        W.tile = w4 ? 4 : 2;
+        W.BN = w4 ? 64 : 128;
+        W.ntiles = (Cout + W.BN - 1) / W.BN;
+        std::vector<float> packed(w4 ? wino4_packed_elems(Cout, C0, W.BN) : wino_packed_elems(Cout, C0, W.BN)),
+            bias((size_t)W.ntiles * W.BN, 0.f);
+        if (w4)
+            wino4_pack_host(w_host, Cout, C0, W.BN, packed.data());
+        else
+            wino_pack_host(w_host, Cout, C0, W.BN, packed.data());
         std::copy(b_host, b_host + Cout, bias.begin());
         float* V = nullptr;
         int rc = EAMM_OK;
@@ -774,12 +813,23 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
             !done(hipMalloc((void**)&V, vel * sizeof(float)), "hipMalloc") &&
             !done(hipMemcpy(W.u, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
             !done(hipMemcpy(W.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")) {
+            // timing-mode knob: EAMM_OP_WINO_PART = 1 times the input transform alone, 2 the GEMM alone
+            int part = env_int("EAMM_OP_WINO_PART", 0);
+            bool timing = false;
             auto run = [&]() {
-                hipError_t e = wino_transform_launch(in0, nullptr, nullptr, B, Hin, Win, C0, V, s);
-                if (e != hipSuccess) return e;
+                const bool tr = !timing || part != 2, gm = !timing || part != 1;
+                hipError_t e = hipSuccess;
+                if (w4) {
+                    if (tr) e = wino4_transform_launch(in0, nullptr, nullptr, B, Hin, Win, C0, V, s);
+                    if (e != hipSuccess || !gm) return e;
+                    return wino4_gemm_launch(W, V, B, Hin, Win, act, resid, out, s, tile_n - 2100);
+                }
+                if (tr) e = wino_transform_launch(in0, nullptr, nullptr, B, Hin, Win, C0, V, s);
+                if (e != hipSuccess || !gm) return e;
                 return wino_gemm_launch(W, V, B, Hin, Win, act, resid, out, s, tile_n - 2000);
             };
             if (!done(run(), "winograd launch") && iters > 0 && avg_ms) {
+                timing = true;
                 hipEvent_t e0, e1;
                 (void)hipEventCreate(&e0);
                 (void)hipEventCreate(&e1);

@@ -91,10 +91,11 @@ void patch_pack_host(const float* w_oihw_3x3, int Cout, int Cin, const int* cin_
 hipError_t patch_phase_launch(const PatchLayer& L, const float* in0, const float* in1, int B, int H, int W, int act,
                               float* out, hipStream_t stream);
 
-// ---- Winograd F(2x2,3x3) path for the bottleneck convolutions (conv_winograd.hip)
+// ---- Winograd paths for the bottleneck convolutions: F(2x2,3x3) (conv_winograd.hip), F(4x4,3x3) (conv_winograd4.hip)
 struct WinoLayer {
     int Cin = 0, Cout = 0, BN = 128, ntiles = 0;
-    float* u = nullptr;     // device, packed [ntiles][16*Cin/32][BN][32]
+    int tile = 2;           // output tile side: 2 -> 16 transform points, BN 128; 4 -> 36 points, BN 64
+    float* u = nullptr;     // device, packed [ntiles][(tile+2)^2*Cin/32][BN][32]
     float* bias = nullptr;  // device, [ntiles*BN]
 };
 size_t wino_packed_elems(int Cout, int Cin, int BN);
@@ -104,6 +105,14 @@ hipError_t wino_transform_launch(const float* x, const float* s, const float* t,
                                  hipStream_t stream);
 hipError_t wino_gemm_launch(const WinoLayer& L, const float* V, int B, int H, int W, int act, const float* resid,
                             float* out, hipStream_t stream, int variant = 0);
+
+size_t wino4_packed_elems(int Cout, int Cin, int BN);
+void wino4_pack_host(const float* w_oihw, int Cout, int Cin, int BN, float* dst);
+// V[36][B*H/4*W/4][C] = B^T d B of x (optionally of relu(x*s + t)); H, W multiples of 4
+hipError_t wino4_transform_launch(const float* x, const float* s, const float* t, int B, int H, int W, int C, float* V,
+                                  hipStream_t stream);
+hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, int W, int act, const float* resid,
+                             float* out, hipStream_t stream, int variant = 0);
 
 // ---- motion / warp / image kernels (motion.hip) ---------------------------------------------
 hipError_t kp_prepare_launch(const float* kd_val, const float* kd_jac, const float* ks_val, const float* ks_jac,

@@ -197,6 +197,10 @@ class Engine:
     def flops_per_frame(self) -> float:
         return self._L.eamm_flops_per_frame(self._ctx)
 
+    def bottleneck_form(self, frames: int) -> int:
+        """0 = direct, 2 = Winograd F(2x2,3x3), 4 = Winograd F(4x4,3x3) for a call of ``frames`` frames."""
+        return self._L.eamm_bottleneck_form(self._ctx, int(frames))
+
     @property
     def encode_flops(self) -> float:
         return self._L.eamm_encode_flops(self._ctx)

@@ -133,6 +133,9 @@ int eamm_import_source_cache(eamm_ctx* ctx, const void* src, int ns, void* strea
 /* Algorithmic work of one eamm_forward_frames call of n frames (for roofline accounting). */
 double eamm_flops_per_frame(const eamm_ctx* ctx);
 double eamm_encode_flops(const eamm_ctx* ctx);
+/* Form the bottleneck ResBlock2d convolutions take for a call of n frames: 0 = direct, 2 = Winograd F(2x2,3x3),
+ * 4 = Winograd F(4x4,3x3) (executed multiplies = 1, 4/9, 1/4 of the reference's; negative on a bad handle). */
+int eamm_bottleneck_form(const eamm_ctx* ctx, int n);
 
 /*
  * ---- key-point detectors -----------------------------------------------

@@ -55,7 +55,7 @@ def main():
         for tile in TILES:
             if tile > 1000 and (ks != 3 or kw != 3):
                 continue
-            if 2000 <= tile < 2100 and (up or pool or C1 or C0 % 64):
+            if 2000 <= tile < 2200 and (up or pool or C1 or C0 % 64 or (tile >= 2100 and (H % 4 or W % 4))):
                 continue
             if tile == 3000 and (not up or resid):
                 continue
