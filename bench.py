@@ -42,8 +42,8 @@ HBM_PEAK_GBS = 8000.0
 # FETCH_SIZE (KB) * 2 + WRITE_SIZE (KB) of the dominant kernel, profiles/r01_rocprofv3_pmc_{fetch,write}_*.txt
 TRAFFIC_WINO = int((180579.8 * 2 + 65536.0) * 1024)     # wino_gemm_kernel: V is read by both N tiles (algorithmic 339-406 MB)
 TRAFFIC_DIRECT = int((75139.8 * 2 + 65536.0) * 1024)    # conv_mfma_dma_kernel 256x256 (algorithmic 204 MB)
-TRAFFIC_WINO4 = None     # wino4_gemm_kernel: filled in from the PMC passes under profiles/
-TRAFFIC_SRC = "profiles/r01_rocprofv3_pmc_{fetch,write}_bottleneck_{winograd,conv_256x256tile}.txt"
+TRAFFIC_WINO4 = int((143463.7 * 2 + 65536.0) * 1024)     # wino4_gemm_kernel (algorithmic V 151 MB + U 9.4 MB per XCD + 67 MB out)
+TRAFFIC_SRC = "profiles/r01_rocprofv3_pmc_{fetch,write}_bottleneck_{winograd4,winograd,conv_256x256tile}.txt"
 
 
 def cpu_baseline(cfg, sd, size, frames):

@@ -25,6 +25,7 @@
 #include "conv_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace eamm {
 
@@ -34,71 +35,95 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------------------
 // input transform
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 y) {
-    return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), fmaf(a, x.w, y.w));
+// VEC floats per thread (ext vector: arithmetic is element-wise)
+template <int VEC> struct vec_of;
+template <> struct vec_of<1> { typedef float type; };
+template <> struct vec_of<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct vec_of<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <typename T> __device__ __forceinline__ T vfma(float a, T x, T y);
+template <> __device__ __forceinline__ float vfma<float>(float a, float x, float y) { return fmaf(a, x, y); }
+template <> __device__ __forceinline__ vec_of<2>::type vfma(float a, vec_of<2>::type x, vec_of<2>::type y) {
+    vec_of<2>::type r;
+    r[0] = fmaf(a, x[0], y[0]); r[1] = fmaf(a, x[1], y[1]);
+    return r;
 }
-__device__ __forceinline__ float4 f4_sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 f4_add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+template <> __device__ __forceinline__ vec_of<4>::type vfma(float a, vec_of<4>::type x, vec_of<4>::type y) {
+    vec_of<4>::type r;
+    r[0] = fmaf(a, x[0], y[0]); r[1] = fmaf(a, x[1], y[1]); r[2] = fmaf(a, x[2], y[2]); r[3] = fmaf(a, x[3], y[3]);
+    return r;
+}
+template <typename T> __device__ __forceinline__ T vrelu_affine(T v, T sc, T sh);
+template <> __device__ __forceinline__ float vrelu_affine<float>(float v, float sc, float sh) { return fmaxf(fmaf(v, sc, sh), 0.f); }
+template <> __device__ __forceinline__ vec_of<2>::type vrelu_affine(vec_of<2>::type v, vec_of<2>::type sc, vec_of<2>::type sh) {
+    vec_of<2>::type r;
+    r[0] = fmaxf(fmaf(v[0], sc[0], sh[0]), 0.f); r[1] = fmaxf(fmaf(v[1], sc[1], sh[1]), 0.f);
+    return r;
+}
+template <> __device__ __forceinline__ vec_of<4>::type vrelu_affine(vec_of<4>::type v, vec_of<4>::type sc, vec_of<4>::type sh) {
+    vec_of<4>::type r;
+    r[0] = fmaxf(fmaf(v[0], sc[0], sh[0]), 0.f); r[1] = fmaxf(fmaf(v[1], sc[1], sh[1]), 0.f);
+    r[2] = fmaxf(fmaf(v[2], sc[2], sh[2]), 0.f); r[3] = fmaxf(fmaf(v[3], sc[3], sh[3]), 0.f);
+    return r;
+}
 
 // (B^T d) for six values in place
-__device__ __forceinline__ void bt6(float4& d0, float4& d1, float4& d2, float4& d3, float4& d4, float4& d5) {
-    const float4 s12 = f4_add4(d1, d2), m12 = f4_sub4(d1, d2);
-    const float4 s34 = f4_add4(d3, d4), m43 = f4_sub4(d4, d3);
-    const float4 m31 = f4_sub4(d3, d1), m42 = f4_sub4(d4, d2);
-    const float4 t0 = f4_fma(4.f, d0, f4_fma(-5.f, d2, d4));
-    const float4 t1 = f4_fma(-4.f, s12, s34);
-    const float4 t2 = f4_fma(4.f, m12, m43);
-    const float4 t3 = f4_fma(2.f, m31, m42);
-    const float4 t4 = f4_fma(-2.f, m31, m42);
-    const float4 t5 = f4_fma(4.f, d1, f4_fma(-5.f, d3, d5));
+template <typename T> __device__ __forceinline__ void bt6(T& d0, T& d1, T& d2, T& d3, T& d4, T& d5) {
+    const T s12 = d1 + d2, m12 = d1 - d2;
+    const T s34 = d3 + d4, m43 = d4 - d3;
+    const T m31 = d3 - d1, m42 = d4 - d2;
+    const T t0 = vfma(4.f, d0, vfma(-5.f, d2, d4));
+    const T t1 = vfma(-4.f, s12, s34);
+    const T t2 = vfma(4.f, m12, m43);
+    const T t3 = vfma(2.f, m31, m42);
+    const T t4 = vfma(-2.f, m31, m42);
+    const T t5 = vfma(4.f, d1, vfma(-5.f, d3, d5));
     d0 = t0; d1 = t1; d2 = t2; d3 = t3; d4 = t4; d5 = t5;
 }
 
+// One thread per (tile, VEC channels): a wave covers 64*VEC contiguous channels of one tile.
+template <int VEC>
 __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float* __restrict__ x,
                                                                     const float* __restrict__ s,
                                                                     const float* __restrict__ t, int B, int H, int W,
                                                                     int C, float* __restrict__ V) {
-    const int c4n = C >> 2;
+    typedef typename vec_of<VEC>::type T;
+    const int cvn = C / VEC;
     const int Hq = H >> 2, Wq = W >> 2;
     const size_t Mq = (size_t)B * Hq * Wq;
-    const size_t total = Mq * c4n;
+    const size_t total = Mq * cvn;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % c4n);
-        const size_t q = idx / c4n;
+        const int cv = (int)(idx % cvn);
+        const size_t q = idx / cvn;
         const int qx = (int)(q % Wq);
         const int qy = (int)((q / Wq) % Hq);
         const int b = (int)(q / ((size_t)Wq * Hq));
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        T sc = T(1.f), sh = T(0.f);
         if (s != nullptr) {
-            sc = reinterpret_cast<const float4*>(s)[c4];
-            sh = reinterpret_cast<const float4*>(t)[c4];
+            sc = reinterpret_cast<const T*>(s)[cv];
+            sh = reinterpret_cast<const T*>(t)[cv];
         }
-        const float4* img = reinterpret_cast<const float4*>(x) + (size_t)b * H * W * c4n + c4;
-        float4 d[6][6];
+        const T* img = reinterpret_cast<const T*>(x) + (size_t)b * H * W * cvn + cv;
+        T d[6][6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int yy = 4 * qy - 1 + i;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int xx = 4 * qx - 1 + j;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                T v = T(0.f);
                 if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                    v = img[(size_t)(yy * W + xx) * c4n];
-                    if (s != nullptr) {  // zero padding applies to the ACTIVATED tensor: only in-range pixels
-                        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-                        v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-                        v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-                    }
+                    v = img[(size_t)(yy * W + xx) * cvn];
+                    if (s != nullptr) v = vrelu_affine(v, sc, sh);  // zero padding applies to the ACTIVATED tensor
                 }
                 d[i][j] = v;
             }
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);   // along y
-        float4* out = reinterpret_cast<float4*>(V) + q * c4n + c4;
-        const size_t plane = Mq * c4n;
+        T* out = reinterpret_cast<T*>(V) + q * cvn + cv;
+        const size_t plane = Mq * cvn;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);                              // along x
@@ -138,6 +163,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     constexpr int A_STAGE = SUB * BM * BK, B_STAGE = SUB * BN * BK;  // floats per stage
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;       // DMA instructions per wave per chunk
     constexpr int NPIECE = SUB * (A_INSTR + B_INSTR);
+    constexpr bool TRACE = DBG == 8 || DBG == 9;   // DBG: 0 product; 1 no DMA in the loop; 8/9 interval trace (with/without DMA)
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
     static_assert(BK == 32, "two 16-wide K steps per chunk");
 
@@ -231,7 +257,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
                 constexpr int gi = step * MF + q;
                 if constexpr (gi % PE == PE - 1 && gi / PE < NPIECE) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more && DBG != 1 && !(DBG == 2 && ((gi / PE) & 1))) dma_piece(std::integral_constant<int, gi / PE>{});
+                    if (more && DBG != 1 && DBG != 9) dma_piece(std::integral_constant<int, gi / PE>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -292,7 +318,10 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
         const bool more = sc + D < nsuper;
         n_sc = sc + D;
         n_st = st_next;
+        long long ts0 = 0, ts1 = 0, ts2 = 0;
+        if constexpr (TRACE) ts0 = __builtin_readcyclecounter();
         compute(st, more);
+        if constexpr (TRACE) ts1 = __builtin_readcyclecounter();
         if (--xi_left == 0) {
             xi_left = per_xi;
             fold_x(xj);
@@ -301,10 +330,18 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
                 fold_y(xrow++);
             }
         }
+        if constexpr (TRACE) ts2 = __builtin_readcyclecounter();
         if (D > 1 && more) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NPIECE) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (TRACE) {   // diagnostic (tools/wino4_trace.py): cycle stamps of block 0 go to the `resid` buffer
+            const long long ts3 = __builtin_readcyclecounter();
+            if (blockIdx.x == 0 && lane == 0 && sc < 72) {
+                long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(p.resid)) + (wave * 72 + sc) * 4;
+                dbg[0] = ts0; dbg[1] = ts1; dbg[2] = ts2; dbg[3] = ts3;
+            }
         }
         __syncthreads();
         st = st + 1 == NST ? 0 : st + 1;
@@ -335,7 +372,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     const unsigned out_bytes = (unsigned)p.Mq * 16u * (unsigned)p.Cout * 4u;
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsr =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, p.resid != nullptr ? out_bytes : 0u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, (p.resid != nullptr && !TRACE) ? out_bytes : 0u, 0x00020000);
     const float lo = p.act == ACT_RELU ? 0.f : -INFINITY;
     const unsigned row_bytes = (unsigned)p.W * (unsigned)p.Cout * 4u;
     const float* e_src = smem + (e_px * BM + e_row0) * LDO + e_c4 * 4;
@@ -408,9 +445,19 @@ size_t wino4_packed_elems(int Cout, int Cin, int BN) {
 hipError_t wino4_transform_launch(const float* x, const float* s, const float* t, int B, int H, int W, int C, float* V,
                                   hipStream_t stream) {
     if ((H & 3) || (W & 3) || (C & 3)) return hipErrorInvalidValue;
-    const size_t total = (size_t)B * (H / 4) * (W / 4) * (C / 4);
+    static const int vec = [] {
+        const char* e = getenv("EAMM_WINO4_TR_VEC");
+        const int v = e ? atoi(e) : 4;
+        return (v == 1 || v == 2) ? v : 4;
+    }();
+    const size_t total = (size_t)B * (H / 4) * (W / 4) * (C / vec);
     const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)1 << 20);
-    hipLaunchKernelGGL(wino4_input_transform_kernel, dim3(blocks), dim3(256), 0, stream, x, s, t, B, H, W, C, V);
+    if (vec == 1)
+        hipLaunchKernelGGL(wino4_input_transform_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, s, t, B, H, W, C, V);
+    else if (vec == 2)
+        hipLaunchKernelGGL(wino4_input_transform_kernel<2>, dim3(blocks), dim3(256), 0, stream, x, s, t, B, H, W, C, V);
+    else
+        hipLaunchKernelGGL(wino4_input_transform_kernel<4>, dim3(blocks), dim3(256), 0, stream, x, s, t, B, H, W, C, V);
     return hipGetLastError();
 }
 
@@ -460,7 +507,8 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
         case 3: return sub4 ? wino4_launch_variant<4, 2, 8>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream);
         case 4: return wino4_launch_variant<2, 4, 4>(a, stream);
         case 10: return wino4_launch_variant<4, 2, 4, 1>(a, stream);
-        case 11: return wino4_launch_variant<4, 2, 4, 2>(a, stream);
+        case 16: return wino4_launch_variant<4, 2, 4, 8>(a, stream);
+        case 17: return wino4_launch_variant<4, 2, 4, 9>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }
