@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/micro/dma_bw.hip -o tools/micro/dma_bw
 // Microbenchmark: LDS-DMA (buffer_load ... lds) streaming rate per CU when every CU streams at once.
 //   dma_bw <group> <region_KB> <inflight> <iters> [mode]
 // group   consecutive blocks (same XCD after the remap) that read the SAME stream (1 = private streams)
