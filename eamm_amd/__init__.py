@@ -9,7 +9,8 @@ from .engine import Engine  # noqa: F401
 from .clip import EngineBackend, animate_clip, shard_bounds  # noqa: F401
 from .keypoints import normalize_kp  # noqa: F401
 from .keypoint_detector import KPDetector, KPDetector_a  # noqa: F401
+from .deconv_tail import DeconvTail  # noqa: F401
 from .config import kp_detector_config, kp_detector_a_config, tiny_kp_config  # noqa: F401
 
-__all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "shard_bounds", "normalize_kp", "KPDetector", "KPDetector_a",
+__all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "shard_bounds", "normalize_kp", "KPDetector", "KPDetector_a", "DeconvTail",
            "hot_path_config", "tiny_config"]

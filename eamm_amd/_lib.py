@@ -46,6 +46,10 @@ class EammKpConfig(C.Structure):
     ]
 
 
+class EammDeconvConfig(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("channels", C.c_int32 * 9), ("max_batch", C.c_int32)]
+
+
 class EammKpOutputs(C.Structure):
     _fields_ = [("value", C.c_void_p), ("jacobian", C.c_void_p), ("heatmap", C.c_void_p)]
 
@@ -76,6 +80,12 @@ SIGNATURES = {
     "eamm_kp_finalize_weights": (C.c_int, [C.c_void_p]),
     "eamm_kp_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(EammKpOutputs), C.c_void_p]),
     "eamm_kp_detect_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(EammKpOutputs), C.c_void_p]),
+    "eamm_deconv_create": (C.c_int, [C.POINTER(EammDeconvConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "eamm_deconv_destroy": (None, [C.c_void_p]),
+    "eamm_deconv_last_error": (C.c_char_p, [C.c_void_p]),
+    "eamm_deconv_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "eamm_deconv_finalize_weights": (C.c_int, [C.c_void_p]),
+    "eamm_deconv_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "eamm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "eamm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64), C.c_int]),
@@ -115,7 +125,7 @@ def lib() -> C.CDLL:
     return _lib
 
 
-def check(code: int, ctx=None, kp: bool = False):
+def check(code: int, ctx=None, kp: bool = False, deconv: bool = False):
     if code != EAMM_OK:
-        msg = (lib().eamm_kp_last_error if kp else lib().eamm_last_error)(ctx)
+        msg = (lib().eamm_deconv_last_error if deconv else lib().eamm_kp_last_error if kp else lib().eamm_last_error)(ctx)
         raise EammError(code, msg.decode() if msg else "?")

@@ -295,6 +295,17 @@ void conv_pack_host(const float* w, int Cout, int Cin, int kh, int kw, const int
     }
 }
 
+// Four explicit 2x2 phase filters (not derived from a 3x3 kernel): wph [4][Cout][Cin][4], phase = 2*py + px, tap =
+// 2*ty + tx reading input pixel (y - 1 + py + ty, x - 1 + px + tx) for output pixel (2y + py, 2x + px).  This is the
+// footprint of ConvTranspose2d(kernel 4, stride 2, padding 1) as well as of the collapsed UpBlock2d.
+void conv_pack_phases_host(const float* wph, int Cout, int Cin, const int* cin_map, int cin_packed, int BN, bool swizzle,
+                           float* dst) {
+    const size_t per_phase = conv_packed_elems(4, cin_packed, Cout, BN, 1);
+    std::memset(dst, 0, sizeof(float) * per_phase * 4);
+    for (int ph = 0; ph < 4; ++ph)
+        pack_one(wph + (size_t)ph * Cout * Cin * 4, Cout, Cin, 4, cin_map, cin_packed, BN, swizzle, dst + per_phase * ph);
+}
+
 ConvPlan conv_plan(const ConvLayer& L, int M, int force_splits) {
     ConvPlan pl;
     const int BM = L.BM;
@@ -389,6 +400,7 @@ hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream,
     else if (L.kh == 3 && L.kw == 3) e = launch_tile<3, 3, false>(L.BN, a, blocks, stream);
     else if (L.kh == 7 && L.kw == 7) e = launch_tile<7, 7, false>(L.BN, a, blocks, stream);
     else if (L.kh == 7 && L.kw == 1) e = launch_tile<7, 1, false>(L.BN, a, blocks, stream);
+    else if (L.kh == 1 && L.kw == 1) e = launch_tile<1, 1, false>(L.BN, a, blocks, stream);
     if (e != hipSuccess) return e;
     if (pl.splits > 1) {
         const int rows = io.pool ? (a.M >> 2) : a.M;

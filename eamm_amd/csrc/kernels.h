@@ -58,6 +58,9 @@ size_t conv_packed_elems(int taps, int cin_packed, int Cout, int BN, int nphase)
 // 3x3 weights and emits the four collapsed 2x2 filters.
 void conv_pack_host(const float* w, int Cout, int Cin, int kh, int kw, const int* cin_map, int cin_packed, int BN,
                     bool phase, bool swizzle, float* dst);
+// Same packing from four explicit 2x2 phase filters wph [4][Cout][Cin][4] (ConvTranspose2d k4 s2 p1, conv_mfma.hip).
+void conv_pack_phases_host(const float* wph, int Cout, int Cin, const int* cin_map, int cin_packed, int BN, bool swizzle,
+                           float* dst);
 // LDS-DMA tile configurations: id -> (BM, BN); returns false for an unknown id.
 bool conv_dma_tile(int dma_cfg, int* BM, int* BN);
 struct ConvArgs;

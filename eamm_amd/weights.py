@@ -125,6 +125,24 @@ def kp_state_dict_spec(cfg):
     return spec
 
 
+DECONV_CHANNELS = (256, 256, 128, 128, 128, 35)   # AT_net2.decon, reference util.py:559-574
+
+
+def deconv_state_dict_spec(channels=DECONV_CHANNELS):
+    """Checkpoint layout of the nn.Sequential `AT_net2.decon` (reference util.py:559-576): ConvTranspose2d at index
+    3i ([Cin,Cout,k,k], k = 6 for the first layer, 4 after), BatchNorm2d at 3i+1 for every layer but the last."""
+    spec = []
+    n = len(channels) - 1
+    for i in range(n):
+        k = 6 if i == 0 else 4
+        # "conv_w" draws with fan_in = shape[1]*k*k; a stride-2 transposed conv sums k*k/4 taps of shape[0] inputs
+        spec.append((f"{3 * i}.weight", (channels[i], channels[i + 1], k, k), "convT_w", 2.0))
+        spec.append((f"{3 * i}.bias", (channels[i + 1],), "conv_b", None))
+        if i + 1 < n:
+            _norm(f"{3 * i + 1}", channels[i + 1], spec)
+    return spec
+
+
 def antialias_kernel(channels: int, sigma: float = 1.5) -> torch.Tensor:
     """The fixed 13x13 Gaussian buffer of the anti-alias down-sampler.
 
@@ -149,6 +167,9 @@ def synthetic_state_dict(cfg, seed: int = 1234, spec=None) -> "OrderedDict[str, 
     for key, shape, kind, gain in (state_dict_spec(cfg) if spec is None else spec):
         if kind == "conv_w":
             fan_in = shape[1] * shape[2] * shape[3]
+            v = rs.standard_normal(shape) * math.sqrt(gain / fan_in)
+        elif kind == "convT_w":
+            fan_in = shape[0] * shape[2] * shape[3] / 4.0
             v = rs.standard_normal(shape) * math.sqrt(gain / fan_in)
         elif kind == "conv_b":
             v = 0.1 * rs.standard_normal(shape)

@@ -179,6 +179,32 @@ int eamm_kp_detect(eamm_kp_ctx* ctx, const float* image /*[B,3,H,W]*/, int B, co
 int eamm_kp_detect_features(eamm_kp_ctx* ctx, const float* feature_map, int B, const eamm_kp_outputs* out, void* stream);
 
 /*
+ * ---- N3: audio-to-feature deconvolution tail ------------------------------------------------------------
+ * Replaces the nn.Sequential `AT_net2.decon` (reference modules/util.py:559-576), which the reference evaluates
+ * once per frame on the LSTM output (util.py:604-607) to produce the [35,64,64] maps KPDetector_a consumes
+ * (demo.py:219): num_layers ConvTranspose2d layers -- the first 6x6 / stride 2 / padding 1 on the 1x1 input, the
+ * rest 4x4 / stride 2 / padding 1 -- each but the last followed by eval-mode BatchNorm2d + ReLU.
+ * State-dict keys are the Sequential's: "0.weight" [C0,C1,6,6], "0.bias", "1.weight", "1.bias", "1.running_mean",
+ * "1.running_var", "3.weight" [C1,C2,4,4], ... (strict check in eamm_deconv_finalize_weights).
+ */
+typedef struct eamm_deconv_ctx eamm_deconv_ctx;
+
+typedef struct eamm_deconv_config {
+    int32_t num_layers;     /* reference: 5                                                          */
+    int32_t channels[9];    /* [0] input features (256); [i+1] outputs of layer i (256,128,128,128,35);
+                             * every layer INPUT width must be a multiple of 32                      */
+    int32_t max_batch;      /* frames per eamm_deconv_forward call                                   */
+} eamm_deconv_config;
+
+int eamm_deconv_create(const eamm_deconv_config* cfg, int device, eamm_deconv_ctx** out);
+void eamm_deconv_destroy(eamm_deconv_ctx* ctx);
+const char* eamm_deconv_last_error(const eamm_deconv_ctx* ctx);
+int eamm_deconv_load_tensor(eamm_deconv_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim);
+int eamm_deconv_finalize_weights(eamm_deconv_ctx* ctx);
+/* x: [B, channels[0]] (= the reference's [B,C,1,1]) device fp32; out: [B, channels[L], S, S] NCHW, S = 4 << (L-1). */
+int eamm_deconv_forward(eamm_deconv_ctx* ctx, const float* x, int B, float* out, void* stream);
+
+/*
  * Stage timing for roofline accounting (bench.py): while enabled, every eamm_forward_frames call
  * records HIP events on the caller's stream at its stage boundaries and around every bottleneck launch
  * (up to 256 calls between reads).  eamm_profile_read waits for the recorded calls and returns

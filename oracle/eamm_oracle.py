@@ -222,6 +222,20 @@ def kp_detector_a_forward(sd, cfg, feature_map):
     return kp_head(sd, cfg, feature_map)
 
 
+def deconv_tail(sd, x):
+    """`AT_net2.decon` (reference util.py:559-576, evaluated per frame at :604-607): ConvTranspose2d(k6,s2,p1) on the
+    [B,C,1,1] LSTM feature, then ConvTranspose2d(k4,s2,p1) layers, eval BatchNorm2d + ReLU after all but the last.
+    `sd` uses the Sequential's keys ("0.weight", "1.running_mean", "3.weight", ...)."""
+    n = 1 + max(int(k.split(".")[0]) for k in sd if k.endswith(".weight") and sd[k].dim() == 4) // 3
+    out = x.reshape(x.shape[0], -1, 1, 1)
+    for i in range(n):
+        w, b = sd[f"{3 * i}.weight"].to(out.dtype), sd[f"{3 * i}.bias"].to(out.dtype)
+        out = F.conv_transpose2d(out, w, b, stride=2, padding=1)
+        if i + 1 < n:
+            out = F.relu(batch_norm_eval(out, sd, f"{3 * i + 1}"))
+    return out
+
+
 def animate_clip(sd, cfg, source_image, kp_source, kp_driving_seq):
     """Counterpart of the per-frame loop in demo.py:251-281: one generator call per driving frame,
     prediction returned as float32 [H,W,3] arrays (np.transpose(pred, [0,2,3,1])[0])."""

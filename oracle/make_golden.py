@@ -193,7 +193,43 @@ def kp_detector_cases():
         json.dump(report, f, indent=1, sort_keys=True)
 
 
+def deconv_tail_case():
+    """Fixture for the deconvolution tail (N3): the reference's own `AT_net2().decon` (modules/util.py:559-576) with
+    seeded weights, driven the way AT_net2.forward drives it -- one [1,256,1,1] LSTM feature per frame
+    (util.py:600-607) -- plus the whole clip as one batch (what the drop-in does); the oracle must reproduce both."""
+    from eamm_amd.weights import deconv_state_dict_spec
+    import_reference()
+    from modules.util import AT_net2  # type: ignore
+    torch.manual_seed(0)
+    net = AT_net2().eval()
+    sd = synthetic_state_dict(None, seed=99, spec=deconv_state_dict_spec())
+    net.decon.load_state_dict(sd, strict=True)
+    t = 2
+    rs = np.random.RandomState(11)
+    x = torch.from_numpy(rs.standard_normal((t, 256)).astype(np.float32))      # lstm_out[0, t, :]
+    with torch.no_grad():
+        per_frame = torch.cat([net.decon(x[i:i + 1, :, None, None]) for i in range(t)], 0)   # util.py:603-607
+        batched = net.decon(x[:, :, None, None])
+        mine = orc.deconv_tail(sd, x)
+        ref64 = orc.deconv_tail({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x.double())
+    d_batch = float((per_frame - batched).abs().max())
+    d = float((mine - per_frame).abs().max())
+    floor = float((per_frame.double() - ref64).abs().max())
+    assert d <= max(2e-6, 2 * floor), (d, floor)
+    blob = {"weight_seed": np.int64(99), "x": x.numpy(), "out": per_frame.numpy(), "floor": np.float64(floor)}
+    np.savez_compressed(os.path.join(GOLDEN, "deconv_tail.npz"), **blob)
+    rep = {"oracle_vs_reference": d, "fp32_vs_fp64_floor": floor, "per_frame_vs_batched_reference": d_batch,
+           "stats": stats(per_frame)}
+    with open(os.path.join(GOLDEN, "summary_deconv.json"), "w") as f:
+        json.dump(rep, f, indent=1, sort_keys=True)
+    print("deconv_tail", rep)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "deconv":
+        os.makedirs(GOLDEN, exist_ok=True)
+        deconv_tail_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "normalize_kp":   # add this fixture without touching the others
         os.makedirs(GOLDEN, exist_ok=True)
         normalize_kp_case()
@@ -214,6 +250,7 @@ def main():
     summary["full512_clip1"] = case(OAG, "full512_clip1", full, 512, 1, 1234, 8)
     normalize_kp_case()
     kp_detector_cases()
+    deconv_tail_case()
     with open(os.path.join(GOLDEN, "summary.json"), "w") as f:
         json.dump({"torch": torch.__version__, "cases": summary}, f, indent=1, sort_keys=True)
     for name, rep in summary.items():

@@ -1,0 +1,95 @@
+"""Audio-to-feature deconvolution tail: oracle vs the fixture captured from the reference's
+`AT_net2().decon` (CPU), and the HIP module vs the same fixture and the oracle (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from eamm_amd import DeconvTail
+from eamm_amd.weights import DECONV_CHANNELS, deconv_state_dict_spec, synthetic_state_dict
+from oracle import eamm_oracle as orc
+
+TOL = 2e-5   # stated fp32 tolerance (max abs, outputs are O(1)); the reference's own fp32-vs-fp64 floor is 1.6e-6
+
+
+def fixture():
+    z = np.load(os.path.join(GOLDEN, "deconv_tail.npz"))
+    sd = synthetic_state_dict(None, seed=int(z["weight_seed"]), spec=deconv_state_dict_spec())
+    return z, sd, torch.from_numpy(z["x"])
+
+
+def test_oracle_matches_reference_fixture():
+    z, sd, x = fixture()
+    out = orc.deconv_tail(sd, x)
+    assert tuple(out.shape) == (x.shape[0], 35, 64, 64)
+    assert float((out - torch.from_numpy(z["out"])).abs().max()) <= max(2e-6, 2 * float(z["floor"]))
+    # frames are independent: the reference's per-frame calls (util.py:603-607) equal one batched call
+    one = torch.cat([orc.deconv_tail(sd, x[i:i + 1]) for i in range(x.shape[0])], 0)
+    assert float((one - out).abs().max()) <= 5e-6
+
+
+def test_module_layout_and_errors():
+    m = DeconvTail()
+    spec = deconv_state_dict_spec()
+    sd = m.state_dict()
+    # nn.Sequential numbering of the reference (util.py:559-574): 0,1,(2) 3,4,(5) ... 12
+    assert sorted(sd) == sorted(k for k, *_ in spec) and all(tuple(sd[k].shape) == tuple(s) for k, s, *_ in spec)
+    assert "12.weight" in sd and tuple(sd["12.weight"].shape) == (128, 35, 4, 4) and "13.weight" not in sd
+    # drop-in inside a parent module: the checkpoint's `decon.N.*` keys load unchanged
+    parent = torch.nn.Module()
+    parent.decon = DeconvTail()
+    parent.load_state_dict({"decon." + k: v for k, v in synthetic_state_dict(None, seed=1, spec=spec).items()}, strict=True)
+    m.eval()
+    with pytest.raises(RuntimeError, match="GPU"):        # no CPU fallback
+        m(torch.zeros(1, 256, 1, 1))
+    with pytest.raises(ValueError):
+        DeconvTail(channels=(256, 35))
+
+
+@pytest.mark.gpu
+def test_hip_module_matches_reference_fixture():
+    z, sd, x = fixture()
+    m = DeconvTail().eval()
+    m.load_state_dict(sd, strict=True)
+    m.cuda()
+    out = m(x.cuda()[:, :, None, None])                    # the reference's call shape [B,256,1,1]
+    assert tuple(out.shape) == (x.shape[0], 35, 64, 64)
+    err = float((out.cpu() - torch.from_numpy(z["out"])).abs().max())
+    assert err <= TOL, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 7, 40])
+def test_hip_module_matches_oracle_any_batch(batch):
+    _, sd, _ = fixture()
+    m = DeconvTail(max_batch=8).eval()                     # 40 > max_batch: the handle is rebuilt larger
+    m.load_state_dict(sd, strict=True)
+    m.cuda()
+    g = torch.Generator().manual_seed(batch)
+    x = torch.randn(batch, 256, generator=g)
+    out = m(x.cuda()).cpu()
+    ref = orc.deconv_tail(sd, x)
+    assert float((out - ref).abs().max()) <= TOL
+    again = m(x.cuda()).cpu()
+    assert torch.equal(out, again)                         # deterministic: no atomics in the split-K path
+    one = m(x[batch // 2:batch // 2 + 1].cuda()).cpu()     # batch independence
+    assert float((one - out[batch // 2:batch // 2 + 1]).abs().max()) <= 5e-6
+
+
+@pytest.mark.gpu
+def test_hip_module_small_config_and_weight_update():
+    ch = (64, 32, 32, 19)                                  # 3 layers: 1x1 -> 4x4 -> 8x8 -> 16x16, odd output width
+    spec = deconv_state_dict_spec(ch)
+    sd = synthetic_state_dict(None, seed=3, spec=spec)
+    m = DeconvTail(channels=ch).eval()
+    m.load_state_dict(sd, strict=True)
+    m.cuda()
+    x = torch.randn(5, 64, generator=torch.Generator().manual_seed(0))
+    out = m(x.cuda()).cpu()
+    assert tuple(out.shape) == (5, 19, 16, 16)
+    assert float((out - orc.deconv_tail(sd, x)).abs().max()) <= TOL
+    sd2 = synthetic_state_dict(None, seed=4, spec=spec)    # in-place weight update is picked up (version counters)
+    m.load_state_dict(sd2, strict=True)
+    assert float((m(x.cuda()).cpu() - orc.deconv_tail(sd2, x)).abs().max()) <= TOL
