@@ -32,7 +32,8 @@ struct eamm_ctx : eamm::CtxBase {
     int wino_tile = 4;                     // preferred output tile (EAMM_WINO_TILE): 4 -> F(4x4) where it applies, 2 -> F(2x2)
     int wino4_variant = 0;                 // wino4_gemm_kernel pipeline variant
     float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] (F(2x2)) or [36][F*hf*wf/16][Cb] transformed activations
-    int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd form
+    int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd F(2x2) form
+    int wino4_min_m = 20480;               // ... in F(4x4) form: 80 of 256 CUs busy still beats the direct kernel (measured: 5 frames at 256^2)
     int wino_variant = 0;                  // wino_gemm_kernel pipeline variant (see wino_gemm_launch); in-pipeline all are within noise
     std::vector<float*> pre_s, pre_t;  // res-block pre-activation scale/shift (norm1)
     float* aa_w = nullptr;
@@ -165,6 +166,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->Cb = c->down_c.back();
     read_tile_knobs(c);
     c->wino_min_m = env_int("EAMM_WINO_MIN_M", c->wino_min_m);
+    c->wino4_min_m = env_int("EAMM_WINO4_MIN_M", c->wino4_min_m);
     c->wino_variant = env_int("EAMM_WINO_VARIANT", c->wino_variant);   // < 0 disables the Winograd bottleneck
     c->wino_tile = env_int("EAMM_WINO_TILE", c->wino_tile);
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
@@ -424,8 +426,10 @@ int eamm_encode_source(eamm_ctx* c, const float* source, int ns, void* stream_) 
 // 0 = direct, 2 = Winograd F(2x2,3x3), 4 = Winograd F(4x4,3x3) for a call of n frames
 static int bottleneck_form(const eamm_ctx* c, int n) {
     const int hf = c->hf, wf = c->wf;
-    if (c->wres1.empty() || (size_t)n * hf * wf < (size_t)c->wino_min_m) return 0;
-    return (!c->w4res1.empty() && hf % 4 == 0 && wf % 4 == 0) ? 4 : 2;
+    if (c->wres1.empty()) return 0;
+    const size_t px = (size_t)n * hf * wf;
+    if (!c->w4res1.empty() && hf % 4 == 0 && wf % 4 == 0 && px >= (size_t)c->wino4_min_m) return 4;
+    return px >= (size_t)c->wino_min_m ? 2 : 0;
 }
 
 int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd_jac, const float* ks_val,
