@@ -203,6 +203,28 @@ def test_constructor_variants_match_oracle(name):
         assert out[k].shape == ref[k].shape and errs[k] <= TOL[k], (name, k, errs[k])
 
 
+@pytest.mark.parametrize("form,env", [(4, {"EAMM_WINO4_MIN_M": "1"}),
+                                      (2, {"EAMM_WINO_TILE": "2", "EAMM_WINO_MIN_M": "1"}),
+                                      (0, {"EAMM_WINO_MIN_M": "-1"})])
+def test_bottleneck_forms_match_reference_fixture(form, env, monkeypatch):
+    """The three forms of the bottleneck convolutions -- Winograd F(4x4,3x3), F(2x2,3x3), direct -- forced through the
+    library's knobs (read at eamm_create) on the tiny configuration, each against the reference fixture."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = tiny_config()
+    fx = load_case("tiny64_clip3")
+    sd, src, kp_d, kp_s, n, _ = inputs_from_fixture(fx, cfg)
+    gen = OcclusionAwareGenerator(**cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    e = gen.encode_source(src.to(DEV), max_frames=n)
+    assert e.bottleneck_form(n) == form
+    pred = e.forward_frames(cuda(kp_d), cuda(kp_s))["prediction"]
+    err = float((pred.cpu() - torch.from_numpy(fx["prediction"])).abs().max())
+    report(f"bottleneck form {form}", {"prediction": err})
+    assert err <= TOL["prediction"]
+
+
 def test_module_forward_source_cache():
     """forward() skips the source encoder only for the very same, unmodified tensor object; an in-place change or a
     different tensor re-encodes (results must track the data, as in the reference which always re-encodes)."""
