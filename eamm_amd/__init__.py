@@ -6,11 +6,11 @@ libeamm_hip.so, a C-ABI library of hand-written HIP kernels (include/eamm_hip.h)
 from .config import hot_path_config, tiny_config  # noqa: F401
 from .generator import OcclusionAwareGenerator  # noqa: F401
 from .engine import Engine  # noqa: F401
-from .clip import EngineBackend, animate_clip, shard_bounds  # noqa: F401
+from .clip import EngineBackend, animate_clip, driving_keypoints, shard_bounds  # noqa: F401
 from .keypoints import normalize_kp  # noqa: F401
 from .keypoint_detector import KPDetector, KPDetector_a  # noqa: F401
 from .deconv_tail import DeconvTail  # noqa: F401
 from .config import kp_detector_config, kp_detector_a_config, tiny_kp_config  # noqa: F401
 
-__all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "shard_bounds", "normalize_kp", "KPDetector", "KPDetector_a", "DeconvTail",
+__all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "driving_keypoints", "shard_bounds", "normalize_kp", "KPDetector", "KPDetector_a", "DeconvTail",
            "hot_path_config", "tiny_config"]

@@ -57,6 +57,28 @@ class EngineBackend:
         self.engine.check_numeric()
 
 
+@torch.no_grad()
+def driving_keypoints(deconv_tail, kp_detector_a, lstm_features: torch.Tensor, batch: int = 64) -> Dict[str, torch.Tensor]:
+    """Per-frame driving key points of a clip from the audio network's LSTM output, on the device.
+
+    Reference: ``AT_net2.forward`` runs ``self.decon`` on ``lstm_out[:, t]`` for every step t (modules/util.py:600-607)
+    and demo.py:219 feeds each ``deco_out[:, t]`` to ``kp_detector_a`` -- two batch-1 module calls per frame.  Here the
+    T frames go through ``DeconvTail`` and ``KPDetector_a`` ``batch`` at a time.  ``lstm_features``: [T,256] (or the
+    reference's [1,T,256]).  Returns {'value': [T,K,2], 'jacobian': [T,K,2,2]} (no heat-maps: demo.py never reads them).
+    """
+    if lstm_features.dim() == 3 and lstm_features.shape[0] == 1:
+        lstm_features = lstm_features[0]
+    if lstm_features.dim() != 2:
+        raise RuntimeError(f"expected [T,C] LSTM features, got {tuple(lstm_features.shape)}")
+    parts: Dict[str, List[torch.Tensor]] = {}
+    for t0 in range(0, lstm_features.shape[0], batch):
+        kp = kp_detector_a(deconv_tail(lstm_features[t0:t0 + batch].contiguous()))
+        for k in ("value", "jacobian"):
+            if k in kp:
+                parts.setdefault(k, []).append(kp[k])
+    return {k: torch.cat(v, 0) for k, v in parts.items()}
+
+
 def _bcast_kp(kp: Optional[Dict[str, torch.Tensor]], device, src: int, group) -> Dict[str, torch.Tensor]:
     """Broadcast a key-point dict from `src` (shapes first, then payload)."""
     rank = dist.get_rank(group)

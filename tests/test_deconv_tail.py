@@ -7,8 +7,8 @@ import pytest
 import torch
 
 from conftest import GOLDEN
-from eamm_amd import DeconvTail
-from eamm_amd.weights import DECONV_CHANNELS, deconv_state_dict_spec, synthetic_state_dict
+from eamm_amd import DeconvTail, KPDetector_a, driving_keypoints, kp_detector_a_config
+from eamm_amd.weights import DECONV_CHANNELS, deconv_state_dict_spec, kp_state_dict_spec, synthetic_state_dict
 from oracle import eamm_oracle as orc
 
 TOL = 2e-5   # stated fp32 tolerance (max abs, outputs are O(1)); the reference's own fp32-vs-fp64 floor is 1.6e-6
@@ -93,3 +93,24 @@ def test_hip_module_small_config_and_weight_update():
     sd2 = synthetic_state_dict(None, seed=4, spec=spec)    # in-place weight update is picked up (version counters)
     m.load_state_dict(sd2, strict=True)
     assert float((m(x.cuda()).cpu() - orc.deconv_tail(sd2, x)).abs().max()) <= TOL
+
+
+@pytest.mark.gpu
+def test_driving_keypoints_chain_matches_oracle():
+    """LSTM features -> decon -> KPDetector_a, the per-frame front end of demo.py:219, batched on the device, against
+    the oracle's composition of the two reference restatements."""
+    _, sd_d, _ = fixture()
+    cfg = kp_detector_a_config()
+    sd_k = synthetic_state_dict(cfg, seed=77, spec=kp_state_dict_spec(cfg))
+    tail = DeconvTail().eval()
+    tail.load_state_dict(sd_d, strict=True)
+    kpa = KPDetector_a(**cfg).eval()
+    kpa.load_state_dict(sd_k, strict=True)
+    tail.cuda(), kpa.cuda()
+    x = 0.3 * torch.randn(1, 11, 256, generator=torch.Generator().manual_seed(5))   # [1,T,256] as lstm_out
+    kp = driving_keypoints(tail, kpa, x.cuda(), batch=4)                             # 4 + 4 + 3: ragged last batch
+    with torch.no_grad():
+        ref = orc.kp_detector_a_forward(sd_k, cfg, orc.deconv_tail(sd_d, x[0]))
+    assert tuple(kp["value"].shape) == (11, 10, 2) and tuple(kp["jacobian"].shape) == (11, 10, 2, 2)
+    assert float((kp["value"].cpu() - ref["value"]).abs().max()) <= 5e-5
+    assert float((kp["jacobian"].cpu() - ref["jacobian"]).abs().max()) <= 2e-4
