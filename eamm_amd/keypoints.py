@@ -38,3 +38,41 @@ def normalize_kp(kp_source: Dict[str, torch.Tensor], kp_driving: Dict[str, torch
             jd = torch.matmul(kp_driving["jacobian"], torch.inverse(kp_driving_initial["jacobian"]))
             out["jacobian"] = torch.matmul(jd, kp_source["jacobian"])
     return out
+
+
+def one_euro_smooth(seq: torch.Tensor, mincutoff: float = 1.0, beta: float = 0.0, dcutoff: float = 1.0,
+                    freq: float = 30.0, scale: float = 1.0) -> torch.Tensor:
+    """One-Euro low-pass filter along dim 0 of ``seq`` ([T, ...]), element-wise over the rest -- the reference's
+    ``filter1.OneEuroFilter`` (filter1.py:13-47) applied as ``process(x * scale) / scale`` frame after frame
+    (demo.py:237-250).  The recurrence is sequential in T and tiny (K*2 or K*4 values per frame): it runs on the host in
+    float32 in the reference's operation order and returns a tensor on ``seq``'s device."""
+    x_all = (seq.detach().to("cpu", torch.float32) * scale)
+    out = torch.empty_like(x_all)
+    te = 1.0 / freq
+
+    def alpha_of(cutoff):
+        tau = 1.0 / (2 * np.pi * cutoff)
+        return 1.0 / (1.0 + tau / te)
+
+    a_d = alpha_of(dcutoff)
+    prev_x = prev_s = prev_edx = None
+    for t in range(x_all.shape[0]):
+        x = x_all[t]
+        if prev_x is None:                      # first sample: dx = 0, both low-pass filters pass their input through
+            edx = torch.zeros_like(x)
+            s = x
+        else:
+            dx = (x - prev_x) * freq
+            edx = a_d * dx + (1.0 - a_d) * prev_edx
+            a = alpha_of(mincutoff + beta * edx.abs())
+            s = a * x + (1.0 - a) * prev_s
+        prev_x, prev_s, prev_edx = x, s, edx
+        out[t] = s
+    return (out / scale).to(seq.device)
+
+
+def smooth_keypoints(kp_seq: Dict[str, torch.Tensor], mincutoff: float = 0.05, beta: float = 8.0, dcutoff: float = 1.0,
+                     freq: float = 100.0, scale: float = 10.0) -> Dict[str, torch.Tensor]:
+    """Temporal smoothing of a clip's driving key points, defaults = the reference's (demo.py:241-250: one filter for
+    the values, one for the jacobians, inputs scaled by 10).  ``kp_seq``: {'value': [T,K,2], 'jacobian': [T,K,2,2]}."""
+    return {k: one_euro_smooth(v, mincutoff, beta, dcutoff, freq, scale) for k, v in kp_seq.items()}

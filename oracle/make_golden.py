@@ -193,6 +193,30 @@ def kp_detector_cases():
         json.dump(report, f, indent=1, sort_keys=True)
 
 
+def smoothing_case():
+    """Fixture for the key-point smoothing between the two loops of make_animation_smooth (demo.py:237-250): the
+    reference's own filter1.OneEuroFilter, driven exactly as demo.py drives it (per frame, `.process(x*10)/10`, one
+    filter object for values and one for jacobians), on a seeded random-walk key-point sequence."""
+    import_reference()
+    from filter1 import OneEuroFilter  # type: ignore
+    rs = np.random.RandomState(21)
+    t, k = 24, 10
+    value = torch.from_numpy(np.cumsum(0.02 * rs.standard_normal((t, 1, k, 2)), 0).astype(np.float32))
+    jac = torch.from_numpy((np.eye(2) + np.cumsum(0.03 * rs.standard_normal((t, 1, k, 2, 2)), 0)).astype(np.float32))
+    blob = {"value": value[:, 0].numpy(), "jacobian": jac[:, 0].numpy()}
+    for name, kw, sc in (("kp", dict(mincutoff=0.05, beta=8, dcutoff=1.0, freq=100), 10),       # demo.py:241-250
+                         ("emo", dict(mincutoff=1, beta=0.2, dcutoff=1.0, freq=100), 100)):     # demo.py:231-239
+        fv, fj = OneEuroFilter(**kw), OneEuroFilter(**kw)
+        ov, oj = [], []
+        for j in range(t):
+            ov.append(fv.process(value[j].cpu() * sc) / sc)
+            oj.append(fj.process(jac[j].cpu() * sc) / sc)
+        blob[name + "_value"] = torch.cat(ov, 0).numpy()
+        blob[name + "_jacobian"] = torch.cat(oj, 0).numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "one_euro.npz"), **blob)
+    print("one_euro", {k: v.shape for k, v in blob.items()})
+
+
 def deconv_tail_case():
     """Fixture for the deconvolution tail (N3): the reference's own `AT_net2().decon` (modules/util.py:559-576) with
     seeded weights, driven the way AT_net2.forward drives it -- one [1,256,1,1] LSTM feature per frame
@@ -226,6 +250,10 @@ def deconv_tail_case():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "smooth":
+        os.makedirs(GOLDEN, exist_ok=True)
+        smoothing_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "deconv":
         os.makedirs(GOLDEN, exist_ok=True)
         deconv_tail_case()
@@ -251,6 +279,7 @@ def main():
     normalize_kp_case()
     kp_detector_cases()
     deconv_tail_case()
+    smoothing_case()
     with open(os.path.join(GOLDEN, "summary.json"), "w") as f:
         json.dump({"torch": torch.__version__, "cases": summary}, f, indent=1, sort_keys=True)
     for name, rep in summary.items():

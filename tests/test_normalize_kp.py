@@ -31,3 +31,21 @@ def test_normalize_kp_matches_reference(fx, adapt, rel, relj):
     assert torch.equal(kp_d["value"], fx["kp_driving_value"])
     if not rel:   # `relative=False` is the identity (demo.py:558 default) whatever adapt_movement_scale says
         assert torch.equal(out["value"], kp_d["value"]) and torch.equal(out["jacobian"], kp_d["jacobian"])
+
+
+@pytest.mark.parametrize("name,kw", [("kp", {}), ("emo", dict(mincutoff=1.0, beta=0.2, dcutoff=1.0, freq=100.0, scale=100.0))])
+def test_smooth_keypoints_matches_reference_filter(name, kw):
+    """Temporal smoothing between the two loops of make_animation_smooth (demo.py:231-250) against the reference's own
+    filter1.OneEuroFilter driven per frame (fixture from oracle/make_golden.py): defaults = the key-point filter,
+    the second parameter set is the emotion-displacement filter."""
+    from eamm_amd import one_euro_smooth, smooth_keypoints
+    z = np.load(os.path.join(GOLDEN, "one_euro.npz"))
+    seq = {"value": torch.from_numpy(z["value"]), "jacobian": torch.from_numpy(z["jacobian"])}
+    out = smooth_keypoints(seq, **kw)
+    for k in ("value", "jacobian"):
+        ref = torch.from_numpy(z[f"{name}_{k}"])
+        assert out[k].shape == ref.shape and torch.allclose(out[k], ref, atol=2e-6, rtol=0), (name, k)
+    assert torch.allclose(out["value"][0], seq["value"][0], atol=1e-7, rtol=0)   # the first frame passes through (x*s/s)
+    assert float((out["value"] - seq["value"]).abs().max()) > 1e-3       # ... and later ones are really filtered
+    flat = one_euro_smooth(seq["value"].reshape(24, -1), **(kw or dict(mincutoff=0.05, beta=8.0, dcutoff=1.0, freq=100.0, scale=10.0)))
+    assert torch.equal(flat.reshape(out["value"].shape), out["value"])  # element-wise: the shape does not matter
