@@ -163,7 +163,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     constexpr int A_STAGE = SUB * BM * BK, B_STAGE = SUB * BN * BK;  // floats per stage
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;       // DMA instructions per wave per chunk
     constexpr int NPIECE = SUB * (A_INSTR + B_INSTR);
-    constexpr bool TRACE = DBG == 8 || DBG == 9;   // DBG: 0 product; 1 no DMA in the loop; 8/9 interval trace (with/without DMA)
+    constexpr bool TRACE = DBG == 8 || DBG == 9;   // DBG: 0 product; 1 no DMA in the loop; 8/9 interval trace (with/without DMA);
+    constexpr bool YOUNG_FIRST = DBG != 20;        // 20: every wave interleaves its pieces (the first version)
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
     static_assert(BK == 32, "two 16-wide K steps per chunk");
 
@@ -246,6 +247,15 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
             for (int j = 0; j < NT; ++j) b[buf][j] = *reinterpret_cast<const f32x4_t*>(b_base + j * 16 * BK);
         };
         fetch(0, 0);
+        if constexpr (YOUNG_FIRST) {
+            // The matrix pipe serves the older wave of a SIMD first (waves 0..NW/2-1 finish an interval's MFMAs
+            // before waves NW/2.. get going), and a younger wave's interleaved pieces are gated by its own MFMA
+            // progress, so they used to issue late, in the tail the older wave no longer covers.  The younger half
+            // therefore issues its pieces before its first MFMA, while it would be waiting for the pipe anyway
+            // (measured: 2.29 -> 2.25 ms per step; moving the older half's pieces as well, or more pieces to one
+            // half, is slower -- profiles/r01_wino4_gemm_investigation.txt).
+            if (more && wave >= NW / 2) static_for<NPIECE>([&](auto kc) { dma_piece(kc); });
+        }
         static_for<STEPS>([&](auto sc) {
             constexpr int step = decltype(sc)::value;
             if constexpr (step + 1 < STEPS) fetch(step + 1, (step + 1) & 1);
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
                 constexpr int gi = step * MF + q;
                 if constexpr (gi % PE == PE - 1 && gi / PE < NPIECE) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more && DBG != 1 && DBG != 9) dma_piece(std::integral_constant<int, gi / PE>{});
+                    if (more && DBG != 1 && DBG != 9 && !(YOUNG_FIRST && wave >= NW / 2)) dma_piece(std::integral_constant<int, gi / PE>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -507,6 +517,7 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
         case 3: return sub4 ? wino4_launch_variant<4, 2, 8>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream);
         case 4: return wino4_launch_variant<2, 4, 4>(a, stream);
         case 10: return wino4_launch_variant<4, 2, 4, 1>(a, stream);
+        case 5: return sub4 ? wino4_launch_variant<4, 2, 4, 20>(a, stream) : wino4_launch_variant<2, 2, 4, 20>(a, stream);
         case 16: return wino4_launch_variant<4, 2, 4, 8>(a, stream);
         case 17: return wino4_launch_variant<4, 2, 4, 9>(a, stream);
         default: return hipErrorInvalidValue;
