@@ -50,6 +50,7 @@ struct CtxBase {
     int dma_min_m = 1024;       // smallest per-phase M for which an LDS-DMA tile is preferred
     int big_min_m = 49152;      // ... and for which Cout % 256 == 0 layers use the 256x256 tile (>= 192 M tiles)
     int dma_cfg_n256 = 2, dma_cfg_n128 = 2, dma_cfg_n64 = 3;
+    int patch_wino = 1;         // up blocks on the patch kernel in Winograd F(2x2,2x2) form (EAMM_PATCH_WINO)
     int patch_min_blocks = 192; // fewest workgroups for which UpBlock2d layers use the spatial-patch kernel (< 0: never)
 };
 
@@ -222,6 +223,11 @@ int build_patch(CtxBase* c, const std::string& conv, const std::string& norm, in
     std::copy(bf.begin(), bf.end(), bias_pad.begin());
     int rc = upload(c, &P->w, packed);
     if (rc) return rc;
+    if (c->patch_wino) {
+        std::vector<float> pw(patch_wino_packed_elems(cin_packed, Cout));
+        patch_wino_pack_host(wf.data(), Cout, Cin, map.data(), cin_packed, pw.data());
+        if ((rc = upload(c, &P->w_wino, pw))) return rc;
+    }
     return upload(c, &P->bias, bias_pad);
 }
 
@@ -298,7 +304,10 @@ int launch_up(CtxBase* c, const LayerSet& S, const ConvIO& io, hipStream_t s) {
     if (S.has_patch) {
         const int blocks = ((io.Hin + 15) / 16) * ((io.Win + 15) / 16) * io.B * ((S.patch.Cout + 63) / 64);
         if (blocks >= c->patch_min_blocks && io.Hin >= 16 && io.Win >= 16 && io.act == ACT_RELU && !io.resid && !io.out2 && !io.pool && !io.nchw) {
-            HIP_TRY(c, patch_phase_launch(S.patch, io.in0, io.in1, io.B, io.Hin, io.Win, io.act, io.out, s));
+            if (S.patch.w_wino && !(io.Hin & 1) && !(io.Win & 1))
+                HIP_TRY(c, patch_wino_launch(S.patch, io.in0, io.in1, io.B, io.Hin, io.Win, io.act, io.out, s));
+            else
+                HIP_TRY(c, patch_phase_launch(S.patch, io.in0, io.in1, io.B, io.Hin, io.Win, io.act, io.out, s));
             return EAMM_OK;
         }
     }
@@ -320,6 +329,7 @@ inline void read_tile_knobs(CtxBase* c) {
     // tuning knobs (defaults measured on MI355X, profiles/): EAMM_DMA_MIN_M < 0 disables the LDS-DMA kernels
     c->dma_min_m = env_int("EAMM_DMA_MIN_M", c->dma_min_m);
     c->big_min_m = env_int("EAMM_BIG_MIN_M", c->big_min_m);
+    c->patch_wino = env_int("EAMM_PATCH_WINO", c->patch_wino);
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
     c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);
     c->dma_cfg_n64 = env_int("EAMM_DMA_CFG_N64", c->dma_cfg_n64);

@@ -747,8 +747,9 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: bad argument");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
-    if (tile_n == 3000) {  // spatial-patch kernel for the collapsed up-convolution
-        if (kh != 3 || kw != 3 || !up || pool || resid || splitk > 1 || (Cout & 3))
+    if (tile_n == 3000 || tile_n == 3001) {  // spatial-patch kernel for the collapsed up-convolution (3001: Winograd F(2x2,2x2) form)
+        const bool pw = tile_n == 3001;
+        if (kh != 3 || kw != 3 || !up || pool || resid || splitk > 1 || (Cout & 3) || (pw && ((Hin | Win) & 1)))
             return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported patch-kernel configuration");
         PatchLayer P;
         P.C0 = C0;
@@ -756,6 +757,11 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         P.Cout = Cout;
         std::vector<float> packed(patch_packed_elems(C0 + C1, Cout)), bias((size_t)((Cout + 63) / 64) * 64, 0.f);
         patch_pack_host(w_host, Cout, C0 + C1, nullptr, C0 + C1, packed.data());
+        std::vector<float> packed_w;
+        if (pw) {
+            packed_w.resize(patch_wino_packed_elems(C0 + C1, Cout));
+            patch_wino_pack_host(w_host, Cout, C0 + C1, nullptr, C0 + C1, packed_w.data());
+        }
         std::copy(b_host, b_host + Cout, bias.begin());
         int rc = EAMM_OK;
         auto bad = [&](hipError_t e, const char* what) {
@@ -765,8 +771,13 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         if (!bad(hipMalloc((void**)&P.w, packed.size() * sizeof(float)), "hipMalloc") &&
             !bad(hipMalloc((void**)&P.bias, bias.size() * sizeof(float)), "hipMalloc") &&
             !bad(hipMemcpy(P.w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
-            !bad(hipMemcpy(P.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")) {
-            auto run = [&]() { return patch_phase_launch(P, in0, in1, B, Hin, Win, act, out, s); };
+            !bad(hipMemcpy(P.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
+            (!pw || (!bad(hipMalloc((void**)&P.w_wino, packed_w.size() * sizeof(float)), "hipMalloc") &&
+                     !bad(hipMemcpy(P.w_wino, packed_w.data(), packed_w.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")))) {
+            auto run = [&]() {
+                return pw ? patch_wino_launch(P, in0, in1, B, Hin, Win, act, out, s)
+                          : patch_phase_launch(P, in0, in1, B, Hin, Win, act, out, s);
+            };
             if (!bad(run(), "patch launch") && iters > 0 && avg_ms) {
                 hipEvent_t e0, e1;
                 (void)hipEventCreate(&e0);
@@ -784,6 +795,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
             bad(hipStreamSynchronize(s), "hipStreamSynchronize");
         }
         if (P.w) (void)hipFree(P.w);
+        if (P.w_wino) (void)hipFree(P.w_wino);
         if (P.bias) (void)hipFree(P.bias);
         return rc;
     }
