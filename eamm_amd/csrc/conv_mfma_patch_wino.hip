@@ -48,6 +48,7 @@ struct PatchWinoArgs {
     const float* w;        // packed [ntile][cchunk][xi 9][phase 4][64][32], swizzled
     const float* bias;     // [ntiles*64]
     int Cout, act;
+    int young_first;
     float* out;
 };
 
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
     });
 
     // GEMM row of this lane: phase = wave / 2, tile t = 32 (wave % 2) + l31 of the 8x8 tiles, (Ty, Tx) = (t / 8, t % 8)
+    const int yf = p.young_first;
     const int ph = wave >> 1, py = ph >> 1, px = ph & 1;
     const int tl = (wave & 1) * 32 + l31;
     const int idx0 = (2 * (tl >> 3) + py) * QW + 2 * (tl & 7) + px;   // patch pixel e[0][0] of the tile
@@ -159,6 +161,13 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
             a[buf] = v;
         };
         issue(0, 0);
+        // the younger wave of each SIMD (waves 4-7: the matrix pipe serves the older one first) issues its DMA pieces
+        // before its first MFMA, the older wave interleaves them (same placement as wino4_gemm_kernel)
+        const bool young = yf && wave >= QWAVES / 2;
+        if (young) {
+            if (more_w) static_for<B_INSTR>([&](auto jc) { dma_weight_piece(jc, it_next, b_st ^ 1); });
+            if (more_a) dma_patch_piece(xi, cc_next, a_st ^ 1);
+        }
         combine(0);
         static_for<4>([&](auto stc) {
             constexpr int step = decltype(stc)::value;
@@ -172,11 +181,11 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
                 // DMA pieces for the next interval: 4 weight pieces, then (intervals 0..A_INSTR-1) one piece of the next patch
                 if constexpr (g % 4 == 3 && g / 4 < B_INSTR) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more_w) dma_weight_piece(std::integral_constant<int, g / 4>{}, it_next, b_st ^ 1);
+                    if (more_w && !young) dma_weight_piece(std::integral_constant<int, g / 4>{}, it_next, b_st ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 } else if constexpr (g == 4 * B_INSTR + 3) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more_a) dma_patch_piece(xi, cc_next, a_st ^ 1);
+                    if (more_a && !young) dma_patch_piece(xi, cc_next, a_st ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -331,6 +340,8 @@ hipError_t patch_wino_launch(const PatchLayer& L, const float* in0, const float*
     a.Cout = L.Cout;
     a.act = act;
     a.out = out;
+    static const int yfe = [] { const char* e = getenv("EAMM_PWINO_YOUNG_FIRST"); return e ? atoi(e) : 1; }();
+    a.young_first = yfe;
     constexpr size_t lds_loop = sizeof(float) * 2 * (QPAD * CONV_BK + 4 * QBN * CONV_BK);
     constexpr size_t lds_epi = sizeof(float) * 256 * (QBN + 4);
     constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
