@@ -36,6 +36,12 @@ constexpr int QPAD = (QPIX + 7) / 8 * 8; // rounded to whole DMA instructions (8
 constexpr int QBN = 64;                  // output channels per workgroup
 constexpr int QNT = 2;                   // 32-wide MFMA tiles along N per wave
 constexpr int QWAVES = 8;
+constexpr int QHALF = QW * (QW / 2);      // patch pixels per column parity (162)
+
+// 16-byte-slot swizzle of patch pixel (row r, half-column ch): the lanes of a wave differ in (Ty, Tx) with r = 2 Ty + m,
+// ch = Tx + k; 2 (Ty mod 4) + bit 0 of (Tx + k)/2 is distinct over each group of 16 lanes a ds_read_b128 serves at once,
+// and the two lanes of a pair sit on different bank halves (position parity) -- conflict-free fragment reads.
+__device__ __forceinline__ int patch_swz(int r, int ch) { return ((r & 6) | ((ch >> 1) & 1)) & 7; }
 }  // namespace
 
 struct PatchWinoArgs {
@@ -49,6 +55,7 @@ struct PatchWinoArgs {
     const float* bias;     // [ntiles*64]
     int Cout, act;
     int young_first;
+    long long* trace;      // diagnostic (tools/pwino_trace.py): per-interval cycle stamps of workgroup 0, or null
     float* out;
 };
 
@@ -87,12 +94,16 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
     auto dma_patch_piece = [&](int j, int cc, int st) {
         const int piece = wave + QWAVES * j;
         if (j < A_INSTR && piece * 8 < QPAD) {
-            const int i = piece * 8 + (lane >> 3);   // patch pixel
-            const int pr = i / QW, pc = i - pr * QW;
+            // LDS position q of the patch image: even patch columns first, then odd ones (QHALF positions each), rows of
+            // QW/2 -- a wave reads every second column, so this keeps its 32 lanes on both halves of the banks; the
+            // 16-byte slot is XOR-swizzled with g(row, half-column) (patch_swz) instead of the position bits
+            const int q = piece * 8 + (lane >> 3);
+            const int hp = q >= QHALF ? 1 : 0, qq = q - hp * QHALF;
+            const int pr = qq / (QW / 2), ch = qq - pr * (QW / 2), pc = 2 * ch + hp;
             const int y = ty0 + pr - 1, x = tx0 + pc - 1;
-            const bool ok = (i < QPIX) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W);
+            const bool ok = (q < QPIX) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W);
             const int pix = (b * p.H + y) * p.W + x;
-            const int slot = ((lane & 7) ^ ((i >> 1) & 7)) << 2;
+            const int slot = ((lane & 7) ^ patch_swz(pr, ch)) << 2;
             const int c0 = cc * BK;
             const bool first = c0 < p.C0;
             const int C = first ? p.C0 : p.C1;
@@ -124,7 +135,6 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
     const int yf = p.young_first;
     const int ph = wave >> 1, py = ph >> 1, px = ph & 1;
     const int tl = (wave & 1) * 32 + l31;
-    const int idx0 = (2 * (tl >> 3) + py) * QW + 2 * (tl & 7) + px;   // patch pixel e[0][0] of the tile
 
     // One interval = one transform point of one channel chunk: 4 K steps x QNT tiles x 4 MFMAs.  The interval body
     // exists ONCE (transform point at run time, wave-uniform): nine unrolled copies next to the 128 + 32 accumulator
@@ -137,19 +147,29 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
         const float sij = si * sj;
         const float* a_stage = As + a_st * A_STAGE;
         const float* b_stage = Bs + b_st * B_STAGE + ph * (QBN * BK);
-        int idx0_l = idx0, l31_l = l31;     // opaque per interval: keeps the fragment addresses out of loop-invariant VGPRs
-        asm volatile("" : "+v"(idx0_l), "+v"(l31_l));
-        const int i00 = idx0_l + ra * QW + ca, i01 = idx0_l + ra * QW + cb, i10 = idx0_l + rb * QW + ca,
-                  i11 = idx0_l + rb * QW + cb;
+        int ty_l = tl >> 3, tx_l = tl & 7, l31_l = l31;     // opaque per interval: keeps the fragment addresses out of loop-invariant VGPRs
+        asm volatile("" : "+v"(ty_l), "+v"(tx_l), "+v"(l31_l));
+        // term (a,b) reads patch pixel (2 Ty + py + a, 2 Tx + px + b) -> position parity*QHALF + row*(QW/2) + half-column
+        auto term = [&](int a_, int b_, int& pos, int& swz) {
+            const int m = py + a_, pb = px + b_;
+            const int r = 2 * ty_l + m, chn = tx_l + (pb >> 1);
+            pos = (pb & 1) * QHALF + r * (QW / 2) + chn;
+            swz = patch_swz(r, chn);
+        };
+        int p00, p01, p10, p11, g00, g01, g10, g11;
+        term(ra, ca, p00, g00);
+        term(ra, cb, p01, g01);
+        term(rb, ca, p10, g10);
+        term(rb, cb, p11, g11);
         f32x4 a[2], bb[2][QNT], raw[4];
-        auto ld = [&](int idx, int s) {
-            return *reinterpret_cast<const f32x4*>(a_stage + idx * BK + ((((2 * s + half)) ^ ((idx >> 1) & 7)) << 2));
+        auto ld = [&](int pos, int swz, int s) {
+            return *reinterpret_cast<const f32x4*>(a_stage + pos * BK + ((((2 * s + half)) ^ swz) << 2));
         };
         auto issue = [&](int s, int buf) {
-            raw[0] = ld(i00, s);
-            raw[1] = ld(i01, s);
-            raw[2] = ld(i10, s);
-            raw[3] = ld(i11, s);
+            raw[0] = ld(p00, g00, s);
+            raw[1] = ld(p01, g01, s);
+            raw[2] = ld(p10, g10, s);
+            raw[3] = ld(p11, g11, s);
             const float* bt = b_stage + l31_l * BK + (((2 * s + half) ^ ((l31_l >> 1) & 7)) << 2);
 #pragma unroll
             for (int j = 0; j < QNT; ++j) bb[buf][j] = *reinterpret_cast<const f32x4*>(bt + j * 32 * BK);
@@ -224,8 +244,15 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
     int cc = 0, xi = 0;
     for (int it = 0; it < nint; ++it) {
         const int a_st = cc & 1;
+        long long ts0 = 0, ts1 = 0;
+        if (p.trace) ts0 = __builtin_readcyclecounter();
         compute(xi, a_st, b_st, it + 1, cc + 1, it + 1 < nint, cc + 1 < cchunks);
+        if (p.trace) ts1 = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.trace && blockIdx.x == 0 && lane == 0 && it < 72) {
+            long long* d = p.trace + (wave * 72 + it) * 3;
+            d[0] = ts0; d[1] = ts1; d[2] = __builtin_readcyclecounter();
+        }
         __syncthreads();
         b_st ^= 1;
         if (++xi == 9) {
@@ -315,7 +342,7 @@ void patch_wino_pack_host(const float* w, int Cout, int Cin, const int* cin_map,
 }
 
 hipError_t patch_wino_launch(const PatchLayer& L, const float* in0, const float* in1, int B, int H, int W, int act,
-                             float* out, hipStream_t stream) {
+                             float* out, hipStream_t stream, long long* trace) {
     if ((L.C0 % CONV_BK) || (L.C1 % CONV_BK) || (L.Cout & 3) || (H & 1) || (W & 1) || L.w_wino == nullptr)
         return hipErrorInvalidValue;
     PatchWinoArgs a{};
@@ -342,6 +369,7 @@ hipError_t patch_wino_launch(const PatchLayer& L, const float* in0, const float*
     a.out = out;
     static const int yfe = [] { const char* e = getenv("EAMM_PWINO_YOUNG_FIRST"); return e ? atoi(e) : 1; }();
     a.young_first = yfe;
+    a.trace = trace;
     constexpr size_t lds_loop = sizeof(float) * 2 * (QPAD * CONV_BK + 4 * QBN * CONV_BK);
     constexpr size_t lds_epi = sizeof(float) * 256 * (QBN + 4);
     constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;

@@ -747,8 +747,10 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: bad argument");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
-    if (tile_n == 3000 || tile_n == 3001) {  // spatial-patch kernel for the collapsed up-convolution (3001: Winograd F(2x2,2x2) form)
-        const bool pw = tile_n == 3001;
+    if (tile_n == 3000 || tile_n == 3001 || tile_n == 3002) {   // 3002: 3001 + interval trace into `resid` (diagnostic)  // spatial-patch kernel for the collapsed up-convolution (3001: Winograd F(2x2,2x2) form)
+        const bool pw = tile_n != 3000;
+        long long* trace = tile_n == 3002 ? reinterpret_cast<long long*>(const_cast<float*>(resid)) : nullptr;
+        if (tile_n == 3002) resid = nullptr;
         if (kh != 3 || kw != 3 || !up || pool || resid || splitk > 1 || (Cout & 3) || (pw && ((Hin | Win) & 1)))
             return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported patch-kernel configuration");
         PatchLayer P;
@@ -775,7 +777,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
             (!pw || (!bad(hipMalloc((void**)&P.w_wino, packed_w.size() * sizeof(float)), "hipMalloc") &&
                      !bad(hipMemcpy(P.w_wino, packed_w.data(), packed_w.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")))) {
             auto run = [&]() {
-                return pw ? patch_wino_launch(P, in0, in1, B, Hin, Win, act, out, s)
+                return pw ? patch_wino_launch(P, in0, in1, B, Hin, Win, act, out, s, trace)
                           : patch_phase_launch(P, in0, in1, B, Hin, Win, act, out, s);
             };
             if (!bad(run(), "patch launch") && iters > 0 && avg_ms) {

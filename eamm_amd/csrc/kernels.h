@@ -94,7 +94,7 @@ size_t patch_packed_elems(int Cin_packed, int Cout);
 size_t patch_wino_packed_elems(int Cin_packed, int Cout);
 void patch_wino_pack_host(const float* w_oihw_3x3, int Cout, int Cin, const int* cin_map, int cin_packed, float* dst);
 hipError_t patch_wino_launch(const PatchLayer& L, const float* in0, const float* in1, int B, int H, int W, int act,
-                             float* out, hipStream_t stream);
+                             float* out, hipStream_t stream, long long* trace = nullptr);
 void patch_pack_host(const float* w_oihw_3x3, int Cout, int Cin, const int* cin_map, int cin_packed, float* dst);
 hipError_t patch_phase_launch(const PatchLayer& L, const float* in0, const float* in1, int B, int H, int W, int act,
                               float* out, hipStream_t stream);
