@@ -150,27 +150,24 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
         int ty_l = tl >> 3, tx_l = tl & 7, l31_l = l31;     // opaque per interval: keeps the fragment addresses out of loop-invariant VGPRs
         asm volatile("" : "+v"(ty_l), "+v"(tx_l), "+v"(l31_l));
         // term (a,b) reads patch pixel (2 Ty + py + a, 2 Tx + px + b) -> position parity*QHALF + row*(QW/2) + half-column
-        auto term = [&](int a_, int b_, int& pos, int& swz) {
+        // LDS float index of a term's 16 bytes at K step s: base ^ (8 s) -- the step only flips bits 1-2 of the
+        // XOR-swizzled slot, so one v_xor per read replaces the per-step address arithmetic
+        auto term = [&](int a_, int b_) {
             const int m = py + a_, pb = px + b_;
             const int r = 2 * ty_l + m, chn = tx_l + (pb >> 1);
-            pos = (pb & 1) * QHALF + r * (QW / 2) + chn;
-            swz = patch_swz(r, chn);
+            const int pos = (pb & 1) * QHALF + r * (QW / 2) + chn;
+            return pos * BK + ((half ^ patch_swz(r, chn)) << 2);
         };
-        int p00, p01, p10, p11, g00, g01, g10, g11;
-        term(ra, ca, p00, g00);
-        term(ra, cb, p01, g01);
-        term(rb, ca, p10, g10);
-        term(rb, cb, p11, g11);
+        const int b00 = term(ra, ca), b01 = term(ra, cb), b10 = term(rb, ca), b11 = term(rb, cb);
+        const int bw0 = l31_l * BK + ((half ^ ((l31_l >> 1) & 7)) << 2);
         f32x4 a[2], bb[2][QNT], raw[4];
-        auto ld = [&](int pos, int swz, int s) {
-            return *reinterpret_cast<const f32x4*>(a_stage + pos * BK + ((((2 * s + half)) ^ swz) << 2));
-        };
-        auto issue = [&](int s, int buf) {
-            raw[0] = ld(p00, g00, s);
-            raw[1] = ld(p01, g01, s);
-            raw[2] = ld(p10, g10, s);
-            raw[3] = ld(p11, g11, s);
-            const float* bt = b_stage + l31_l * BK + (((2 * s + half) ^ ((l31_l >> 1) & 7)) << 2);
+        auto issue = [&](auto sc_, int buf) {
+            constexpr int s = decltype(sc_)::value;
+            raw[0] = *reinterpret_cast<const f32x4*>(a_stage + (b00 ^ (8 * s)));
+            raw[1] = *reinterpret_cast<const f32x4*>(a_stage + (b01 ^ (8 * s)));
+            raw[2] = *reinterpret_cast<const f32x4*>(a_stage + (b10 ^ (8 * s)));
+            raw[3] = *reinterpret_cast<const f32x4*>(a_stage + (b11 ^ (8 * s)));
+            const float* bt = b_stage + (bw0 ^ (8 * s));
 #pragma unroll
             for (int j = 0; j < QNT; ++j) bb[buf][j] = *reinterpret_cast<const f32x4*>(bt + j * 32 * BK);
         };
@@ -180,7 +177,7 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
             for (int e = 0; e < 4; ++e) v[e] = fmaf(sij, raw[3][e], fmaf(si, raw[2][e], fmaf(sj, raw[1][e], v[e])));
             a[buf] = v;
         };
-        issue(0, 0);
+        issue(std::integral_constant<int, 0>{}, 0);
         // the younger wave of each SIMD (waves 4-7: the matrix pipe serves the older one first) issues its DMA pieces
         // before its first MFMA, the older wave interleaves them (same placement as wino4_gemm_kernel)
         const bool young = yf && wave >= QWAVES / 2;
@@ -191,7 +188,7 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
         combine(0);
         static_for<4>([&](auto stc) {
             constexpr int step = decltype(stc)::value;
-            if constexpr (step + 1 < 4) issue(step + 1, (step + 1) & 1);
+            if constexpr (step + 1 < 4) issue(std::integral_constant<int, step + 1>{}, (step + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
             static_for<4 * QNT>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
