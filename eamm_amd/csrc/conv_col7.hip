@@ -1,0 +1,180 @@
+// Column-patch kernel for the 7x1 (vertical) MFMA convolution behind the generator's final 7x7 convolution
+// (reference modules/generator.py:47,92: Conv2d(64 -> 3, 7x7, pad 3) + sigmoid).
+//
+// The final layer runs as a 7x1 convolution with N = (dx, co) = 21 "output channels" followed by a horizontal gather
+// (final_shift_sum_kernel, motion.hip).  The im2col-style kernel re-fetched its activation operand
+// once per vertical tap -- 7 x 268 MB through L2 per launch at 256^2 x 16 frames, which bounds it (5.6 TB/s of
+// L2 -> LDS traffic for 89 TFLOP/s).  Here a persistent workgroup walks 16x16-pixel tiles:
+//   * per 32-channel chunk the (16+6) x 16 input patch is DMA'd into LDS once (44 KiB); vertical tap t of output pixel
+//     (r, c) is patch pixel (r + t, c) = the same swizzled LDS image 2 KiB further on, so the seven taps' A fragments
+//     cost no address arithmetic at all (an immediate offset);
+//   * the whole weight tensor ([chunks][7][32][32] = 56 KiB for 64 input channels) stays resident in LDS;
+//   * the patch of the next (tile, chunk) unit streams in behind the 112 MFMAs of the current one (two stages).
+// Operand traffic drops from 7x to 22/16 = 1.4x the activation; the kernel is matrix-pipe bound (N = 21 of a 32-wide
+// tile is the remaining waste).  Output: the [B,H,W,32] partial products the gather kernel reads.
+#include "conv_common.h"
+
+#include <algorithm>
+
+namespace eamm {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+namespace {
+constexpr int CT = 16;                   // tile side
+constexpr int CPR = CT + 6;              // patch rows (halo 3 above and below)
+constexpr int CPIX = CPR * CT;           // 352 patch pixels = 44 DMA instructions of 8 pixels
+constexpr int CWAVES = 8;
+constexpr int CMAXCH = 2;                // channel chunks whose weights fit beside the two patch stages
+}  // namespace
+
+struct Col7Args {
+    const float* in;       // [B,H,W,C]
+    unsigned in_bytes, w_bytes;
+    int C, B, H, W;
+    int tiles_x, tiles_y, tiles;   // tiles per row / column / in total (B * tiles_y * tiles_x)
+    const float* w;        // packed [C/32][7][32][32], LDS-DMA swizzle
+    float* out;            // [B,H,W,32]
+};
+
+__global__ __launch_bounds__(CWAVES * 64) void conv_col7_kernel(const Col7Args p) {
+    constexpr int BK = CONV_BK;
+    constexpr int A_STAGE = CPIX * BK;             // floats (44 KiB)
+    constexpr int W_TAP = 32 * BK;                 // one (chunk, tap) weight tile
+    constexpr int A_PIECES = CPIX / 8;             // 44
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [cchunks*7][32][32] weights, [2][A_STAGE] patches
+    const int cchunks = p.C / BK;
+    float* const Ws = smem;
+    float* const As = smem + cchunks * 7 * W_TAP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    // unit u of this workgroup = (tile first + (u / cchunks) * gridDim.x, chunk u % cchunks)
+    const int first = blockIdx.x;
+    const int my_tiles = first < p.tiles ? (p.tiles - first + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int units = my_tiles * cchunks;
+    auto tile_of = [&](int u, int& b, int& ty0, int& tx0, int& cc) {
+        const int k = u / cchunks;
+        cc = u - k * cchunks;
+        int t = first + k * (int)gridDim.x;
+        tx0 = (t % p.tiles_x) * CT;
+        t /= p.tiles_x;
+        ty0 = (t % p.tiles_y) * CT;
+        b = t / p.tiles_y;
+    };
+    // patch piece j (0..43) of unit u into stage st: patch pixels 8j .. 8j+7, pixel q = (row q / 16, column q % 16)
+    auto dma_patch_piece = [&](int j, int u, int st) {
+        int b, ty0, tx0, cc;
+        tile_of(u, b, ty0, tx0, cc);
+        const int q = j * 8 + (lane >> 3);
+        const int y = ty0 + (q >> 4) - 3, x = tx0 + (q & 15);
+        const bool ok = ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W);
+        const int slot = ((lane & 7) ^ ((q >> 1) & 7)) << 2;
+        const unsigned off = ok ? (unsigned)(((b * p.H + y) * p.W + x) * p.C + cc * BK + slot) * 4u : OOB;
+        float* dst = As + st * A_STAGE + j * (8 * BK);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsi, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+    };
+
+    if (units == 0) return;
+    // ---- prologue: all weights + the first patch
+    for (int j = wave; j < cchunks * 7 * 4; j += CWAVES) {   // 1 KiB pieces of the weight tensor
+        const unsigned off = (unsigned)(j * (8 * BK) + lane * 4) * 4u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(Ws + j * (8 * BK)), 16, off, 0, 0, 0);
+    }
+    for (int j = wave; j < A_PIECES; j += CWAVES) dma_patch_piece(j, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc;
+    static_for<16>([&](auto rc) { acc[decltype(rc)::value] = 0.f; });
+
+    // this lane's pixel inside the tile: wave w owns rows 2w, 2w+1
+    const int trow = 2 * wave + (l31 >> 4), tcol = l31 & 15;
+    const int idx0 = trow * CT + tcol;                                 // patch pixel of tap 0 (dy = -3)
+    const int a_off = idx0 * BK + ((half ^ ((idx0 >> 1) & 7)) << 2);   // + 8*s for K step s via XOR; + tap * CT * BK
+    const int b_off = l31 * BK + ((half ^ ((l31 >> 1) & 7)) << 2);
+
+    for (int u = 0; u < units; ++u) {
+        const int st = u & 1;
+        const bool more = u + 1 < units;
+        const float* a_stage = As + st * A_STAGE;
+        int b, ty0, tx0, cc;
+        tile_of(u, b, ty0, tx0, cc);
+        const float* w_stage = Ws + cc * 7 * W_TAP;
+        // 7 taps x 4 K steps x 4 MFMAs; the next unit's patch pieces (wave, wave+8, ...: 5 or 6 per wave) ride along
+        f32x4 a[2], bb[2];
+        auto fetch = [&](auto tc, auto sc_, int buf) {
+            constexpr int t = decltype(tc)::value, s = decltype(sc_)::value;
+            a[buf] = *reinterpret_cast<const f32x4*>(a_stage + ((a_off ^ (8 * s)) + t * CT * BK));
+            bb[buf] = *reinterpret_cast<const f32x4*>(w_stage + ((b_off ^ (8 * s)) + t * W_TAP));
+        };
+        fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+        static_for<28>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;       // (tap, K step) index
+            if constexpr (g + 1 < 28)
+                fetch(std::integral_constant<int, (g + 1) / 4>{}, std::integral_constant<int, (g + 1) % 4>{}, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], bb[g & 1][q], acc, 0, 0, 0);
+            });
+            if constexpr (g % 4 == 1 && g / 4 < 6) {     // one patch piece after every 16 MFMAs, 6 slots
+                __builtin_amdgcn_sched_barrier(0);
+                const int j = wave + CWAVES * (g / 4);
+                if (more && j < A_PIECES) dma_patch_piece(j, u + 1, st ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        if (cc == cchunks - 1) {
+            // epilogue of the tile: lanes 0..31 of a wave hold the 32 channels of one pixel -> 128-byte rows
+            static_for<16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;   // pixel of the wave's 32: row m / 16, column m % 16
+                const int y = ty0 + 2 * wave + (m >> 4), x = tx0 + (m & 15);
+                if (y < p.H && x < p.W) p.out[((size_t)(b * p.H + y) * p.W + x) * 32 + l31] = acc[r];
+                acc[r] = 0.f;
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+hipError_t conv_col7_launch(const float* in, int C, int B, int H, int W, const float* w_swizzled, float* out,
+                            hipStream_t stream) {
+    if (C % CONV_BK || C / CONV_BK > CMAXCH || C < CONV_BK) return hipErrorInvalidValue;
+    Col7Args a{};
+    a.in = in;
+    const size_t ib = (size_t)B * H * W * C * 4, wb = (size_t)(C / CONV_BK) * 7 * 32 * CONV_BK * 4;
+    if (ib >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    a.in_bytes = (unsigned)ib;
+    a.w_bytes = (unsigned)wb;
+    a.C = C;
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.tiles_x = (W + CT - 1) / CT;
+    a.tiles_y = (H + CT - 1) / CT;
+    a.tiles = B * a.tiles_x * a.tiles_y;
+    a.w = w_swizzled;
+    a.out = out;
+    const size_t lds = wb + sizeof(float) * 2 * CPIX * CONV_BK;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static unsigned long long configured = 0;
+    if (hipError_t e = ensure_dynamic_lds(conv_col7_kernel, 160 * 1024, &configured); e != hipSuccess) return e;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int blocks = std::min(a.tiles, cus);
+    hipLaunchKernelGGL(conv_col7_kernel, dim3(blocks), dim3(CWAVES * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace eamm

@@ -41,6 +41,8 @@ struct eamm_ctx : eamm::CtxBase {
     int head_nc = 0;               // > 0: head is a 7x1 convolution over (dx, co), co < head_nc
     float* final_bias = nullptr;   // bias of the final conv, applied by the shift-sum kernel
     float* final_part = nullptr;   // [F,H,W,32] (dx,co) partial products of the final 7x7 conv
+    float* final_w_swz = nullptr;  // the 7x1 weights in LDS-DMA layout for the column-patch kernel (conv_col7.hip)
+    int col7 = 1;                  // EAMM_COL7: 0 = im2col-style kernel for the final convolution
 
     // source cache (exportable): feat [S,hf,wf,Cb], src_small [S,h,w,4], src_full [S,3,H,W]
     float *feat = nullptr, *src_small = nullptr, *src_full = nullptr;
@@ -169,6 +171,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->wino4_min_m = env_int("EAMM_WINO4_MIN_M", c->wino4_min_m);
     c->wino_variant = env_int("EAMM_WINO_VARIANT", c->wino_variant);   // < 0 disables the Winograd bottleneck
     c->wino_tile = env_int("EAMM_WINO_TILE", c->wino_tile);
+    c->col7 = env_int("EAMM_COL7", c->col7);
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
     c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);
@@ -285,8 +288,9 @@ int eamm_finalize_weights(eamm_ctx* c) {
     }
     {   // final 7x7 (Cout = 3): 7x1 MFMA convolution over (dx, co) + horizontal gather
         std::vector<float> fb;
+        const bool col7_ok = c->col7 && c->up_c.back() % 32 == 0 && c->up_c.back() <= 64;
         if ((rc = build_layer(c, {{"final", ""}}, 7, c->up_c.back(), c->up_c.back(), 0, 0, &c->final_conv,
-                              MODE_ROWSPLIT, &fb)))
+                              MODE_ROWSPLIT, &fb, 0, col7_ok ? &c->final_w_swz : nullptr)))
             return rc;
         if (c->final_conv.Cout != 21) return fail(c, EAMM_ERR_KEY, "final.weight must have 3 output channels");
         if ((rc = upload(c, &c->final_bias, fb))) return rc;
@@ -629,7 +633,10 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         io.partial_cap = c->partial_elems;
         ConvLayer fl = c->final_conv;
         fl.Cout = 32;  // 32-float pixel stride; channels >= 21 have zero weights
-        HIP_TRY(c, conv_launch(fl, io, s));
+        if (c->final_w_swz && fl.BN == 32)
+            HIP_TRY(c, conv_col7_launch(cur, fl.C0, n, c->H, c->W, c->final_w_swz, c->final_part, s));
+        else
+            HIP_TRY(c, conv_launch(fl, io, s));
         HIP_TRY(c, final_shift_sum_launch(c->final_part, c->final_bias, n, c->H, c->W, o->prediction, s));
     }
     if (o->frames_u8) HIP_TRY(c, to_u8_launch(o->prediction, n, c->H, c->W, o->frames_u8, s));
@@ -747,6 +754,39 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: bad argument");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (tile_n == 4000) {  // column-patch kernel of the final layer's 7x1 convolution: Cout must be the 32-float pixel stride
+        if (kh != 7 || kw != 1 || up || pool || resid || splitk > 1 || C1 || Cout != 32 || act != 0 || C0 % 32 || C0 > 64)
+            return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported column-patch configuration");
+        std::vector<float> packed(conv_packed_elems(7, C0, 32, 32, 1));
+        conv_pack_host(w_host, 32, C0, 7, 1, nullptr, C0, 32, false, true, packed.data());
+        float* wd = nullptr;
+        int rc = EAMM_OK;
+        auto bad = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess) rc = fail(nullptr, EAMM_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+            return e != hipSuccess;
+        };
+        if (!bad(hipMalloc((void**)&wd, packed.size() * sizeof(float)), "hipMalloc") &&
+            !bad(hipMemcpy(wd, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")) {
+            auto run = [&]() { return conv_col7_launch(in0, C0, B, Hin, Win, wd, out, s); };
+            if (!bad(run(), "col7 launch") && iters > 0 && avg_ms) {
+                hipEvent_t e0, e1;
+                (void)hipEventCreate(&e0);
+                (void)hipEventCreate(&e1);
+                (void)hipEventRecord(e0, s);
+                for (int i = 0; i < iters; ++i) (void)run();
+                (void)hipEventRecord(e1, s);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                *avg_ms = ms / iters;
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+            }
+            bad(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
+        if (wd) (void)hipFree(wd);
+        return rc;   // bias is not applied here (the gather kernel adds it in the pipeline): callers pass zeros
+    }
     if (tile_n == 3000 || tile_n == 3001 || tile_n == 3002) {   // 3002: 3001 + interval trace into `resid` (diagnostic)  // spatial-patch kernel for the collapsed up-convolution (3001: Winograd F(2x2,2x2) form)
         const bool pw = tile_n != 3000;
         long long* trace = tile_n == 3002 ? reinterpret_cast<long long*>(const_cast<float*>(resid)) : nullptr;

@@ -99,6 +99,11 @@ void patch_pack_host(const float* w_oihw_3x3, int Cout, int Cin, const int* cin_
 hipError_t patch_phase_launch(const PatchLayer& L, const float* in0, const float* in1, int B, int H, int W, int act,
                               float* out, hipStream_t stream);
 
+// ---- column-patch kernel for the 7x1 convolution of the final layer (conv_col7.hip): in [B,H,W,C] (C = 32 or 64),
+// w = conv_pack_host(..., kh 7, kw 1, BN 32, swizzle) image [C/32][7][32][32], out [B,H,W,32]
+hipError_t conv_col7_launch(const float* in, int C, int B, int H, int W, const float* w_swizzled, float* out,
+                            hipStream_t stream);
+
 // ---- Winograd paths for the bottleneck convolutions: F(2x2,3x3) (conv_winograd.hip), F(4x4,3x3) (conv_winograd4.hip)
 struct WinoLayer {
     int Cin = 0, Cout = 0, BN = 128, ntiles = 0;

@@ -29,7 +29,7 @@ def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
-def run_case(B, H, W, C0, C1, Cout, ks, kw=0, up=0, act=0, pool=0, resid=False, splitk=0, tile_n=0, seed=0):
+def run_case(B, H, W, C0, C1, Cout, ks, kw=0, up=0, act=0, pool=0, resid=False, splitk=0, tile_n=0, seed=0, zero_bias=False):
     kw = kw or ks
     g = torch.Generator().manual_seed(seed)
     cin = C0 + C1
@@ -37,6 +37,8 @@ def run_case(B, H, W, C0, C1, Cout, ks, kw=0, up=0, act=0, pool=0, resid=False, 
     in1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
     w = torch.randn(Cout, cin, ks, kw, generator=g) * (2.0 / (cin * ks * kw)) ** 0.5
     b = 0.1 * torch.randn(Cout, generator=g)
+    if zero_bias:   # the column-patch kernel leaves the bias to the gather kernel that follows it
+        b = torch.zeros(Cout)
     Ho, Wo = (H << up), (W << up)
     res = torch.randn(B, Cout, Ho, Wo, generator=g) if resid else None
     want = ref_conv(in0, in1, w, b, ks, kw, up, act, pool, res)
@@ -92,6 +94,11 @@ CASES = {
     "dma512x64":         dict(B=2, H=16, W=20, C0=32, C1=0, Cout=64, ks=3, act=1, tile_n=1003),
     "dma512x64_up":      dict(B=1, H=16, W=16, C0=128, C1=0, Cout=64, ks=3, up=1, act=1, tile_n=1003),
     "dma256_bottleneck": dict(B=4, H=64, W=64, C0=256, C1=0, Cout=256, ks=3, resid=True, tile_n=1001),
+    # column-patch kernel of the final layer's 7x1 convolution (tile_n = 4000): N = 32-float pixel stride
+    "col7_final_like":   dict(B=2, H=32, W=32, C0=64, C1=0, Cout=32, ks=7, kw=1, tile_n=4000, zero_bias=True),
+    "col7_one_chunk":    dict(B=1, H=16, W=48, C0=32, C1=0, Cout=32, ks=7, kw=1, tile_n=4000, zero_bias=True),
+    "col7_ragged":       dict(B=3, H=20, W=24, C0=64, C1=0, Cout=32, ks=7, kw=1, tile_n=4000, zero_bias=True),
+    "col7_many_tiles":   dict(B=5, H=128, W=128, C0=64, C1=0, Cout=32, ks=7, kw=1, tile_n=4000, zero_bias=True),
     # spatial-patch kernel for the collapsed up-convolution (tile_n = 3000)
     "patch_up_basic":    dict(B=2, H=16, W=16, C0=64, C1=0, Cout=64, ks=3, up=1, act=1, tile_n=3000),
     "patch_up_concat":   dict(B=1, H=32, W=16, C0=32, C1=64, Cout=128, ks=3, up=1, act=1, tile_n=3000),

@@ -19,6 +19,7 @@ LAYERS = [
     ("up0", 64, 64, 256, 0, 128, 3, 1, 1, 0, 0),
     ("up1", 128, 128, 128, 0, 64, 3, 1, 1, 0, 0),
     ("final7x1", 256, 256, 64, 0, 21, (7, 1), 0, 0, 0, 0),
+    ("final7x1n32", 256, 256, 64, 0, 32, (7, 1), 0, 0, 0, 0),
     ("hg_enc0", 64, 64, 64, 0, 128, 3, 0, 1, 1, 0),
     ("hg_enc1", 32, 32, 128, 0, 256, 3, 0, 1, 1, 0),
     ("hg_enc2", 16, 16, 256, 0, 512, 3, 0, 1, 1, 0),
@@ -53,7 +54,9 @@ def main():
         out = torch.empty(B, Ho >> pool, Wo >> pool, Cout, device=dev)
         flops = 2.0 * B * Ho * Wo * Cout * cin * ks * kw   # reference-algorithmic (un-collapsed) FLOPs
         for tile in TILES:
-            if tile > 1000 and (ks != 3 or kw != 3):
+            if tile == 4000 and not (ks == 7 and kw == 1 and Cout == 32):
+                continue
+            if 1000 < tile < 4000 and (ks != 3 or kw != 3):
                 continue
             if 2000 <= tile < 2200 and (up or pool or C1 or C0 % 64 or (tile >= 2100 and (H % 4 or W % 4))):
                 continue
