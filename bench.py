@@ -181,9 +181,9 @@ def main():
         frames = args.steps * B * world
         fps = frames / dt
         # dominant kernel: the bottleneck 3x3 256->256 convolution, 2*num_bottleneck_blocks launches per step.
-        # With >= 49152 pixels per launch it runs as wino_gemm_kernel (Winograd F(2x2,3x3): 16 GEMMs over the
-        # transformed input, 2.25x fewer MACs than the reference's direct convolution), else as the direct
-        # LDS-DMA conv_mfma_dma_kernel.  `achieved` is what the matrix pipe actually executes (bounded by the
+        # From 5 frames per call it runs as wino4_gemm_kernel (Winograd F(4x4,3x3): 36 GEMMs over the transformed
+        # input, 4x fewer MACs than the reference's direct convolution; F(2x2,3x3) / wino_gemm_kernel when a map side
+        # is not a multiple of 4), else as the direct LDS-DMA conv_mfma_dma_kernel (eamm_bottleneck_form).  `achieved` is what the matrix pipe actually executes (bounded by the
         # 157.3 TFLOP/s fp32 MFMA peak); `achieved_algorithmic` prices the same launches (+ their input
         # transforms) at the reference's direct-convolution FLOPs, so it can exceed the peak.
         hf = S >> cfg["num_down_blocks"]
