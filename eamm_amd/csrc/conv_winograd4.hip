@@ -147,6 +147,8 @@ struct Wino4Args {
     int act;
     const float* resid;    // NHWC [B,H,W,Cout]
     float* out;            // NHWC [B,H,W,Cout]
+    int groups;            // > 1: the six rows of transform points are split over `groups` workgroups per tile (small M)
+    float* zout;           // groups > 1: [24][Mq][Cout] x-folded products Z[i][q], finished by wino4_output_transform_kernel
 };
 
 __constant__ float WINO4_AT[4][8] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f},
@@ -180,10 +182,13 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
 
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int ntile = L % p.ntiles;
-    const int mtile = L / p.ntiles;
+    const int mtile = (L / p.ntiles) % p.mtiles;
+    const int grp = L / (p.ntiles * p.mtiles);          // which rows of transform points (0 when groups == 1)
+    const int rows_per = 6 / p.groups;
     const int mbase = mtile * BM;
-    const int cchunks = p.C / BK;             // channel chunks per transform point
-    const int nsuper = 36 * cchunks / SUB;    // barrier intervals
+    const int cchunks = p.C / BK;                         // channel chunks per transform point
+    const int ci_base = grp * rows_per * 6 * cchunks;     // first chunk of this workgroup's transform points
+    const int nsuper = rows_per * 6 * cchunks / SUB;      // barrier intervals
 
     unsigned arow_off[A_INSTR];
 #pragma unroll
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     auto dma_piece = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int sub = k / (A_INSTR + B_INSTR), r = k % (A_INSTR + B_INSTR);
-        const int ci = n_sc * SUB + sub;              // chunk index: xi * cchunks + cc
+        const int ci = ci_base + n_sc * SUB + sub;    // chunk index: xi * cchunks + cc
         const int xi = ci / cchunks, cc = ci - xi * cchunks;
         if constexpr (r < A_INSTR) {
             const unsigned off = arow_off[r] + (unsigned)xi * plane_bytes + (unsigned)(cc * BK * 4);
@@ -308,6 +313,24 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
         });
     };
 
+    // split form (few tiles): row i is complete in x -> its four Z[q] go to HBM, the y fold happens in
+    // wino4_output_transform_kernel over all six rows
+    auto store_z = [&](int i) {
+        static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            static_for<NT>([&](auto jc) {
+                constexpr int jj = decltype(jc)::value;
+                const int col = ntile * BN + wn * NT * 16 + jj * 16 + r16;
+                static_for<4>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const int row = mbase + wm * 16 + 4 * g + r;
+                    if (row < p.Mq && col < p.Cout) p.zout[((size_t)(i * 4 + q) * p.Mq + row) * p.Cout + col] = Z[q][jj][r];
+                    Z[q][jj][r] = 0.f;
+                });
+            });
+        });
+    };
+
     // ---- main loop: ring of NST stages, DMA runs D = NST-1 intervals ahead of the MFMAs
     constexpr int D = NST - 1;
     const int per_xi = cchunks / SUB;  // barrier intervals per transform point
@@ -323,7 +346,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     }
     __syncthreads();
     int st = 0, st_next = D % NST;
-    int xi_left = per_xi, xj = 0, xrow = 0;
+    int xi_left = per_xi, xj = 0, xrow = grp * rows_per;
     for (int sc = 0; sc < nsuper; ++sc) {
         const bool more = sc + D < nsuper;
         n_sc = sc + D;
@@ -337,7 +360,10 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
             fold_x(xj);
             if (++xj == 6) {
                 xj = 0;
-                fold_y(xrow++);
+                if (p.zout != nullptr)
+                    store_z(xrow++);
+                else
+                    fold_y(xrow++);
             }
         }
         if constexpr (TRACE) ts2 = __builtin_readcyclecounter();
@@ -358,6 +384,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
         st_next = st_next + 1 == NST ? 0 : st_next + 1;
     }
 
+    if (p.zout != nullptr) return;
     // ---- epilogue: one output row py (four pixels) per round, staged through LDS, 16-byte row accesses.
     // A thread keeps the same (channel group, px) and walks BM / PER tiles; their output offsets are decoded once
     // (py only adds a row stride) and out-of-range tiles / channels get an offset the buffer descriptor rejects,
@@ -414,6 +441,45 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rso, e_off[k], soff, 0);
         }
     });
+}
+
+// y fold of the split form: Y[p][q] = sum_i A^T[p][i] Z[i][q] (+ bias, residual, activation) -> the 4x4 output pixels
+__global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Z, const float* __restrict__ bias,
+                                                                     const float* __restrict__ resid, int Mq, int Cout, int H,
+                                                                     int W, int act, float* __restrict__ out) {
+    const int c4n = Cout >> 2;
+    const int Hq = H >> 2, Wq = W >> 2;
+    const size_t total = (size_t)Mq * c4n;
+    const size_t plane = (size_t)Mq * c4n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const int m = (int)(idx / c4n);
+        const int qx = m % Wq, tq = m / Wq;
+        const int qy = tq % Hq, b = tq / Hq;
+        const f32x4_t* z = reinterpret_cast<const f32x4_t*>(Z) + idx;
+        const f32x4_t bs = reinterpret_cast<const f32x4_t*>(bias)[c4];
+        const float lo = act == ACT_RELU ? 0.f : -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4_t zi[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) zi[i] = z[(size_t)(i * 4 + q) * plane];
+            const f32x4_t s12 = zi[1] + zi[2], d12 = zi[1] - zi[2], s34 = zi[3] + zi[4], d34 = zi[3] - zi[4];
+            f32x4_t y[4];
+            y[0] = zi[0] + s12 + s34;
+            y[1] = d12 + 2.f * d34;
+            y[2] = s12 + 4.f * s34;
+            y[3] = d12 + 8.f * d34 + zi[5];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const size_t o = (((size_t)(b * H + 4 * qy + pp) * W + 4 * qx + q) * Cout) / 4 + c4;
+                f32x4_t v = y[pp] + bs;
+                if (resid != nullptr) v = v + reinterpret_cast<const f32x4_t*>(resid)[o];
+                v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
+                reinterpret_cast<f32x4_t*>(out)[o] = v;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -482,12 +548,12 @@ static hipError_t wino4_launch_variant(const Wino4Args& a, hipStream_t stream) {
     auto kern = wino4_gemm_kernel<NT, WM, WN, SUB, NST, PE, DBG>;
     static unsigned long long configured = 0;  // per-device bit mask
     if (hipError_t e = ensure_dynamic_lds(kern, lds, &configured); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles), dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles * a.groups), dim3(WM * WN * 64), lds, stream, a);
     return hipGetLastError();
 }
 
 hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, int W, int act, const float* resid,
-                             float* out, hipStream_t stream, int variant) {
+                             float* out, hipStream_t stream, int variant, int groups, float* zbuf) {
     constexpr int BM = 64, BN = 64;
     if (L.tile != 4 || L.BN != BN || (L.Cout & 3) || L.Cin % (2 * CONV_BK) || (H & 3) || (W & 3))
         return hipErrorInvalidValue;
@@ -505,23 +571,34 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     a.act = act;
     a.resid = resid;
     a.out = out;
+    if (groups != 1 && groups != 2 && groups != 3 && groups != 6) return hipErrorInvalidValue;
+    if (groups > 1 && zbuf == nullptr) return hipErrorInvalidValue;
+    a.groups = groups;
+    a.zout = groups > 1 ? zbuf : nullptr;
     const size_t vb = (size_t)36 * a.Mq * a.C * sizeof(float), ub = wino4_packed_elems(L.Cout, L.Cin, BN) * sizeof(float);
     if (vb >= 0xFFFFFFF0ull || ub >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
     a.v_bytes = (unsigned)vb;
     a.u_bytes = (unsigned)ub;
     const bool sub4 = L.Cin % (4 * CONV_BK) == 0;
+    hipError_t e = hipErrorInvalidValue;
     switch (variant) {   // (chunks per barrier, ring depth, MFMAs per DMA piece)
-        case 0: return sub4 ? wino4_launch_variant<4, 2, 4>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream);
-        case 1: return wino4_launch_variant<2, 2, 4>(a, stream);
-        case 2: return wino4_launch_variant<2, 3, 4>(a, stream);
-        case 3: return sub4 ? wino4_launch_variant<4, 2, 8>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream);
-        case 4: return wino4_launch_variant<2, 4, 4>(a, stream);
-        case 10: return wino4_launch_variant<4, 2, 4, 1>(a, stream);
-        case 5: return sub4 ? wino4_launch_variant<4, 2, 4, 20>(a, stream) : wino4_launch_variant<2, 2, 4, 20>(a, stream);
-        case 16: return wino4_launch_variant<4, 2, 4, 8>(a, stream);
-        case 17: return wino4_launch_variant<4, 2, 4, 9>(a, stream);
-        default: return hipErrorInvalidValue;
+        case 0: e = sub4 ? wino4_launch_variant<4, 2, 4>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream); break;
+        case 1: e = wino4_launch_variant<2, 2, 4>(a, stream); break;
+        case 2: e = wino4_launch_variant<2, 3, 4>(a, stream); break;
+        case 3: e = sub4 ? wino4_launch_variant<4, 2, 8>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream); break;
+        case 4: e = wino4_launch_variant<2, 4, 4>(a, stream); break;
+        case 5: e = sub4 ? wino4_launch_variant<4, 2, 4, 20>(a, stream) : wino4_launch_variant<2, 2, 4, 20>(a, stream); break;
+        case 10: e = wino4_launch_variant<4, 2, 4, 1>(a, stream); break;
+        case 16: e = wino4_launch_variant<4, 2, 4, 8>(a, stream); break;
+        case 17: e = wino4_launch_variant<4, 2, 4, 9>(a, stream); break;
+        default: break;
     }
+    if (e != hipSuccess || groups == 1) return e;
+    const size_t total = (size_t)a.Mq * (L.Cout / 4);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)1 << 20);
+    hipLaunchKernelGGL(wino4_output_transform_kernel, dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid, a.Mq, L.Cout, H,
+                       W, act, out);
+    return hipGetLastError();
 }
 
 }  // namespace eamm

@@ -32,8 +32,9 @@ struct eamm_ctx : eamm::CtxBase {
     int wino_tile = 4;                     // preferred output tile (EAMM_WINO_TILE): 4 -> F(4x4) where it applies, 2 -> F(2x2)
     int wino4_variant = 0;                 // wino4_gemm_kernel pipeline variant
     float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] (F(2x2)) or [36][F*hf*wf/16][Cb] transformed activations
+    float* wino_z = nullptr;               // [24][F*hf*wf/16][Cb] x-folded products of the split F(4x4) form (few tiles)
     int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd F(2x2) form
-    int wino4_min_m = 20480;               // ... in F(4x4) form: 80 of 256 CUs busy still beats the direct kernel (measured: 5 frames at 256^2)
+    int wino4_min_m = 0;                   // ... in F(4x4) form: with the transform-point rows split over workgroups it wins from one frame up
     int wino_variant = 0;                  // wino_gemm_kernel pipeline variant (see wino_gemm_launch); in-pipeline all are within noise
     std::vector<float*> pre_s, pre_t;  // res-block pre-activation scale/shift (norm1)
     float* aa_w = nullptr;
@@ -335,6 +336,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
     if ((rc = dev_alloc(c, &c->tmp, F * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->final_part, F * HW * 32))) return rc;
     if (!c->wres1.empty() && (rc = dev_alloc(c, &c->wino_v, 4 * F * hwf * c->Cb))) return rc;
+    if (!c->w4res1.empty() && (rc = dev_alloc(c, &c->wino_z, 24 * ((F * hwf + 15) / 16) * c->Cb))) return rc;
     c->up_buf.resize(c->nd);
     for (int i = 0; i < c->nd; ++i)
         if ((rc = dev_alloc(c, &c->up_buf[i], F * (hwf << (2 * (i + 1))) * c->up_c[i]))) return rc;
@@ -549,17 +551,31 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         if (sub) HIP_TRY(c, hipEventRecord(sub[nsub++], s));     \
     } while (0)
     const bool wino4 = form == 4;
+    // F(4x4) with few tiles: split the six rows of transform points over 2, 3 or 6 workgroups per (tile, cout) block --
+    // the largest split that still fits one round of the chip (64 x 64 blocks, one per CU)
+    int w4g = 1;
+    if (wino4) {
+        const int nb = ((n * (hf / 4) * (wf / 4) + 63) / 64) * ((c->Cb + 63) / 64);
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+        for (int gsel : {6, 3, 2})
+            if (nb * gsel <= cus) {
+                w4g = gsel;
+                break;
+            }
+        w4g = env_int("EAMM_WINO4_GROUPS", w4g);
+    }
     for (int i = 0; i < nr && wino; ++i) {
         // conv1(relu(norm1(x))): the pre-activation rides on the input transform; norm2 + relu in the epilogue
         SUB_MARK();
         if (wino4) {
             HIP_TRY(c, wino4_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, c->wino_v, s));
             SUB_MARK();
-            HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], c->wino_v, n, hf, wf, ACT_RELU, nullptr, c->tmp, s, c->wino4_variant));
+            HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], c->wino_v, n, hf, wf, ACT_RELU, nullptr, c->tmp, s, c->wino4_variant, w4g, c->wino_z));
             SUB_MARK();
             HIP_TRY(c, wino4_transform_launch(c->tmp, nullptr, nullptr, n, hf, wf, c->Cb, c->wino_v, s));
             SUB_MARK();
-            HIP_TRY(c, wino4_gemm_launch(c->w4res2[i], c->wino_v, n, hf, wf, ACT_NONE, x, xn, s, c->wino4_variant));   // out += x
+            HIP_TRY(c, wino4_gemm_launch(c->w4res2[i], c->wino_v, n, hf, wf, ACT_NONE, x, xn, s, c->wino4_variant, w4g, c->wino_z));   // out += x
         } else {
             HIP_TRY(c, wino_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, c->wino_v, s));
             SUB_MARK();
@@ -841,8 +857,10 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         if (P.bias) (void)hipFree(P.bias);
         return rc;
     }
-    if (tile_n >= 2000 && tile_n < 2200) {  // Winograd: input transform + GEMM; 2000 + variant F(2x2,3x3), 2100 + variant F(4x4,3x3)
+    if (tile_n >= 2000 && tile_n < 2200) {  // Winograd: input transform + GEMM; 2000 + variant F(2x2,3x3), 2100 + variant F(4x4,3x3),
+        // 2150 + groups (2, 3, 6): F(4x4,3x3) with the transform-point rows split over workgroups + output-transform kernel
         const bool w4 = tile_n >= 2100;
+        const int w4_groups = tile_n >= 2150 ? tile_n - 2150 : 1;
         if (kh != 3 || kw != 3 || up || pool || C1 || splitk > 1 || C0 % 64 || (Cout & 3) ||
             (w4 && ((Hin & 3) || (Win & 3))))
             return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported Winograd configuration");
@@ -859,7 +877,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         else
             wino_pack_host(w_host, Cout, C0, W.BN, packed.data());
         std::copy(b_host, b_host + Cout, bias.begin());
-        float* V = nullptr;
+        float *V = nullptr, *Zb = nullptr;
         int rc = EAMM_OK;
         auto done = [&](hipError_t e, const char* what) {
             if (e != hipSuccess) rc = fail(nullptr, EAMM_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
@@ -869,6 +887,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         if (!done(hipMalloc((void**)&W.u, packed.size() * sizeof(float)), "hipMalloc") &&
             !done(hipMalloc((void**)&W.bias, bias.size() * sizeof(float)), "hipMalloc") &&
             !done(hipMalloc((void**)&V, vel * sizeof(float)), "hipMalloc") &&
+            !done(hipMalloc((void**)&Zb, (size_t)24 * B * ((Hin + 3) / 4) * ((Win + 3) / 4) * Cout * sizeof(float) + 16), "hipMalloc") &&
             !done(hipMemcpy(W.u, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
             !done(hipMemcpy(W.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")) {
             // timing-mode knob: EAMM_OP_WINO_PART = 1 times the input transform alone, 2 the GEMM alone
@@ -880,7 +899,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
                 if (w4) {
                     if (tr) e = wino4_transform_launch(in0, nullptr, nullptr, B, Hin, Win, C0, V, s);
                     if (e != hipSuccess || !gm) return e;
-                    return wino4_gemm_launch(W, V, B, Hin, Win, act, resid, out, s, tile_n - 2100);
+                    return wino4_gemm_launch(W, V, B, Hin, Win, act, resid, out, s, w4_groups > 1 ? 0 : tile_n - 2100, w4_groups, Zb);
                 }
                 if (tr) e = wino_transform_launch(in0, nullptr, nullptr, B, Hin, Win, C0, V, s);
                 if (e != hipSuccess || !gm) return e;
@@ -906,6 +925,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         if (W.u) (void)hipFree(W.u);
         if (W.bias) (void)hipFree(W.bias);
         if (V) (void)hipFree(V);
+        if (Zb) (void)hipFree(Zb);
         return rc;
     }
     ConvLayer L;
