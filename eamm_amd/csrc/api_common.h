@@ -109,7 +109,7 @@ enum LayerMode { MODE_PLAIN = 0, MODE_PHASE = 1, MODE_ROWSPLIT = 2 };
 // returned in *row_bias instead of being applied by the convolution.
 int build_layer(CtxBase* c, const std::vector<FoldSpec>& parts, int ks, int C0_real, int C0_packed, int C1_real,
                 int C1_packed, ConvLayer* L, LayerMode mode = MODE_PLAIN, std::vector<float>* row_bias = nullptr,
-                int dma_cfg = 0, float** w_swizzled = nullptr) {
+                int dma_cfg = 0, float** w_swizzled = nullptr, int w_swizzled_bn = 0) {
     // `parts` are stacked along Cout (the flow head stacks mask + occlusion into one convolution)
     const int Cin = C0_real + C1_real;
     const int T = ks * ks;
@@ -192,8 +192,9 @@ int build_layer(CtxBase* c, const std::vector<FoldSpec>& parts, int ks, int C0_r
     int rc = upload(c, &L->w, packed);
     if (rc) return rc;
     if (w_swizzled) {   // second image of the same weights in the LDS-DMA (XOR-swizzled) layout
-        std::vector<float> ps(packed.size());
-        conv_pack_host(wf.data(), Cout, Cin, kh, kw, map.data(), cin_packed, L->BN, L->phase, true, ps.data());
+        const int sbn = w_swizzled_bn ? w_swizzled_bn : L->BN;   // N tile of the swizzled image (the consumer kernel's)
+        std::vector<float> ps(conv_packed_elems(taps, cin_packed, Cout, sbn, L->phase ? 4 : 1));
+        conv_pack_host(wf.data(), Cout, Cin, kh, kw, map.data(), cin_packed, sbn, L->phase, true, ps.data());
         if ((rc = upload(c, w_swizzled, ps))) return rc;
     }
     return upload(c, &L->bias, bias_pad);

@@ -147,6 +147,162 @@ __global__ __launch_bounds__(CWAVES * 64) void conv_col7_kernel(const Col7Args p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Same tile geometry for the row-split flow head (7x1 over N = 7 x (K+2) = 84 of 96, two concatenated inputs, 128 input
+// channels): the weights ([4][7][96][32] = 336 KiB) do not fit, so they stream one (chunk, tap) tile per barrier interval
+// (NT x 4 KiB, double buffered) next to the two patch stages; one workgroup per 16x16 tile.
+struct Col7sArgs {
+    const float* in0;      // [B,H,W,C0]
+    const float* in1;      // [B,H,W,C1] or null
+    unsigned in0_bytes, in1_bytes, w_bytes;
+    int C0, C1, B, H, W;
+    int tiles_x, tiles_y;
+    const float* w;        // packed [(C0+C1)/32][7][NT*32][32], LDS-DMA swizzle
+    float* out;            // [B,H,W,PS]
+    int PS;                // pixel stride of `out` in floats (>= NT*32)
+};
+
+template <int NT>
+__global__ __launch_bounds__(CWAVES * 64) void conv_col7s_kernel(const Col7sArgs p) {
+    constexpr int BK = CONV_BK;
+    constexpr int A_STAGE = CPIX * BK;             // floats (44 KiB)
+    constexpr int W_STAGE = NT * 32 * BK;          // one (chunk, tap) weight tile
+    constexpr int A_PIECES = CPIX / 8;             // 44
+    constexpr int W_PIECES = NT * 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][A_STAGE] patches, [2][W_STAGE] weights
+    float* const As = smem;
+    float* const Ws = smem + 2 * A_STAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int cchunks = (p.C0 + p.C1) / BK;
+    const int nint = cchunks * 7;
+
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx0 = (t % p.tiles_x) * CT;
+    t /= p.tiles_x;
+    const int ty0 = (t % p.tiles_y) * CT;
+    const int b = t / p.tiles_y;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in0, 0, p.in0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.in1 ? p.in1 : p.in0), 0, p.in1 ? p.in1_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    auto dma_patch_piece = [&](int j, int cc, int st) {
+        const int q = j * 8 + (lane >> 3);
+        const int y = ty0 + (q >> 4) - 3, x = tx0 + (q & 15);
+        const bool ok = ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W);
+        const int slot = ((lane & 7) ^ ((q >> 1) & 7)) << 2;
+        const int c0 = cc * BK;
+        const bool first = c0 < p.C0;
+        const int C = first ? p.C0 : p.C1;
+        const int coff = first ? c0 : c0 - p.C0;
+        const unsigned off = ok ? (unsigned)(((b * p.H + y) * p.W + x) * C + coff + slot) * 4u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (lds_ptr_t)(As + st * A_STAGE + j * (8 * BK)), 16, off, 0, 0, 0);
+    };
+    auto dma_weight_piece = [&](int j, int it, int st) {   // piece j (0..W_PIECES-1) of interval it
+        const unsigned off = (unsigned)((it * NT * 32 + j * 8) * BK + lane * 4) * 4u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(Ws + st * W_STAGE + j * (8 * BK)), 16, off, 0, 0, 0);
+    };
+
+    for (int j = wave; j < A_PIECES; j += CWAVES) dma_patch_piece(j, 0, 0);
+    for (int j = wave; j < W_PIECES; j += CWAVES) dma_weight_piece(j, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc[NT];
+    static_for<NT>([&](auto jc) { static_for<16>([&](auto rc) { acc[decltype(jc)::value][decltype(rc)::value] = 0.f; }); });
+
+    const int trow = 2 * wave + (l31 >> 4), tcol = l31 & 15;
+    const int idx0 = trow * CT + tcol;
+    const int a_off = idx0 * BK + ((half ^ ((idx0 >> 1) & 7)) << 2);
+    const int b_off = l31 * BK + ((half ^ ((l31 >> 1) & 7)) << 2);
+
+    int cc = 0, tap = 0;
+    for (int it = 0; it < nint; ++it) {
+        const bool more_w = it + 1 < nint, more_a = cc + 1 < cchunks;
+        const float* a_stage = As + (cc & 1) * A_STAGE + tap * (CT * BK);
+        const float* w_stage = Ws + (it & 1) * W_STAGE;
+        f32x4 a[2], bb[2][NT];
+        auto fetch = [&](auto sc_, int buf) {
+            constexpr int s = decltype(sc_)::value;
+            a[buf] = *reinterpret_cast<const f32x4*>(a_stage + (a_off ^ (8 * s)));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bb[buf][j] = *reinterpret_cast<const f32x4*>(w_stage + (b_off ^ (8 * s)) + j * 32 * BK);
+        };
+        fetch(std::integral_constant<int, 0>{}, 0);
+        static_for<4>([&](auto stc) {
+            constexpr int step = decltype(stc)::value;
+            if constexpr (step + 1 < 4) fetch(std::integral_constant<int, step + 1>{}, (step + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<4 * NT>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int tq = q / NT, j = q % NT;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step & 1][tq], bb[step & 1][j][tq], acc[j], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (step == 0) {          // next interval's weights: pieces wave, wave + 8, ...
+                if (more_w)
+                    for (int j = wave; j < W_PIECES; j += CWAVES) dma_weight_piece(j, it + 1, (it + 1) & 1);
+            } else if constexpr (step == 1) {   // next chunk's patch: piece tap*8 + wave (44 pieces over the 7 taps)
+                const int j = tap * CWAVES + wave;
+                if (more_a && j < A_PIECES) dma_patch_piece(j, cc + 1, (cc + 1) & 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (++tap == 7) {
+            tap = 0;
+            ++cc;
+        }
+    }
+    static_for<NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        static_for<16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int y = ty0 + 2 * wave + (m >> 4), x = tx0 + (m & 15);
+            if (y < p.H && x < p.W) p.out[((size_t)(b * p.H + y) * p.W + x) * p.PS + j * 32 + l31] = acc[j][r];
+        });
+    });
+}
+
+hipError_t conv_col7s_launch(const float* in0, int C0, const float* in1, int C1, int B, int H, int W, const float* w_swizzled,
+                             int ntile32, float* out, int pixel_stride, hipStream_t stream) {
+    if (C0 % CONV_BK || C1 % CONV_BK || C0 < CONV_BK || ntile32 != 3 || pixel_stride < ntile32 * 32)
+        return hipErrorInvalidValue;
+    Col7sArgs a{};
+    a.in0 = in0;
+    a.in1 = C1 ? in1 : nullptr;
+    const size_t px = (size_t)B * H * W;
+    const size_t b0 = px * C0 * 4, b1 = px * C1 * 4, wb = (size_t)((C0 + C1) / CONV_BK) * 7 * ntile32 * 32 * CONV_BK * 4;
+    if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    a.in0_bytes = (unsigned)b0;
+    a.in1_bytes = (unsigned)b1;
+    a.w_bytes = (unsigned)wb;
+    a.C0 = C0;
+    a.C1 = C1;
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.tiles_x = (W + CT - 1) / CT;
+    a.tiles_y = (H + CT - 1) / CT;
+    a.w = w_swizzled;
+    a.out = out;
+    a.PS = pixel_stride;
+    constexpr size_t lds = sizeof(float) * (2 * CPIX * CONV_BK + 2 * 3 * 32 * CONV_BK);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static unsigned long long configured = 0;
+    if (hipError_t e = ensure_dynamic_lds(conv_col7s_kernel<3>, lds, &configured); e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_col7s_kernel<3>, dim3(a.tiles_x * a.tiles_y * B), dim3(CWAVES * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t conv_col7_launch(const float* in, int C, int B, int H, int W, const float* w_swizzled, float* out,
                             hipStream_t stream) {
     if (C % CONV_BK || C / CONV_BK > CMAXCH || C < CONV_BK) return hipErrorInvalidValue;

@@ -40,6 +40,7 @@ struct eamm_ctx : eamm::CtxBase {
     float* aa_w = nullptr;
     float* head_bias = nullptr;    // mask / occlusion biases when the head runs row-split (applied by the head kernel)
     int head_nc = 0;               // > 0: head is a 7x1 convolution over (dx, co), co < head_nc
+    float* head_w_swz = nullptr;   // its weights with a 96-wide N tile in LDS-DMA layout (conv_col7s_kernel), or null
     float* final_bias = nullptr;   // bias of the final conv, applied by the shift-sum kernel
     float* final_part = nullptr;   // [F,H,W,32] (dx,co) partial products of the final 7x7 conv
     float* final_w_swz = nullptr;  // the 7x1 weights in LDS-DMA layout for the column-patch kernel (conv_col7.hip)
@@ -229,7 +230,9 @@ int eamm_finalize_weights(eamm_ctx* c) {
             // 7x1 MFMA convolution with N = (dx, co) + horizontal gather in the head kernel: pads N to 7*nc (84) of
             // 128 instead of nc (12) of 32 -> 2.3x fewer executed MACs
             std::vector<float> hb;
-            if ((rc = build_layer(c, parts, 7, c->dec_c.back(), c->dec_c.back(), cin0, c->Cp0, &c->head, MODE_ROWSPLIT, &hb)))
+            const bool col7s_ok = c->col7 && 7 * nc <= 96 && c->dec_c.back() % 32 == 0 && c->Cp0 % 32 == 0;
+            if ((rc = build_layer(c, parts, 7, c->dec_c.back(), c->dec_c.back(), cin0, c->Cp0, &c->head, MODE_ROWSPLIT, &hb, 0,
+                                  col7s_ok ? &c->head_w_swz : nullptr, 96)))
                 return rc;
             if ((rc = upload(c, &c->head_bias, hb))) return rc;
             c->head_nc = nc;
@@ -518,7 +521,10 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         float* defo = c->deformation;
         if (c->head_nc) {
             head.Cout = 128;  // partial products written with a 128-float pixel stride (7*nc used)
-            HIP_TRY(c, conv_launch(head, io, s));
+            if (c->head_w_swz)
+                HIP_TRY(c, conv_col7s_launch(io.in0, head.C0, io.in1, head.C1, n, h, w, c->head_w_swz, 3, c->logits, 128, s));
+            else
+                HIP_TRY(c, conv_launch(head, io, s));
             HIP_TRY(c, motion_head_rowsplit_launch(c->logits, 128, c->head_nc, c->head_bias, c->kp_rec, n, K, h, w,
                                                    occ ? 1 : 0, defo, c->occlusion, o->mask, o->occlusion_map, s));
         } else {
@@ -770,11 +776,15 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: bad argument");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
-    if (tile_n == 4000) {  // column-patch kernel of the final layer's 7x1 convolution: Cout must be the 32-float pixel stride
-        if (kh != 7 || kw != 1 || up || pool || resid || splitk > 1 || C1 || Cout != 32 || act != 0 || C0 % 32 || C0 > 64)
+    if (tile_n == 4000 || tile_n == 4001) {  // column-patch kernels of the 7x1 convolutions: 4000 final layer (Cout = the 32-float
+        // pixel stride, weights resident), 4001 flow head (two inputs, Cout = 96, streamed weights); no bias (the gather kernels add it)
+        const bool streamed = tile_n == 4001;
+        const int bn = streamed ? 96 : 32;
+        if (kh != 7 || kw != 1 || up || pool || resid || splitk > 1 || Cout != bn || act != 0 || C0 % 32 || C1 % 32 ||
+            (!streamed && (C1 || C0 > 64)))
             return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported column-patch configuration");
-        std::vector<float> packed(conv_packed_elems(7, C0, 32, 32, 1));
-        conv_pack_host(w_host, 32, C0, 7, 1, nullptr, C0, 32, false, true, packed.data());
+        std::vector<float> packed(conv_packed_elems(7, C0 + C1, bn, bn, 1));
+        conv_pack_host(w_host, bn, C0 + C1, 7, 1, nullptr, C0 + C1, bn, false, true, packed.data());
         float* wd = nullptr;
         int rc = EAMM_OK;
         auto bad = [&](hipError_t e, const char* what) {
@@ -783,7 +793,10 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         };
         if (!bad(hipMalloc((void**)&wd, packed.size() * sizeof(float)), "hipMalloc") &&
             !bad(hipMemcpy(wd, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")) {
-            auto run = [&]() { return conv_col7_launch(in0, C0, B, Hin, Win, wd, out, s); };
+            auto run = [&]() {
+                return streamed ? conv_col7s_launch(in0, C0, in1, C1, B, Hin, Win, wd, 3, out, 96, s)
+                                : conv_col7_launch(in0, C0, B, Hin, Win, wd, out, s);
+            };
             if (!bad(run(), "col7 launch") && iters > 0 && avg_ms) {
                 hipEvent_t e0, e1;
                 (void)hipEventCreate(&e0);

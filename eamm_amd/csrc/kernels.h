@@ -104,6 +104,11 @@ hipError_t patch_phase_launch(const PatchLayer& L, const float* in0, const float
 hipError_t conv_col7_launch(const float* in, int C, int B, int H, int W, const float* w_swizzled, float* out,
                             hipStream_t stream);
 
+// streamed-weight variant for the row-split flow head: two concatenated inputs, N = ntile32*32 (3 -> 96), weights packed with
+// conv_pack_host(..., kh 7, kw 1, BN 96, swizzle); out [B,H,W,pixel_stride]
+hipError_t conv_col7s_launch(const float* in0, int C0, const float* in1, int C1, int B, int H, int W, const float* w_swizzled,
+                             int ntile32, float* out, int pixel_stride, hipStream_t stream);
+
 // ---- Winograd paths for the bottleneck convolutions: F(2x2,3x3) (conv_winograd.hip), F(4x4,3x3) (conv_winograd4.hip)
 struct WinoLayer {
     int Cin = 0, Cout = 0, BN = 128, ntiles = 0;

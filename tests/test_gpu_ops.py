@@ -98,6 +98,9 @@ CASES = {
     "col7_final_like":   dict(B=2, H=32, W=32, C0=64, C1=0, Cout=32, ks=7, kw=1, tile_n=4000, zero_bias=True),
     "col7_one_chunk":    dict(B=1, H=16, W=48, C0=32, C1=0, Cout=32, ks=7, kw=1, tile_n=4000, zero_bias=True),
     "col7_ragged":       dict(B=3, H=20, W=24, C0=64, C1=0, Cout=32, ks=7, kw=1, tile_n=4000, zero_bias=True),
+    "col7s_head_like":   dict(B=2, H=32, W=32, C0=64, C1=64, Cout=96, ks=7, kw=1, tile_n=4001, zero_bias=True),
+    "col7s_ragged":      dict(B=3, H=20, W=24, C0=32, C1=32, Cout=96, ks=7, kw=1, tile_n=4001, zero_bias=True),
+    "col7s_one_input":   dict(B=1, H=16, W=16, C0=96, C1=0, Cout=96, ks=7, kw=1, tile_n=4001, zero_bias=True),
     "col7_many_tiles":   dict(B=5, H=128, W=128, C0=64, C1=0, Cout=32, ks=7, kw=1, tile_n=4000, zero_bias=True),
     # spatial-patch kernel for the collapsed up-convolution (tile_n = 3000)
     "patch_up_basic":    dict(B=2, H=16, W=16, C0=64, C1=0, Cout=64, ks=3, up=1, act=1, tile_n=3000),
