@@ -10,21 +10,30 @@ already encoded (the frame-invariant encoder runs once per clip; with N > 1 rank
 cached source tensors are broadcast once over RCCL/xGMI before the timed region).  Inputs (key
 points) are resident in HBM before the timed region; outputs stay on the device.  Frames of a clip
 are independent, so the path shards by frames with no data-path collective: weak scaling, value =
-all ranks' frames / max-over-ranks time.
+all ranks' frames / max-over-ranks time.   `--size 512 --batch 8` is BASELINE.json configs[4].
 
 Prints ONE JSON line with the contract keys plus
   roofline     -- the dominant kernel (the 3x3 256->256 bottleneck convolution: 12 launches per step, 67 % of
                   the reference FLOPs), FLOPs / its average launch duration measured with HIP events on the
                   launch stream inside the timed steps (executed-MFMA and reference-algorithmic figures);
+                  `traffic` comes from profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes written
+                  by tools/pmc_traffic.py) and only when that record was taken at this (size, batch) on the kernel
+                  source that is being run now -- otherwise null;
   cpu_baseline -- the CPU oracle (PyTorch-CPU restatement of the reference, reference loop structure:
                   one frame per call, source encoder re-run every frame) timed on this box's host
-                  cores on a bounded sample of the same workload.
+                  cores on a bounded sample of the same workload, median of >= 5 passes;
+  clip         -- BASELINE.json configs[3]: a `--clip-frames` (2048) frame clip through eamm_amd.animate_clip,
+                  frames sharded contiguously over the ranks, timed from the un-encoded source on rank 0 to the
+                  last frame on every rank: encode + RCCL broadcast of the source cache and key points + compute
+                  (+ gather of uint8 frames to rank 0 with --clip-gather); frames/s = frames / max-over-ranks time.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,20 +43,40 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from eamm_amd import OcclusionAwareGenerator, hot_path_config  # noqa: E402
+from eamm_amd import EngineBackend, OcclusionAwareGenerator, animate_clip, hot_path_config, shard_bounds  # noqa: E402
 from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
 HBM_PEAK_GBS = 8000.0
-# FETCH_SIZE (KB) * 2 + WRITE_SIZE (KB) of the dominant kernel, profiles/r01_rocprofv3_pmc_{fetch,write}_*.txt
-TRAFFIC_WINO = int((180579.8 * 2 + 65536.0) * 1024)     # wino_gemm_kernel: V is read by both N tiles (algorithmic 339-406 MB)
-TRAFFIC_DIRECT = int((75139.8 * 2 + 65536.0) * 1024)    # conv_mfma_dma_kernel 256x256 (algorithmic 204 MB)
-TRAFFIC_WINO4 = int((143463.7 * 2 + 65536.0) * 1024)     # wino4_gemm_kernel (algorithmic V 151 MB + U 9.4 MB per XCD + 67 MB out)
-TRAFFIC_SRC = "profiles/r01_rocprofv3_pmc_{fetch,write}_bottleneck_{winograd4,winograd,conv_256x256tile}.txt"
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+KERNEL_SOURCES = {4: "conv_winograd4.hip", 2: "conv_winograd.hip", 0: "conv_mfma_dma.hip"}   # by bottleneck form
 
 
-def cpu_baseline(cfg, sd, size, frames):
-    """Reference-equivalent CPU loop (demo.py:251-281) on the oracle: B=1, encoder per frame."""
+def kernel_source_digest(form):
+    path = os.path.join(ROOT, "eamm_amd", "csrc", KERNEL_SOURCES[form])
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def measured_traffic(form, size, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 per the
+    gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE) -- (bytes, source) or (None, reason).  A record counts only for
+    the (size, batch) it was taken at and while the kernel's source file is byte-identical to the profiled one."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None, f"{os.path.relpath(TRAFFIC_FILE, ROOT)} missing"
+    rec = table.get(f"form{form}_{size}x{size}_b{batch}")
+    if rec is None:
+        return None, f"no PMC record for form {form} at {size}x{size} batch {batch}"
+    if rec.get("source_sha256_16") != kernel_source_digest(form):
+        return None, f"PMC record of {rec.get('files')} predates the current {KERNEL_SOURCES[form]}"
+    return int((rec["fetch_size_kb"] * 2 + rec["write_size_kb"]) * 1024), rec.get("files")
+
+
+def cpu_baseline(cfg, sd, size, frames, passes=5):
+    """Reference-equivalent CPU loop (demo.py:251-281) on the oracle: B=1, encoder per frame; median of `passes`."""
     from oracle import eamm_oracle as orc  # checker / baseline only; never on the product path
     src = synthetic_source(size, seed=1)
     kp_s = synthetic_keypoints(1, cfg["num_kp"], seed=0)
@@ -69,16 +98,22 @@ def cpu_baseline(cfg, sd, size, frames):
             if t > 5.0:   # already pathological; larger counts only get worse
                 break
     torch.set_num_threads(best)
-    frames = max(4, min(frames, int(20.0 / max(best_t, 1e-3))))   # bound the sample to ~20 s
+    # `passes` passes over the same frames, the whole sample bounded to ~20 s of CPU work
+    per_pass = max(2, min(frames, int(20.0 / passes / max(best_t, 1e-3))))
+    rates = []
+    t_all = time.perf_counter()
     with torch.no_grad():
-        t0 = time.perf_counter()
-        for t in range(1, frames + 1):
-            out = orc.generator_forward(sd, cfg, src, {k: v[t:t + 1] for k, v in kp_d.items()}, kp_s)
-            out["prediction"].numpy()
-        dt = time.perf_counter() - t0
-    return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{frames} frames 256x256, one generator call per frame incl. source encoder "
-                      f"(reference loop demo.py:251-281), PyTorch-CPU fp32 oracle, best of 8..128 threads on "
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            for t in range(1, per_pass + 1):
+                out = orc.generator_forward(sd, cfg, src, {k: v[t:t + 1] for k, v in kp_d.items()}, kp_s)
+                out["prediction"].numpy()
+            rates.append(per_pass / (time.perf_counter() - t0))
+    dt = time.perf_counter() - t_all
+    return {"value": round(statistics.median(rates), 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "passes": [round(r, 3) for r in rates],
+            "sample": f"median of {passes} passes x {per_pass} frames {size}x{size}, one generator call per frame incl. source "
+                      f"encoder (reference loop demo.py:251-281), PyTorch-CPU fp32 oracle, best of 8..128 threads on "
                       f"{ncpu} logical CPUs, {dt:.1f} s"}
 
 
@@ -87,10 +122,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="frames per step per GPU (default 16; 8 at --size 512)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--clip-frames", type=int, default=2048, help="frames of the configs[3] clip leg (0 = skip)")
+    ap.add_argument("--clip-gather", action="store_true", help="clip leg: gather uint8 frames on rank 0 inside the timed region")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 16 if args.size <= 256 else 8
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,6 +163,8 @@ def main():
             t.copy_(h)
 
     def max_over_ranks(x):
+        if not use_dist:
+            return x
         t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -174,8 +215,45 @@ def main():
     prof = eng.profile_read(reset=True)
     eng.profile(False)
     eng.check_numeric()
-    if use_dist:
-        dt = max_over_ranks(dt)
+    dt = max_over_ranks(dt)
+
+    # ---- BASELINE configs[3]: one whole clip, frame-sharded, from the un-encoded source to the last frame ---------
+    clip = None
+    if args.clip_frames > 0:
+        T = args.clip_frames
+        be = EngineBackend(gen, batch=B)
+        if rank == 0:
+            c_src = synthetic_source(S, seed=1).to(dev)
+            c_kps = {k: v.to(dev) for k, v in synthetic_keypoints(1, cfg["num_kp"], seed=0).items()}
+            c_kpd = {k: v.to(dev) for k, v in synthetic_keypoints(T, cfg["num_kp"], seed=2).items()}
+        else:
+            c_src = c_kps = c_kpd = None
+
+        def run_clip(timings=None):
+            out, span = animate_clip(be, c_src, c_kps, c_kpd, S, S, uint8=args.clip_gather, gather=args.clip_gather,
+                                     timings=timings)
+            n = out.shape[0]
+            del out
+            return n, span
+
+        run_clip()                        # warm-up pass (allocator, RCCL channels)
+        fence()
+        t0 = time.perf_counter()
+        n_local, span = run_clip()
+        fence()
+        dt_clip = max_over_ranks(time.perf_counter() - t0)
+        phases = {}
+        run_clip(phases)                  # third pass with a device sync at each phase boundary: where the time goes
+        fence()
+        torch.cuda.empty_cache()
+        if rank == 0:
+            clip = {"frames": T, "frames_per_s": round(T / dt_clip, 2), "seconds": round(dt_clip, 4), "n_gpus": world,
+                    "frames_per_s_per_gpu": round(T / dt_clip / world, 2), "batch": B, "shard_rank0": list(shard_bounds(T, world, 0)),
+                    "timed": "source encode (rank 0) + broadcast of source cache and key points + compute of every "
+                             "shard" + (" + uint8 gather on rank 0" if args.clip_gather else "") + ", max over ranks",
+                    "phases_ms_rank0": {k: round(v, 3) for k, v in phases.items()},
+                    "workload": f"{S}x{S}, {T}-frame clip, contiguous shards of {T}/{world} frames, batch {B} "
+                                f"(BASELINE.json configs[3])"}
 
     if rank == 0:
         frames = args.steps * B * world
@@ -191,7 +269,6 @@ def main():
         calls = max(1, prof["calls"])
         launches = 2 * cfg["num_bottleneck_blocks"] * calls
         form = eng.bottleneck_form(B)          # 0 direct, 2 Winograd F(2x2,3x3), 4 Winograd F(4x4,3x3)
-        wino = form != 0
         algo_flop = 2.0 * (B * hf * hf) * cb * (9 * cb)
         exec_flop = algo_flop * {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0}[form]
         ms_conv = prof["ms"]["bneck_conv"] / launches if prof["calls"] else float("nan")
@@ -199,26 +276,24 @@ def main():
         achieved = exec_flop / (ms_conv * 1e-3) / 1e12
         algo = algo_flop / ((ms_conv + ms_tr) * 1e-3) / 1e12
         total_ms = sum(prof["ms"].values())
+        traffic, traffic_src = measured_traffic(form, S, B)
+        which = "configs[2]" if (S, B) == (256, 16) else ("configs[4]" if (S, B) == (512, 8) else "a non-BASELINE size")
         line = {
             "metric": "256x256 frames/sec (dense-motion + generator forward)" if S == 256 else f"{S}x{S} frames/sec",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{S}x{S}, 10 keypoints, batch={B} synthetic frames per GPU per step, source "
-                                   f"encoded once per clip (BASELINE.json configs[2])",
+                                   f"encoded once per clip (BASELINE.json {which})",
                        "frames_per_step_per_gpu": B, "parallelism": f"frame-sharded x{world}",
                        "flops_per_frame": round(eng.flops_per_frame / 1e9, 3)},
             "roofline": {"bound": "mfma",
-                         "kernel": {4: "wino4_gemm_kernel<2,4,2,...> (bottleneck 3x3 256->256 @64x64 in Winograd F(4x4,3x3) form)",
-                                    2: "wino_gemm_kernel<1,2,4,2> (bottleneck 3x3 256->256 @64x64 in Winograd F(2x2,3x3) form)",
-                                    0: "conv_mfma_dma_kernel<3,3,...> (bottleneck 3x3 256->256 @64x64, direct)"}[form],
+                         "kernel": {4: f"wino4_gemm_kernel<2,4,2,...> (bottleneck 3x3 {cb}->{cb} @{hf}x{hf} in Winograd F(4x4,3x3) form)",
+                                    2: f"wino_gemm_kernel<1,2,4,2> (bottleneck 3x3 {cb}->{cb} @{hf}x{hf} in Winograd F(2x2,3x3) form)",
+                                    0: f"conv_mfma_dma_kernel<3,3,...> (bottleneck 3x3 {cb}->{cb} @{hf}x{hf}, direct)"}[form],
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                         # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
-                         # note in MI355X_MICROARCH.md, + WRITE_SIZE) -- measured once with tools/gpu_profile.sh at this
-                         # workload (batch 16, 256x256) and committed under profiles/; not re-measured by this run
-                         "traffic": {4: TRAFFIC_WINO4, 2: TRAFFIC_WINO, 0: TRAFFIC_DIRECT}[form] if (B == 16 and S == 256) else None,
-                         "traffic_unit": "bytes/launch", "traffic_source": TRAFFIC_SRC,
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "avg_launch_ms": round(ms_conv, 4), "executed_gflop_per_launch": round(exec_flop / 1e9, 2),
                          "achieved_algorithmic": round(algo, 2),
                          "frac_algorithmic": round(algo / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -236,6 +311,7 @@ def main():
         }
         if t_bcast_ms is not None:
             line["source_broadcast_ms"] = round(t_bcast_ms, 3)
+        line["clip"] = clip
         if world == 1 and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, S, args.cpu_frames)
             line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)

@@ -7,10 +7,10 @@ from .config import hot_path_config, tiny_config  # noqa: F401
 from .generator import OcclusionAwareGenerator  # noqa: F401
 from .engine import Engine  # noqa: F401
 from .clip import EngineBackend, animate_clip, driving_keypoints, shard_bounds  # noqa: F401
-from .keypoints import normalize_kp, one_euro_smooth, smooth_keypoints  # noqa: F401
+from .keypoints import apply_emotion_offsets, normalize_kp, one_euro_smooth, smooth_keypoints  # noqa: F401
 from .keypoint_detector import KPDetector, KPDetector_a  # noqa: F401
 from .deconv_tail import DeconvTail  # noqa: F401
 from .config import kp_detector_config, kp_detector_a_config, tiny_kp_config  # noqa: F401
 
-__all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "driving_keypoints", "shard_bounds", "normalize_kp", "smooth_keypoints", "one_euro_smooth", "KPDetector", "KPDetector_a", "DeconvTail",
+__all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "driving_keypoints", "shard_bounds", "normalize_kp", "apply_emotion_offsets", "smooth_keypoints", "one_euro_smooth", "KPDetector", "KPDetector_a", "DeconvTail",
            "hot_path_config", "tiny_config"]

@@ -79,7 +79,23 @@ def driving_keypoints(deconv_tail, kp_detector_a, lstm_features: torch.Tensor, b
     return {k: torch.cat(v, 0) for k, v in parts.items()}
 
 
-def _bcast_kp(kp: Optional[Dict[str, torch.Tensor]], device, src: int, group) -> Dict[str, torch.Tensor]:
+def _staged(group, device) -> bool:
+    """True when collectives on `device` tensors must go through the host: the gloo backend only moves CPU tensors
+    for gather (and stages the rest itself); RCCL ("nccl") takes device tensors directly over xGMI."""
+    return torch.device(device).type == "cuda" and dist.get_backend(group) != "nccl"
+
+
+def _broadcast(t: torch.Tensor, src: int, group, staged: bool):
+    if not staged:
+        dist.broadcast(t, src=src, group=group)
+        return
+    h = t.cpu()
+    dist.broadcast(h, src=src, group=group)
+    if dist.get_rank(group) != src:
+        t.copy_(h)
+
+
+def _bcast_kp(kp: Optional[Dict[str, torch.Tensor]], device, src: int, group, staged: bool = False) -> Dict[str, torch.Tensor]:
     """Broadcast a key-point dict from `src` (shapes first, then payload)."""
     rank = dist.get_rank(group)
     meta = [None]
@@ -90,7 +106,7 @@ def _bcast_kp(kp: Optional[Dict[str, torch.Tensor]], device, src: int, group) ->
     for k in sorted(meta[0]):
         t = kp[k].to(device=device, dtype=torch.float32).contiguous() if rank == src else \
             torch.empty(meta[0][k], dtype=torch.float32, device=device)
-        dist.broadcast(t, src=src, group=group)
+        _broadcast(t, src, group, staged)
         out[k] = t
     return out
 
@@ -98,35 +114,68 @@ def _bcast_kp(kp: Optional[Dict[str, torch.Tensor]], device, src: int, group) ->
 def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optional[Dict[str, torch.Tensor]],
                  kp_driving: Optional[Dict[str, torch.Tensor]], height: int, width: int, uint8: bool = False,
                  group=None, gather: bool = False, kp_driving_initial: Optional[Dict[str, torch.Tensor]] = None,
-                 relative: bool = False, adapt_movement_scale: bool = False
-                 ) -> Tuple[torch.Tensor, Tuple[int, int]]:
+                 relative: bool = False, adapt_movement_scale: bool = False,
+                 emo_driving: Optional[Dict[str, torch.Tensor]] = None, emo_type: str = "linear_3",
+                 timings: Optional[Dict[str, float]] = None) -> Tuple[torch.Tensor, Tuple[int, int]]:
     """Animate one clip; returns (frames of this rank's shard, (start, stop)).
 
-    ``kp_driving_initial`` / ``relative`` / ``adapt_movement_scale`` reproduce the reference loop's
-    ``normalize_kp`` call (demo.py:276) for the whole clip at once, before the frames are sharded.
+    ``emo_driving`` ({'value': [T,E,2], 'jacobian': [T,E,2,2]}, the emotion network's per-frame displacements) adds the
+    reference's emotion offsets to the driving key points first (demo.py:263-271, ``--add_emo``); then
+    ``kp_driving_initial`` / ``relative`` / ``adapt_movement_scale`` reproduce the loop's ``normalize_kp`` call
+    (demo.py:276) -- both for the whole clip at once, on the rank that holds the key points, before the frames are sharded.
 
     Single process: all T frames.  Under torch.distributed: rank 0 supplies ``source_image`` and the
     key points (other ranks may pass None), every rank returns its contiguous shard; with
     ``gather=True`` rank 0 instead returns all T frames (others an empty tensor).
+
+    ``timings`` (a dict, filled in place): wall-clock milliseconds of the phases -- ``keypoints_ms``, ``encode_ms``,
+    ``broadcast_ms``, ``compute_ms``, ``gather_ms`` -- with a device synchronisation at each phase boundary (only when
+    asked for: the un-instrumented pipeline has no host synchronisation before ``backend.finish()``).
     """
+    import time as _time
+    _t = [_time.perf_counter()]
+
+    def mark(name):
+        if timings is None:
+            return
+        if torch.device(backend.device).type == "cuda":
+            torch.cuda.synchronize(backend.device)
+        now = _time.perf_counter()
+        timings[name] = timings.get(name, 0.0) + (now - _t[0]) * 1e3
+        _t[0] = now
+
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     rank = dist.get_rank(group) if distributed else 0
+    if kp_driving is not None:
+        # host-side key-point logic runs where the caller's tensors live; they may sit on different devices
+        kdev = kp_driving["value"].device
+        on = lambda d: None if d is None else {k: v.to(kdev) for k, v in d.items() if k in ("value", "jacobian")}
+        kp_driving, kp_driving_initial, emo_driving = on(kp_driving), on(kp_driving_initial), on(emo_driving)
+        if emo_driving is not None:
+            from .keypoints import apply_emotion_offsets
+            kp_driving = apply_emotion_offsets(kp_driving, emo_driving, emo_type)
     if kp_driving_initial is not None and kp_driving is not None and (relative or adapt_movement_scale):
         from .keypoints import normalize_kp
+        kp_source = on(kp_source)
         kp_driving = normalize_kp(kp_source, kp_driving, kp_driving_initial, adapt_movement_scale=adapt_movement_scale,
                                   use_relative_movement=relative, use_relative_jacobian=relative)
     world = dist.get_world_size(group) if distributed else 1
     backend.prepare(height, width)
+    mark("keypoints_ms")
     # 1. frame-invariant source tensors: encode once on rank 0, one broadcast
     if distributed:
+        staged = _staged(group, backend.device)
         blob = backend.encode(source_image) if rank == 0 else backend.blob_like()
-        dist.broadcast(blob, src=0, group=group)
+        mark("encode_ms")
+        _broadcast(blob, 0, group, staged)
         if rank != 0:
             backend.install(blob)
-        kp_source = _bcast_kp(kp_source, backend.device, 0, group)
-        kp_driving = _bcast_kp(kp_driving, backend.device, 0, group)
+        kp_source = _bcast_kp(kp_source, backend.device, 0, group, staged)
+        kp_driving = _bcast_kp(kp_driving, backend.device, 0, group, staged)
+        mark("broadcast_ms")
     else:
         backend.encode(source_image)
+        mark("encode_ms")
         kp_source = {k: v.to(backend.device) for k, v in kp_source.items() if k in ("value", "jacobian")}
         kp_driving = {k: v.to(backend.device) for k, v in kp_driving.items() if k in ("value", "jacobian")}
     # 2. this rank's contiguous frame range, `batch` frames per launch sequence
@@ -140,18 +189,21 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
     shape_tail = (height, width, 3) if uint8 else (3, height, width)
     dtype = torch.uint8 if uint8 else torch.float32
     local = torch.cat(chunks, dim=0) if chunks else torch.empty((0,) + shape_tail, dtype=dtype, device=backend.device)
+    mark("compute_ms")
     if not (distributed and gather):
         return local, (start, stop)
     # 3. optional gather of the shards on rank 0 (padded to the largest shard, then trimmed)
     longest = shard_bounds(total, world, 0)[1]
-    padded = torch.zeros((longest,) + shape_tail, dtype=dtype, device=backend.device)
+    cdev = torch.device("cpu") if staged else backend.device
+    padded = torch.zeros((longest,) + shape_tail, dtype=dtype, device=cdev)
     padded[: stop - start] = local
     bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
     dist.gather(padded, bufs, dst=0, group=group)
+    mark("gather_ms")
     if rank != 0:
         return local[:0], (start, stop)
     parts = []
     for r in range(world):
         a, b = shard_bounds(total, world, r)
         parts.append(bufs[r][: b - a])
-    return torch.cat(parts, dim=0), (0, total)
+    return torch.cat(parts, dim=0).to(backend.device), (0, total)

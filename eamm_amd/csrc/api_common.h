@@ -54,6 +54,27 @@ struct CtxBase {
     int patch_min_blocks = 192; // fewest workgroups for which UpBlock2d layers use the spatial-patch kernel (< 0: never)
 };
 
+// Every C entry point that touches the device runs under one of these: the handle's device becomes current for
+// the call and the caller's current device is restored on return (PyTorch reads the current device from the HIP
+// runtime, so a library that leaves another device selected would silently redirect the caller's later work).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t status = hipSuccess;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) {
+            status = hipSetDevice(device);
+            switched = status == hipSuccess && prev >= 0;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 int fail(CtxBase* c, int code, const char* fmt, ...) {
     char buf[1024];
     va_list ap;
@@ -343,7 +364,7 @@ inline void read_tile_knobs(CtxBase* c) {
 }
 
 inline void free_owned(CtxBase* c) {
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     (void)hipDeviceSynchronize();
     for (void* p : c->owned) (void)hipFree(p);
     c->owned.clear();

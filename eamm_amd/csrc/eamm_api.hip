@@ -72,6 +72,7 @@ struct eamm_ctx : eamm::CtxBase {
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;   // PROF_CALLS * (NMARK+1 + NSUB)
     std::vector<int> prof_sub;             // sub-events used by each recorded call (0: direct form)
+    std::vector<int> prof_marks;           // stage marks each recorded call completed (NMARK + 1 unless it failed midway)
     int prof_used = 0;
     double prof_ms[NSTAGE] = {0};
     long prof_calls = 0, prof_frames = 0;
@@ -145,7 +146,10 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
             return fail(nullptr, EAMM_ERR_ARG, "max_frames=%d at %dx%d needs a %.1f GiB activation tensor; the limit is 4 GiB "
                         "per tensor -- lower max_frames", g.max_frames, g.height, g.width, biggest / 1073741824.0);
     }
-    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice(%d) failed", device);
+    {   // validate the device without leaving it selected in the caller's thread
+        DeviceGuard probe(device);
+        if (probe.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice(%d) failed", device);
+    }
 
     eamm_ctx* c = new eamm_ctx();
     c->cfg = g;
@@ -171,7 +175,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     read_tile_knobs(c);
     c->wino_min_m = env_int("EAMM_WINO_MIN_M", c->wino_min_m);
     c->wino4_min_m = env_int("EAMM_WINO4_MIN_M", c->wino4_min_m);
-    c->wino_variant = env_int("EAMM_WINO_VARIANT", c->wino_variant);   // < 0 disables the Winograd bottleneck
+    c->wino_variant = env_int("EAMM_WINO_VARIANT", c->wino_variant);   // pipeline variant of wino_gemm_kernel (EAMM_WINO_MIN_M < 0 disables the Winograd bottleneck)
     c->wino_tile = env_int("EAMM_WINO_TILE", c->wino_tile);
     c->col7 = env_int("EAMM_COL7", c->col7);
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
@@ -184,6 +188,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
 
 void eamm_destroy(eamm_ctx* c) {
     if (!c) return;
+    DeviceGuard guard(c->device);
     free_owned(c);
     for (auto& e : c->prof_events) (void)hipEventDestroy(e);
     delete c;
@@ -196,7 +201,8 @@ int eamm_load_tensor(eamm_ctx* c, const char* key, const float* host, const int6
 int eamm_finalize_weights(eamm_ctx* c) {
     if (!c) return EAMM_ERR_ARG;
     if (c->finalized) return fail(c, EAMM_ERR_STATE, "weights already finalised");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     const eamm_config& g = c->cfg;
     {
         std::vector<std::string> want;
@@ -400,6 +406,8 @@ int eamm_encode_source(eamm_ctx* c, const float* source, int ns, void* stream_) 
     if (!c || !source) return fail(c, EAMM_ERR_ARG, "null argument");
     if (!c->finalized) return fail(c, EAMM_ERR_STATE, "call eamm_finalize_weights first");
     if (ns < 1 || ns > c->cfg.max_sources) return fail(c, EAMM_ERR_ARG, "ns=%d outside [1,%d]", ns, c->cfg.max_sources);
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     const size_t HW = (size_t)c->H * c->W;
     HIP_TRY(c, hipMemcpyAsync(c->src_full, source, (size_t)ns * 3 * HW * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -438,7 +446,8 @@ static int bottleneck_form(const eamm_ctx* c, int n) {
     if (c->wres1.empty()) return 0;
     const size_t px = (size_t)n * hf * wf;
     if (!c->w4res1.empty() && hf % 4 == 0 && wf % 4 == 0 && px >= (size_t)c->wino4_min_m) return 4;
-    return px >= (size_t)c->wino_min_m ? 2 : 0;
+    // F(2x2) tiles are the 2x2 pixel quads: odd map sides (a configuration eamm_create accepts) take the direct form
+    return (px >= (size_t)c->wino_min_m && !(hf & 1) && !(wf & 1)) ? 2 : 0;
 }
 
 int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd_jac, const float* ks_val,
@@ -453,6 +462,8 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     if (ns != 1 && ns != n) return fail(c, EAMM_ERR_ARG, "%d cached sources cannot serve %d frames (need 1 or n)", ns, n);
     if ((o->occlusion_map) && !c->cfg.estimate_occlusion_map)
         return fail(c, EAMM_ERR_ARG, "occlusion_map requested but estimate_occlusion_map is off");
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     const int h = c->h, w = c->w, hf = c->hf, wf = c->wf, K = c->K;
     const bool occ = c->cfg.estimate_occlusion_map != 0;
@@ -462,11 +473,15 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         ev = c->prof_events.data() + (size_t)c->prof_used * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB);
         c->prof_n.push_back(n);
         c->prof_sub.push_back(0);
+        c->prof_marks.push_back(0);
         ++c->prof_used;
     }
 #define STAGE_MARK(i)                                  \
     do {                                               \
-        if (ev) HIP_TRY(c, hipEventRecord(ev[i], s)); \
+        if (ev) {                                      \
+            HIP_TRY(c, hipEventRecord(ev[i], s));      \
+            c->prof_marks.back() = (i) + 1;            \
+        }                                              \
     } while (0)
     STAGE_MARK(0);
     // key-point records; 'jacobian' missing from kp_driving => identity (dense_motion.py:55)
@@ -669,7 +684,8 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
 
 int eamm_profile_enable(eamm_ctx* c, int on) {
     if (!c) return EAMM_ERR_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     if (on && c->prof_events.empty()) {
         c->prof_events.resize((size_t)eamm_ctx::PROF_CALLS * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB));
         for (auto& e : c->prof_events) HIP_TRY(c, hipEventCreate(&e));
@@ -680,34 +696,47 @@ int eamm_profile_enable(eamm_ctx* c, int on) {
 
 int eamm_profile_read(eamm_ctx* c, double* stage_ms, int nstage, int64_t* calls, int64_t* frames, int reset) {
     if (!c || !stage_ms || nstage != eamm_ctx::NSTAGE) return fail(c, EAMM_ERR_ARG, "nstage must be %d", eamm_ctx::NSTAGE);
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     // stage index of each of the NMARK recorded intervals; the bottleneck interval (5) is split below
     static const int stage_of[eamm_ctx::NMARK] = {0, 1, 2, 3, 4, 6, 7, 8};
+    int dropped = 0;
     for (int k = 0; k < c->prof_used; ++k) {  // fold finished event sets into the totals
         hipEvent_t* ev = c->prof_events.data() + (size_t)k * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB);
-        HIP_TRY(c, hipEventSynchronize(ev[eamm_ctx::NMARK]));
-        for (int i = 0; i < eamm_ctx::NMARK; ++i) {
+        // a call that failed midway leaves a partly recorded set: skip it (its events are re-recorded by a later call)
+        bool ok = c->prof_marks[k] == eamm_ctx::NMARK + 1 && hipEventSynchronize(ev[eamm_ctx::NMARK]) == hipSuccess;
+        double ms_set[eamm_ctx::NSTAGE] = {0};
+        for (int i = 0; ok && i < eamm_ctx::NMARK; ++i) {
             float ms = 0.f;
-            HIP_TRY(c, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-            c->prof_ms[stage_of[i]] += ms;
+            ok = hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess;
+            ms_set[stage_of[i]] += ms;
         }
         const int nsub = c->prof_sub[k];
-        if (nsub > 1) {  // Winograd form: even intervals are input transforms, odd ones the GEMM kernels
+        if (ok && nsub > 1) {  // Winograd form: even intervals are input transforms, odd ones the GEMM kernels
             hipEvent_t* sub = ev + eamm_ctx::NMARK + 1;
             double tr = 0;
-            for (int i = 0; i + 1 < nsub; i += 2) {
+            for (int i = 0; ok && i + 1 < nsub; i += 2) {
                 float ms = 0.f;
-                HIP_TRY(c, hipEventElapsedTime(&ms, sub[i], sub[i + 1]));
+                ok = hipEventElapsedTime(&ms, sub[i], sub[i + 1]) == hipSuccess;
                 tr += ms;
             }
-            c->prof_ms[5] += tr;
-            c->prof_ms[6] -= tr;
+            ms_set[5] += tr;
+            ms_set[6] -= tr;
         }
+        if (!ok) {
+            (void)hipGetLastError();
+            ++dropped;
+            continue;
+        }
+        for (int i = 0; i < eamm_ctx::NSTAGE; ++i) c->prof_ms[i] += ms_set[i];
         c->prof_calls += 1;
         c->prof_frames += c->prof_n[k];
     }
+    (void)dropped;
     c->prof_used = 0;
     c->prof_n.clear();
     c->prof_sub.clear();
+    c->prof_marks.clear();
     for (int i = 0; i < nstage; ++i) stage_ms[i] = c->prof_ms[i];
     if (calls) *calls = c->prof_calls;
     if (frames) *frames = c->prof_frames;
@@ -720,6 +749,8 @@ int eamm_profile_read(eamm_ctx* c, double* stage_ms, int nstage, int64_t* calls,
 
 int eamm_check_numeric(eamm_ctx* c, void* stream_) {
     if (!c) return EAMM_ERR_ARG;
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     int flag = 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     HIP_TRY(c, hipMemcpyAsync(&flag, c->bad_flag, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -740,6 +771,8 @@ size_t eamm_source_cache_bytes(const eamm_ctx* c, int ns) {
 int eamm_export_source_cache(eamm_ctx* c, void* dst, int ns, void* stream_) {
     if (!c || !dst) return fail(c, EAMM_ERR_ARG, "null argument");
     if (ns < 1 || ns > c->ns_cached) return fail(c, EAMM_ERR_STATE, "only %d sources are cached", c->ns_cached);
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     const size_t a = (size_t)ns * c->hf * c->wf * c->Cb, b = (size_t)ns * c->h * c->w * 4, d = (size_t)ns * 3 * c->H * c->W;
     float* p = reinterpret_cast<float*>(dst);
@@ -753,6 +786,8 @@ int eamm_import_source_cache(eamm_ctx* c, const void* src, int ns, void* stream_
     if (!c || !src) return fail(c, EAMM_ERR_ARG, "null argument");
     if (!c->finalized) return fail(c, EAMM_ERR_STATE, "call eamm_finalize_weights first");
     if (ns < 1 || ns > c->cfg.max_sources) return fail(c, EAMM_ERR_ARG, "ns=%d outside [1,%d]", ns, c->cfg.max_sources);
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     const size_t a = (size_t)ns * c->hf * c->wf * c->Cb, b = (size_t)ns * c->h * c->w * 4, d = (size_t)ns * 3 * c->H * c->W;
     const float* p = reinterpret_cast<const float*>(src);
@@ -774,7 +809,8 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
     const bool shape_ok = (kh == 3 && kw == 3) || (kh == 7 && kw == 7) || (kh == 7 && kw == 1);
     if (!in0 || !w_host || !b_host || !out || !shape_ok || C0 % CONV_BK || C1 % CONV_BK || (up && (kh != 3 || kw != 3)))
         return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: bad argument");
-    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     if (tile_n == 4000 || tile_n == 4001) {  // column-patch kernels of the 7x1 convolutions: 4000 final layer (Cout = the 32-float
         // pixel stride, weights resident), 4001 flow head (two inputs, Cout = 96, streamed weights); no bias (the gather kernels add it)

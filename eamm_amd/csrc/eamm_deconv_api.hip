@@ -92,7 +92,10 @@ int eamm_deconv_create(const eamm_deconv_config* cfg, int device, eamm_deconv_ct
             return fail(nullptr, EAMM_ERR_ARG, "channels[%d] = %d: layer inputs must be positive multiples of 32", i, g.channels[i]);
     if (g.channels[g.num_layers] < 1) return fail(nullptr, EAMM_ERR_ARG, "output channels < 1");
     if (g.max_batch < 1) return fail(nullptr, EAMM_ERR_ARG, "max_batch < 1");
-    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice(%d) failed", device);
+    {   // validate the device without leaving it selected in the caller's thread
+        DeviceGuard probe(device);
+        if (probe.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice(%d) failed", device);
+    }
     eamm_deconv_ctx* c = new eamm_deconv_ctx();
     c->cfg = g;
     c->device = device;
@@ -115,7 +118,8 @@ int eamm_deconv_load_tensor(eamm_deconv_ctx* c, const char* key, const float* ho
 int eamm_deconv_finalize_weights(eamm_deconv_ctx* c) {
     if (!c) return EAMM_ERR_ARG;
     if (c->finalized) return fail(c, EAMM_ERR_STATE, "weights already finalised");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     const eamm_deconv_config& g = c->cfg;
     {   // nn.Sequential numbering: ConvTranspose2d at 3i, BatchNorm2d at 3i+1 (ReLU at 3i+2 has no entries)
         std::vector<std::string> want;
@@ -189,6 +193,8 @@ int eamm_deconv_forward(eamm_deconv_ctx* c, const float* x, int B, float* out, v
     if (!c || !x || !out) return fail(c, EAMM_ERR_ARG, "null argument");
     if (!c->finalized) return fail(c, EAMM_ERR_STATE, "call eamm_deconv_finalize_weights first");
     if (B < 1 || B > c->cfg.max_batch) return fail(c, EAMM_ERR_ARG, "batch %d outside [1,%d]", B, c->cfg.max_batch);
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     for (int i = 0; i < c->nl; ++i) {
         const bool last = i + 1 == c->nl;

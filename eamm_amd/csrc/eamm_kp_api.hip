@@ -76,7 +76,10 @@ int eamm_kp_create(const eamm_kp_config* cfg, int device, eamm_kp_ctx** out) {
     if (g.height % div || g.width % div || g.height / g.inv_scale < 8 || g.width / g.inv_scale < 8)
         return fail(nullptr, EAMM_ERR_ARG, "frame %dx%d not divisible for scale 1/%d and %d hourglass levels", g.height,
                     g.width, g.inv_scale, g.num_blocks);
-    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice(%d) failed", device);
+    {   // validate the device without leaving it selected in the caller's thread
+        DeviceGuard probe(device);
+        if (probe.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice(%d) failed", device);
+    }
     eamm_kp_ctx* c = new eamm_kp_ctx();
     c->cfg = g;
     c->device = device;
@@ -108,7 +111,8 @@ int eamm_kp_load_tensor(eamm_kp_ctx* c, const char* key, const float* host, cons
 int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
     if (!c) return EAMM_ERR_ARG;
     if (c->finalized) return fail(c, EAMM_ERR_STATE, "weights already finalised");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     const eamm_kp_config& g = c->cfg;
     {   // key set: the heads always; the predictor hourglass + anti-alias buffer only when this handle runs them
         std::vector<std::string> want = {"kp.weight", "kp.bias"};
@@ -192,6 +196,8 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
 int eamm_kp_detect(eamm_kp_ctx* c, const float* image, int B, const eamm_kp_outputs* o, void* stream_) {
     if (int rc = check_call(c, image, B, o)) return rc;
     if (!c->cfg.with_predictor) return fail(c, EAMM_ERR_STATE, "this handle was created without the predictor hourglass");
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     const int h = c->h, w = c->w;
     // x = down(x): anti-aliased, NHWC zero-padded to Cin_pad channels            keypoint_detector.py:79-80
@@ -228,6 +234,8 @@ int eamm_kp_detect(eamm_kp_ctx* c, const float* image, int B, const eamm_kp_outp
 int eamm_kp_detect_features(eamm_kp_ctx* c, const float* feature_map, int B, const eamm_kp_outputs* o, void* stream_) {
     if (int rc = check_call(c, feature_map, B, o)) return rc;
     if (c->cfg.with_predictor) return fail(c, EAMM_ERR_STATE, "this handle runs the predictor; use eamm_kp_detect");
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     const int cp = (c->feat_c + 31) / 32 * 32;
     HIP_TRY(c, nchw_to_nhwc_pad_launch(feature_map, B, c->feat_c, c->h, c->w, cp, c->x_in, s));

@@ -71,6 +71,9 @@ class Engine:
         self._ctx = ctx
         self._finalized = False
         self.ns_cached = 0
+        # bumped by every encode / import: lets a caller that caches "my source is the encoded one" (the module's
+        # forward()) notice that somebody else (the clip pipeline) has replaced the engine's source cache since
+        self.cache_generation = 0
 
     # -- lifecycle -------------------------------------------------------------------------------
     def close(self):
@@ -119,6 +122,7 @@ class Engine:
         with torch.cuda.device(self.device):
             _lib.check(self._L.eamm_encode_source(self._ctx, _dev_ptr(src), ns, self._stream()), self._ctx)
         self.ns_cached = ns
+        self.cache_generation += 1
         return ns
 
     def forward_frames(self, kp_driving: dict, kp_source: dict, outputs: Iterable[str] = ("prediction",),
@@ -178,6 +182,7 @@ class Engine:
             _lib.check(self._L.eamm_import_source_cache(self._ctx, _dev_ptr(blob.contiguous()), ns, self._stream()),
                        self._ctx)
         self.ns_cached = ns
+        self.cache_generation += 1
 
     # -- stage timing (HIP events inside the library, on the stream the kernels run on) -----------------
     STAGES = ("front", "hg_enc", "hg_dec", "head", "warp", "bneck_transform", "bneck_conv", "up", "final")

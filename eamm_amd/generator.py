@@ -110,6 +110,7 @@ class OcclusionAwareGenerator(nn.Module):
         self._src_ref = None
         self._src_version = -1
         self._src_engine = None
+        self._src_generation = -1
         self._engine: Optional[Engine] = None
         self._engine_key = None
         for p in self.parameters():  # inference-only path
@@ -147,10 +148,11 @@ class OcclusionAwareGenerator(nn.Module):
         b, _, hh, ww = source_image.shape
         e = self._ensure_engine(hh, ww, b, b)
         fresh = not (self.cache_source and self._src_ref is source_image and self._src_version == source_image._version
-                     and e.ns_cached == b and self._src_engine is e)
+                     and e.ns_cached == b and self._src_engine is e and self._src_generation == e.cache_generation)
         if fresh:
             e.encode_source(source_image)
             self._src_ref, self._src_version, self._src_engine = source_image, source_image._version, e
+            self._src_generation = e.cache_generation
         want = ["prediction", "mask", "sparse_deformed", "deformed"]
         if self.estimate_occlusion_map:
             want.append("occlusion_map")

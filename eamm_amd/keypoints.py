@@ -40,6 +40,35 @@ def normalize_kp(kp_source: Dict[str, torch.Tensor], kp_driving: Dict[str, torch
     return out
 
 
+# demo.py:263-271 (`--add_emo`, type 'linear_3'): key point k of the driving pose receives weight * offset e of the
+# emotion network's displacement, for value and jacobian alike -- (k, e, weight)
+EMOTION_OFFSETS_LINEAR_3 = ((1, 0, 0.2), (4, 1, 1.0), (6, 2, 1.0))
+
+
+def apply_emotion_offsets(kp_driving: Dict[str, torch.Tensor], emo_driving: Dict[str, torch.Tensor],
+                          kind: str = "linear_3") -> Dict[str, torch.Tensor]:
+    """Emotion displacement of the driving key points, the step between ``kp_driving_all[t]`` and ``normalize_kp`` in
+    the reference's second loop (demo.py:263-271), for a whole clip at once: ``kp_driving`` holds [T,K,2] / [T,K,2,2],
+    ``emo_driving`` the emotion network's [T,E,2] / [T,E,2,2] (E >= 3).  Same float32 operations per element as the
+    reference (``v[:,1] + e[:,0]*0.2``; a weight of 1 is the plain sum the reference writes).  Returns new tensors;
+    the reference edits ``kp_driving`` in place, which no later step observes."""
+    if kind != "linear_3":
+        raise ValueError(f"unknown emotion offset type {kind!r} (the reference implements 'linear_3' only, demo.py:265)")
+    out = dict(kp_driving)
+    for key in ("value", "jacobian"):
+        if key not in kp_driving:
+            continue
+        if key not in emo_driving:
+            raise KeyError(key)
+        v, e = kp_driving[key].clone(), emo_driving[key].to(kp_driving[key].device)
+        if e.shape[0] != v.shape[0] or e.shape[1] < 3 or e.shape[2:] != v.shape[2:]:
+            raise RuntimeError(f"emo_driving[{key!r}] has shape {tuple(e.shape)}, expected [{v.shape[0]},>=3,...]")
+        for k, j, wgt in EMOTION_OFFSETS_LINEAR_3:
+            v[:, k] = v[:, k] + (e[:, j] * wgt if wgt != 1.0 else e[:, j])
+        out[key] = v
+    return out
+
+
 def one_euro_smooth(seq: torch.Tensor, mincutoff: float = 1.0, beta: float = 0.0, dcutoff: float = 1.0,
                     freq: float = 30.0, scale: float = 1.0) -> torch.Tensor:
     """One-Euro low-pass filter along dim 0 of ``seq`` ([T, ...]), element-wise over the rest -- the reference's

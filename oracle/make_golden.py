@@ -148,6 +148,60 @@ def normalize_kp_case():
     print("normalize_kp: wrote", len(blob), "arrays")
 
 
+def reference_statements(path, func, pick):
+    """Statements of a block inside a reference function that cannot be imported (see reference_function): `pick`
+    selects the ast node whose body is wanted; the body is compiled as the reference wrote it."""
+    import ast
+    tree = ast.parse(open(path).read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == func)
+    node = next(n for n in ast.walk(fn) if pick(n))
+    return compile(ast.Module(body=node.body, type_ignores=[]), path, "exec")
+
+
+def emotion_case():
+    """Fixture for the emotion key-point offsets of the clip loop (demo.py:263-271, `--add_emo`, type 'linear_3') and the
+    `normalize_kp` call that follows (demo.py:276): the reference's own statements, run per frame as the loop runs them."""
+    import ast
+    from scipy.spatial import ConvexHull
+    demo = os.path.join(REFERENCE, "demo.py")
+
+    def is_offset_block(n):   # `if opt.type == 'linear_3':` whose body assigns into kp_driving[...][:, k]
+        return (isinstance(n, ast.If) and isinstance(n.test, ast.Compare) and isinstance(n.test.left, ast.Attribute)
+                and n.test.left.attr == "type" and isinstance(n.body[0], ast.Assign)
+                and isinstance(n.body[0].targets[0], ast.Subscript))
+
+    code = reference_statements(demo, "make_animation_smooth", is_offset_block)
+    norm = reference_function(demo, "normalize_kp", {"np": np, "torch": torch, "ConvexHull": ConvexHull})
+    t, k, e = 5, 10, 4
+    kp_s = synthetic_keypoints(1, k, seed=0)
+    kp_i = synthetic_keypoints(1, k, seed=100)
+    kp_d = synthetic_keypoints(t, k, seed=2)
+    rs = np.random.RandomState(33)
+    emo = {"value": torch.from_numpy((0.05 * rs.standard_normal((t, e, 2))).astype(np.float32)),
+           "jacobian": torch.from_numpy((0.05 * rs.standard_normal((t, e, 2, 2))).astype(np.float32))}
+    blob = {"kp_source_value": kp_s["value"].numpy(), "kp_source_jacobian": kp_s["jacobian"].numpy(),
+            "kp_initial_value": kp_i["value"].numpy(), "kp_initial_jacobian": kp_i["jacobian"].numpy(),
+            "kp_driving_value": kp_d["value"].numpy(), "kp_driving_jacobian": kp_d["jacobian"].numpy(),
+            "emo_value": emo["value"].numpy(), "emo_jacobian": emo["jacobian"].numpy()}
+    off_v, off_j, nrm_v, nrm_j = [], [], [], []
+    for f in range(t):
+        ns = {"kp_driving": {key: v[f:f + 1].clone() for key, v in kp_d.items()},
+              "emo_driving": {key: v[f:f + 1].clone() for key, v in emo.items()}}
+        exec(code, ns)                                                         # demo.py:266-271
+        off_v.append(ns["kp_driving"]["value"].numpy().copy())
+        off_j.append(ns["kp_driving"]["jacobian"].numpy().copy())
+        out = norm(kp_source={key: v.clone() for key, v in kp_s.items()}, kp_driving=ns["kp_driving"],
+                   kp_driving_initial={key: v.clone() for key, v in kp_i.items()}, use_relative_movement=True,
+                   use_relative_jacobian=True, adapt_movement_scale=True)       # demo.py:276
+        nrm_v.append(out["value"].numpy())
+        nrm_j.append(out["jacobian"].numpy())
+    blob.update(offset_value=np.concatenate(off_v), offset_jacobian=np.concatenate(off_j),
+                normalized_value=np.concatenate(nrm_v), normalized_jacobian=np.concatenate(nrm_j))
+    assert np.abs(blob["offset_value"] - blob["kp_driving_value"]).max() > 1e-3   # the block did something
+    np.savez_compressed(os.path.join(GOLDEN, "emotion_offsets.npz"), **blob)
+    print("emotion_offsets: wrote", len(blob), "arrays")
+
+
 def kp_detector_cases():
     """Fixtures for the key-point detectors (modules/keypoint_detector.py): the reference modules driven with
     seeded weights; the oracle must reproduce them; fp32-vs-fp64 noise floor recorded."""
@@ -262,6 +316,10 @@ def main():
         os.makedirs(GOLDEN, exist_ok=True)
         normalize_kp_case()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "emotion":
+        os.makedirs(GOLDEN, exist_ok=True)
+        emotion_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "kp":
         kp_detector_cases()
         return
@@ -277,6 +335,7 @@ def main():
     summary["full256_clip2"] = case(OAG, "full256_clip2", full, 256, 2, 1234, 4)
     summary["full512_clip1"] = case(OAG, "full512_clip1", full, 512, 1, 1234, 8)
     normalize_kp_case()
+    emotion_case()
     kp_detector_cases()
     deconv_tail_case()
     smoothing_case()

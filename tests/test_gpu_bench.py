@@ -25,12 +25,12 @@ def run(cmd, env=None):
 
 
 def test_bench_single_gpu_line():
-    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-frames", "4"])
+    d = run([sys.executable, "bench.py", "--steps", "10", "--warmup", "3", "--cpu-frames", "10"])
     assert REQUIRED <= set(d)
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak"
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
-    assert abs(d["value"] - 3 * 16 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01   # value == frames / timed seconds
+    assert abs(d["value"] - 10 * 16 / (d["ms_per_step"] * 10e-3)) / d["value"] < 0.01   # value == frames / timed seconds
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert 0.3 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
@@ -39,7 +39,25 @@ def test_bench_single_gpu_line():
     assert w["bound"] == "hbm" and w["unit"] == "GB/s" and w["peak"] == 8000.0 and 0.2 < w["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0
+    assert len(c["passes"]) >= 5 and min(c["passes"]) <= c["value"] <= max(c["passes"])   # median of >= 5 passes
     assert d["value"] > 30 * c["value"]        # north_star target: >= 30x the CPU reference path
+    # roofline.traffic: a committed PMC measurement of THIS kernel source at THIS (size, batch), or null with the reason
+    assert (r["traffic"] is None or r["traffic"] > 0) and r["traffic_source"]
+    # configs[3] leg: the whole 2048-frame clip (encode + compute) must run at the steady-state rate within a few %
+    k = d["clip"]
+    assert k["frames"] == 2048 and k["n_gpus"] == 1 and abs(k["frames_per_s"] - 2048 / k["seconds"]) < 1.0
+    assert 0.9 * d["value"] <= k["frames_per_s"] <= 1.05 * d["value"], (k["frames_per_s"], d["value"])
+    assert {"encode_ms", "compute_ms"} <= set(k["phases_ms_rank0"])
+
+
+def test_bench_512_batch8_line():
+    """BASELINE configs[4]: --size 512 (batch 8 by default) prints the same line for the 512x512 workload."""
+    d = run([sys.executable, "bench.py", "--size", "512", "--steps", "3", "--warmup", "1", "--cpu-frames", "0",
+             "--clip-frames", "0"])
+    assert "512x512" in d["config"]["workload"] and "configs[4]" in d["config"]["workload"]
+    assert d["config"]["frames_per_step_per_gpu"] == 8 and d["clip"] is None and d["cpu_baseline"] is None
+    assert abs(d["value"] - 3 * 8 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01
+    assert 0.3 < d["roofline"]["frac"] <= 1.0 and "128x128" in d["roofline"]["kernel"]
 
 
 def test_bench_two_ranks_share_one_gpu():
@@ -47,9 +65,12 @@ def test_bench_two_ranks_share_one_gpu():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-             "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"],
+             "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--clip-frames", "70", "--clip-gather"],
             env={"EAMM_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and "source_broadcast_ms" in d
+    k = d["clip"]    # 70 frames over 2 ranks: 35 each, broadcast + compute + uint8 gather timed
+    assert k["frames"] == 70 and k["n_gpus"] == 2 and k["shard_rank0"] == [0, 35] and k["frames_per_s"] > 0
+    assert {"encode_ms", "broadcast_ms", "compute_ms", "gather_ms"} <= set(k["phases_ms_rank0"])
     assert abs(d["value"] - 2 * 3 * 16 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01   # whole-job frames / max time
 
 
@@ -59,7 +80,7 @@ def test_bench_rccl_path_single_rank():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-frames", "0"],
+    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-frames", "0", "--clip-frames", "64"],
             env={"EAMM_BENCH_FORCE_DIST": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     assert d["n_gpus"] == 1 and "source_broadcast_ms" in d and d["value"] > 0

@@ -49,3 +49,27 @@ def test_smooth_keypoints_matches_reference_filter(name, kw):
     assert float((out["value"] - seq["value"]).abs().max()) > 1e-3       # ... and later ones are really filtered
     flat = one_euro_smooth(seq["value"].reshape(24, -1), **(kw or dict(mincutoff=0.05, beta=8.0, dcutoff=1.0, freq=100.0, scale=10.0)))
     assert torch.equal(flat.reshape(out["value"].shape), out["value"])  # element-wise: the shape does not matter
+
+
+def test_emotion_offsets_match_reference_loop():
+    """The `--add_emo` step of the clip loop (demo.py:263-271) followed by normalize_kp (demo.py:276), whole clip at once,
+    against the reference's own statements run frame by frame (fixture: oracle/make_golden.py emotion_case)."""
+    from eamm_amd import apply_emotion_offsets
+    z = np.load(os.path.join(GOLDEN, "emotion_offsets.npz"))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    kp_d = {"value": g["kp_driving_value"].clone(), "jacobian": g["kp_driving_jacobian"].clone()}
+    emo = {"value": g["emo_value"], "jacobian": g["emo_jacobian"]}
+    out = apply_emotion_offsets(kp_d, emo)
+    assert torch.equal(out["value"], g["offset_value"]) and torch.equal(out["jacobian"], g["offset_jacobian"])  # same fp32 ops
+    assert torch.equal(kp_d["value"], g["kp_driving_value"])          # returns new tensors
+    touched = (out["value"] != kp_d["value"]).any(dim=-1).any(dim=0)
+    assert touched.nonzero().flatten().tolist() == [1, 4, 6]           # key points 1, 4, 6 only (demo.py:266-271)
+    kp_s = {"value": g["kp_source_value"], "jacobian": g["kp_source_jacobian"]}
+    kp_i = {"value": g["kp_initial_value"], "jacobian": g["kp_initial_jacobian"]}
+    nrm = normalize_kp(kp_s, out, kp_i, adapt_movement_scale=True, use_relative_movement=True, use_relative_jacobian=True)
+    assert torch.allclose(nrm["value"], g["normalized_value"], atol=1e-6, rtol=0)
+    assert torch.allclose(nrm["jacobian"], g["normalized_jacobian"], atol=2e-6, rtol=0)
+    with pytest.raises(ValueError):
+        apply_emotion_offsets(kp_d, emo, kind="linear_4")
+    with pytest.raises(RuntimeError):
+        apply_emotion_offsets(kp_d, {"value": emo["value"][:, :2], "jacobian": emo["jacobian"][:, :2]})
