@@ -61,20 +61,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_dma_kernel(const ConvAr
 
     // ---- A loader: DMA instruction j of this wave fills rows (wave*A_INSTR + j)*8 .. +8; lane -> row
     // rbase + lane/8, physical slot lane%8, i.e. channel slot (lane%8) ^ swz(row) of that pixel.
-    int ry[A_INSTR], rx[A_INSTR], rb[A_INSTR], rq[A_INSTR];
+    // Everything a lane contributes to a piece's address is computed ONCE: the byte offset of its (un-shifted)
+    // pixel in either input and a bit mask of the filter taps that stay inside the image.  Per piece the MFMA
+    // stream then carries one v_add (the chunk's wave-uniform tap / channel displacement), one bit test and
+    // one select (zero padding and the M tail = an offset the buffer descriptor rejects) -- the first version
+    // redid the 2-D bounds test and the pixel address arithmetic per piece.
+    unsigned abase0[A_INSTR], abase1[A_INSTR], tapmask[A_INSTR];
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
         const int row = (wave * A_INSTR + j) * 8 + (lane >> 3);
-        rq[j] = (((lane & 7) ^ ((row >> 1) & 7)) << 2);
+        const int rq = (((lane & 7) ^ ((row >> 1) & 7)) << 2);
         const int m = mbase + row;
+        abase0[j] = abase1[j] = 0;
+        tapmask[j] = 0;
         if (m < p.M) {
-            int b;
-            pix_decode(p, m, b, ry[j], rx[j]);
-            rb[j] = b * p.H * p.W;
-        } else {
-            ry[j] = -(1 << 20);
-            rx[j] = 0;
-            rb[j] = 0;
+            int b, y, x;
+            pix_decode(p, m, b, y, x);
+            const int pix = (b * p.H + y) * p.W + x;
+            abase0[j] = (unsigned)(pix * p.C0 + rq) * 4u;
+            abase1[j] = (unsigned)(pix * p.C1 + rq) * 4u;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int yy = y + t / KW + oy, xx = x + t % KW + ox;
+                if (((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W)) tapmask[j] |= 1u << t;
+            }
         }
     }
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in0, 0, p.in0_bytes, 0x00020000);
@@ -83,37 +93,36 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_dma_kernel(const ConvAr
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
     const int wtile = (phase * p.ntiles + ntile) * p.nchunks;
+    const unsigned w_lane = (unsigned)lane * 16u;
 
     // One chunk = NPIECE DMA instructions per wave (A_INSTR activation pieces, then B_INSTR weight pieces).
     constexpr int NPIECE = A_INSTR + B_INSTR;
     // wave-uniform description of the chunk being fetched (set by chunk_src, read by dma_piece)
-    __amdgpu_buffer_rsrc_t n_rs = rs0;
-    int n_dy = 0, n_dx = 0, n_C = 0, n_coff = 0, n_st = 0;
-    unsigned n_woff = 0;
+    int n_first = 1, n_st = 0;
+    unsigned n_delta = 0, n_tapbit = 0, n_woff = 0;
     auto chunk_src = [&](int ci, int st) {
         const int cc = ci / T, tap = ci - cc * T;
-        n_dy = tap / KW + oy;
-        n_dx = tap % KW + ox;
+        const int dy = tap / KW + oy, dx = tap % KW + ox;
         const int c0 = cc * BK;
-        const bool first = c0 < p.C0;
-        n_rs = first ? rs0 : rs1;
-        n_C = first ? p.C0 : p.C1;
-        n_coff = first ? c0 : c0 - p.C0;
+        n_first = c0 < p.C0;
+        const int C = n_first ? p.C0 : p.C1;
+        const int coff = n_first ? c0 : c0 - p.C0;
+        n_delta = (unsigned)(((dy * p.W + dx) * C + coff) * 4);   // two's complement: the lane's add wraps to the right offset
+        n_tapbit = 1u << tap;
         n_st = st;
-        n_woff = (unsigned)((wtile + ci) * (BN * BK) + wave * (B_INSTR * 8 * BK) + lane * 4) * 4u;
+        n_woff = (unsigned)((wtile + ci) * (BN * BK) + wave * (B_INSTR * 8 * BK)) * 4u;
     };
     auto dma_piece = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
         if constexpr (k < A_INSTR) {
-            const int yy = ry[k] + n_dy, xx = rx[k] + n_dx;
-            const bool ok = ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
-            const unsigned off = ok ? (unsigned)((rb[k] + yy * p.W + xx) * n_C + n_coff + rq[k]) * 4u : OOB;
+            const unsigned base = n_first ? abase0[k] : abase1[k];
+            const unsigned off = (tapmask[k] & n_tapbit) ? base + n_delta : OOB;
             float* dst = As + n_st * A_STAGE + (wave * A_INSTR + k) * (8 * BK);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(n_rs, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(n_first ? rs0 : rs1, (lds_ptr_t)dst, 16, off, 0, 0, 0);
         } else {
             constexpr int j = k - A_INSTR;
             float* dst = Bs + n_st * B_STAGE + (wave * B_INSTR + j) * (8 * BK);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)dst, 16, n_woff + j * (8 * BK * 4), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)dst, 16, w_lane, n_woff + j * (8 * BK * 4), 0, 0);
         }
     };
 

@@ -190,35 +190,50 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     const int ci_base = grp * rows_per * 6 * cchunks;     // first chunk of this workgroup's transform points
     const int nsuper = rows_per * 6 * cchunks / SUB;      // barrier intervals
 
+    // DMA addressing.  Every piece is ONE buffer_load ... lds whose address splits into a per-lane VGPR part that never
+    // changes (the lane's row and 16-byte slot) and a wave-uniform SGPR part that advances by a constant per interval
+    // (transform point / channel chunk for V, chunk index for U) -- no per-piece integer division or vector arithmetic
+    // in the MFMA stream (the first version recomputed xi = ci / cchunks per piece: ~25 scalar instructions each).
     unsigned arow_off[A_INSTR];
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
         const int row = (wave * A_INSTR + j) * 8 + (lane >> 3);
         const int slot = (lane & 7) ^ ((row >> 1) & 7);
         const int m = mbase + row;
-        arow_off[j] = m < p.Mq ? (unsigned)(m * p.C + slot * 4) * 4u : 0xFFFFFFF0u;
+        arow_off[j] = m < p.Mq ? (unsigned)(m * p.C + slot * 4) * 4u : 0xFFFFF000u;   // M tail: out of range (+ the immediate cannot wrap it)
     }
+    const unsigned b_lane = (unsigned)lane * 16u;
     const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, p.v_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, p.u_bytes, 0x00020000);
     const unsigned plane_bytes = (unsigned)p.Mq * (unsigned)p.C * 4u;
+    const unsigned a_wrap = plane_bytes - (unsigned)(cchunks * BK * 4);   // from the last chunks of xi to the first of xi + 1
 
-    int n_sc = 0, n_st = 0;
+    // uniform state of the interval whose pieces are issued next
+    unsigned sa_off = (unsigned)(grp * rows_per * 6) * plane_bytes;                                // (xi, cc) in V
+    unsigned sb_off = (unsigned)((ntile * 36 * cchunks + ci_base) * BN * BK) * 4u +               // chunk ci in U
+                      (unsigned)(wave * B_INSTR * 8 * BK) * 4u;                                    // + this wave's rows
+    int dma_cc = 0, n_st = 0;
+    auto dma_advance = [&]() {
+        dma_cc += SUB;
+        sa_off += SUB * BK * 4;
+        if (dma_cc == cchunks) {
+            dma_cc = 0;
+            sa_off += a_wrap;
+        }
+        sb_off += SUB * BN * BK * 4;
+        n_st = n_st + 1 == NST ? 0 : n_st + 1;
+    };
     auto dma_piece = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int sub = k / (A_INSTR + B_INSTR), r = k % (A_INSTR + B_INSTR);
-        const int ci = ci_base + n_sc * SUB + sub;    // chunk index: xi * cchunks + cc
-        const int xi = ci / cchunks, cc = ci - xi * cchunks;
         if constexpr (r < A_INSTR) {
-            const unsigned off = arow_off[r] + (unsigned)xi * plane_bytes + (unsigned)(cc * BK * 4);
-            const unsigned o2 = arow_off[r] == 0xFFFFFFF0u ? 0xFFFFFFF0u : off;   // M tail: always out of range
             float* dst = As + n_st * A_STAGE + sub * (BM * BK) + (wave * A_INSTR + r) * (8 * BK);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_ptr_t)dst, 16, o2, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_ptr_t)dst, 16, arow_off[r], sa_off, sub * BK * 4, 0);
         } else {
             constexpr int j = r - A_INSTR;
-            const unsigned off =
-                (unsigned)(((ntile * 36 * cchunks + ci) * BN + (wave * B_INSTR + j) * 8) * BK + lane * 4) * 4u;
             float* dst = Bs + n_st * B_STAGE + sub * (BN * BK) + (wave * B_INSTR + j) * (8 * BK);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)dst, 16, b_lane,
+                                                     sb_off + (unsigned)((sub * BN + j * 8) * BK * 4), 0, 0);
         }
     };
 
@@ -240,7 +255,10 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     constexpr int MF = 4 * NT;                   // MFMAs per step
     constexpr int TOTAL_MF = STEPS * MF;
     static_assert(PE >= 1 && NPIECE * PE <= TOTAL_MF, "DMA pieces must fit in the interval");
-    auto compute = [&](int st, bool more) {
+    // MORE: the interval issues the DMA pieces of the interval D ahead; YOUNG: all of them before the first MFMA.
+    // Both are wave-uniform and resolved ONCE per interval (interval() below), so the MFMA stream carries no branches.
+    auto compute = [&](int st, auto more_c, auto young_c) {
+        constexpr bool MORE = decltype(more_c)::value && DBG != 1 && DBG != 9, YOUNG = decltype(young_c)::value;
         f32x4_t a[2], b[2][NT];
         auto fetch = [&](int step, int buf) {
             const int sub = step >> 1, s = step & 1;
@@ -252,15 +270,13 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
             for (int j = 0; j < NT; ++j) b[buf][j] = *reinterpret_cast<const f32x4_t*>(b_base + j * 16 * BK);
         };
         fetch(0, 0);
-        if constexpr (YOUNG_FIRST) {
-            // The matrix pipe serves the older wave of a SIMD first (waves 0..NW/2-1 finish an interval's MFMAs
-            // before waves NW/2.. get going), and a younger wave's interleaved pieces are gated by its own MFMA
-            // progress, so they used to issue late, in the tail the older wave no longer covers.  The younger half
-            // therefore issues its pieces before its first MFMA, while it would be waiting for the pipe anyway
-            // (measured: 2.29 -> 2.25 ms per step; moving the older half's pieces as well, or more pieces to one
-            // half, is slower -- profiles/r01_wino4_gemm_investigation.txt).
-            if (more && wave >= NW / 2) static_for<NPIECE>([&](auto kc) { dma_piece(kc); });
-        }
+        // The matrix pipe serves the older wave of a SIMD first (waves 0..NW/2-1 finish an interval's MFMAs
+        // before waves NW/2.. get going), and a younger wave's interleaved pieces are gated by its own MFMA
+        // progress, so they used to issue late, in the tail the older wave no longer covers.  The younger half
+        // therefore issues its pieces before its first MFMA, while it would be waiting for the pipe anyway
+        // (measured: 2.29 -> 2.25 ms per step; moving the older half's pieces as well, or more pieces to one
+        // half, is slower -- profiles/r01_wino4_gemm_investigation.txt).
+        if constexpr (MORE && YOUNG) static_for<NPIECE>([&](auto kc) { dma_piece(kc); });
         static_for<STEPS>([&](auto sc) {
             constexpr int step = decltype(sc)::value;
             if constexpr (step + 1 < STEPS) fetch(step + 1, (step + 1) & 1);
@@ -270,13 +286,23 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
                 constexpr int t = q / NT, j = q % NT;
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[step & 1][t], b[step & 1][j][t], acc[j], 0, 0, 0);
                 constexpr int gi = step * MF + q;
-                if constexpr (gi % PE == PE - 1 && gi / PE < NPIECE) {
+                if constexpr (MORE && !YOUNG && gi % PE == PE - 1 && gi / PE < NPIECE) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more && DBG != 1 && DBG != 9 && !(YOUNG_FIRST && wave >= NW / 2)) dma_piece(std::integral_constant<int, gi / PE>{});
+                    dma_piece(std::integral_constant<int, gi / PE>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
         });
+    };
+    const bool young = YOUNG_FIRST && wave >= NW / 2;
+    auto interval = [&](int st, bool more) {
+        if (more) {
+            if (young) compute(st, std::true_type{}, std::true_type{});
+            else compute(st, std::true_type{}, std::false_type{});
+            dma_advance();
+        } else {
+            compute(st, std::false_type{}, std::false_type{});
+        }
     };
 
     auto fold_x = [&](int j) {   // Z[q] += A^T[q][j] * M_ij
@@ -335,9 +361,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     constexpr int D = NST - 1;
     const int per_xi = cchunks / SUB;  // barrier intervals per transform point
     for (int k = 0; k < D && k < nsuper; ++k) {
-        n_sc = k;
-        n_st = k;
         static_for<NPIECE>([&](auto kc) { dma_piece(kc); });
+        dma_advance();
     }
     if (D > 1 && nsuper >= D) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NPIECE) : "memory");
@@ -345,15 +370,13 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    int st = 0, st_next = D % NST;
+    int st = 0;
     int xi_left = per_xi, xj = 0, xrow = grp * rows_per;
     for (int sc = 0; sc < nsuper; ++sc) {
         const bool more = sc + D < nsuper;
-        n_sc = sc + D;
-        n_st = st_next;
         long long ts0 = 0, ts1 = 0, ts2 = 0;
         if constexpr (TRACE) ts0 = __builtin_readcyclecounter();
-        compute(st, more);
+        interval(st, more);
         if constexpr (TRACE) ts1 = __builtin_readcyclecounter();
         if (--xi_left == 0) {
             xi_left = per_xi;
@@ -381,7 +404,6 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
         }
         __syncthreads();
         st = st + 1 == NST ? 0 : st + 1;
-        st_next = st_next + 1 == NST ? 0 : st_next + 1;
     }
 
     if (p.zout != nullptr) return;
@@ -576,7 +598,7 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     a.groups = groups;
     a.zout = groups > 1 ? zbuf : nullptr;
     const size_t vb = (size_t)36 * a.Mq * a.C * sizeof(float), ub = wino4_packed_elems(L.Cout, L.Cin, BN) * sizeof(float);
-    if (vb >= 0xFFFFFFF0ull || ub >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    if (vb >= 0xFFFFF000ull || ub >= 0xFFFFF000ull) return hipErrorInvalidValue;
     a.v_bytes = (unsigned)vb;
     a.u_bytes = (unsigned)ub;
     const bool sub4 = L.Cin % (4 * CONV_BK) == 0;
