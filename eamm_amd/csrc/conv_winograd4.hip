@@ -228,7 +228,10 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
         constexpr int sub = k / (A_INSTR + B_INSTR), r = k % (A_INSTR + B_INSTR);
         if constexpr (r < A_INSTR) {
             float* dst = As + n_st * A_STAGE + sub * (BM * BK) + (wave * A_INSTR + r) * (8 * BK);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_ptr_t)dst, 16, arow_off[r], sa_off, sub * BK * 4, 0);
+            // (a local copy: passing the captured array element straight to the builtin makes hipcc 7.2's HOST pass drop the
+            // kernel's stub without a diagnostic -- the library then fails to load with an undefined kernel symbol)
+            const unsigned vo = arow_off[r];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_ptr_t)dst, 16, vo, sa_off, sub * BK * 4, 0);
         } else {
             constexpr int j = r - A_INSTR;
             float* dst = Bs + n_st * B_STAGE + sub * (BN * BK) + (wave * B_INSTR + j) * (8 * BK);
