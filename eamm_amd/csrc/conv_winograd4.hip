@@ -227,7 +227,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
         constexpr int k = decltype(kc)::value;
         constexpr int sub = k / (A_INSTR + B_INSTR), r = k % (A_INSTR + B_INSTR);
         if constexpr (r < A_INSTR) {
-            float* dst = As + n_st * A_STAGE + sub * (BM * BK) + (wave * A_INSTR + r) * (8 * BK);
+            // the instruction's immediate offset moves the LDS address as well as the global one: take it off the LDS side
+            float* dst = As + n_st * A_STAGE + sub * (BM * BK) + (wave * A_INSTR + r) * (8 * BK) - sub * BK;
             // (a local copy: passing the captured array element straight to the builtin makes hipcc 7.2's HOST pass drop the
             // kernel's stub without a diagnostic -- the library then fails to load with an undefined kernel symbol)
             const unsigned vo = arow_off[r];
