@@ -215,6 +215,12 @@ def main():
     prof = eng.profile_read(reset=True)
     eng.profile(False)
     eng.check_numeric()
+    # the timed launches must have produced frames (parity itself is tests/' job: this only refuses to print a rate for
+    # a build whose kernels write garbage): sigmoid-ranged, finite, and not constant
+    chk = step()["prediction"]
+    assert bool(torch.isfinite(chk).all()) and 0.0 < float(chk.min()) and float(chk.max()) < 1.0 and float(chk.std()) > 0.02, \
+        "bench.py: the forward pass produced non-finite or degenerate frames"
+    del chk
     dt = max_over_ranks(dt)
 
     # ---- BASELINE configs[3]: one whole clip, frame-sharded, from the un-encoded source to the last frame ---------
