@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Copy the text/json summaries of one gpurun round (tools/gpu_round.sh <tag>) from gpurun_out/ (scratch) into profiles/
+(tracked), and merge the per-size pmc_traffic.json tables into profiles/pmc_traffic.json.   tools/collect_profiles.py <tag>"""
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+table = {}
+if os.path.exists(os.path.join(P, "pmc_traffic.json")):
+    table = json.load(open(os.path.join(P, "pmc_traffic.json")))
+for size_tag in ("256_b16", "512_b8"):
+    d = os.path.join(G, f"prof_r02{tag}_{size_tag}")
+    if not os.path.isdir(d):
+        continue
+    for src, dst in (("kernel_trace_stats.txt", f"r02_{size_tag}_rocprofv3_kernel_trace_stats.txt"),
+                     ("bench_under_kernel_trace.json", f"r02_{size_tag}_bench_under_kernel_trace.json"),
+                     ("pmc_fetch.txt", f"r02_{size_tag}_pmc_fetch.txt"), ("pmc_write.txt", f"r02_{size_tag}_pmc_write.txt"),
+                     ("pmc_sq.txt", f"r02_{size_tag}_pmc_sq.txt"), ("pmc_lds.txt", f"r02_{size_tag}_pmc_lds.txt")):
+        if os.path.exists(os.path.join(d, src)):
+            shutil.copy(os.path.join(d, src), os.path.join(P, dst))
+    t = os.path.join(d, "pmc_traffic.json")
+    if os.path.exists(t):
+        table.update(json.load(open(t)))
+r = os.path.join(G, f"r02_{tag}")
+for src, dst in (("bench_256_b16.json", "r02_bench_256_b16.json"), ("bench_512_b8.json", "r02_bench_512_b8.json"),
+                 ("module_latency.txt", "r02_module_latency.txt")):
+    if os.path.exists(os.path.join(r, src)):
+        shutil.copy(os.path.join(r, src), os.path.join(P, dst))
+json.dump(table, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+print("profiles/ updated from round", tag, "-- traffic records:", sorted(k for k in table if k.startswith("form")))
