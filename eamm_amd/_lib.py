@@ -86,6 +86,13 @@ SIGNATURES = {
     "eamm_deconv_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "eamm_deconv_finalize_weights": (C.c_int, [C.c_void_p]),
     "eamm_deconv_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "eamm_bn_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "eamm_bn_local_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eamm_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eamm_bn_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                C.c_void_p]),
+    "eamm_bn_last_error": (C.c_char_p, []),
     "eamm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "eamm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64), C.c_int]),

@@ -1,0 +1,195 @@
+// Training-mode BatchNorm2d forward on NCHW fp32 tensors -- SURVEY.md section 8f row N4, first slice (forward and
+// running statistics; no backward).  Reference: sync_batchnorm/batchnorm.py:46-125 (`_SynchronizedBatchNorm.forward`:
+// per-channel sum and sum of squares -> reduce over the replicas -> mean / inverse standard deviation + running
+// statistics on the master (`_compute_mean_std`) -> (x - mean) * (inv_std * weight) + bias).
+//
+// Four HBM-bound kernels; the all-reduce of the 2C (+2) per-channel sums sits between the second and the third and is
+// the caller's (torch.distributed / RCCL):
+//   bn_partial_sums_kernel  x read once (16-byte loads), one (sum, sum of squares) pair per (channel, slice) block
+//   bn_combine_kernel       slices added in a fixed order -> sums[2C], element count in sums[2C], sums[2C+1]
+//   bn_finalize_kernel      mean, inverse standard deviation, running-statistics update, per-channel scale
+//   bn_apply_kernel         x read once more, y written once
+// Algorithmic bytes: 12 B per element (two reads, one write); the statistics are 8 B per channel.
+#include "kernels.h"
+
+#include <algorithm>
+
+namespace eamm {
+
+namespace {
+constexpr int BN_THREADS = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+}  // namespace
+
+// grid (C, S, R): block (c, s, r) covers images n = s, s + S, ... and the r-th of R slices of their HW plane.
+// VEC = 4 needs HW % 4 == 0 (planes then start 16-byte aligned whenever x does).
+template <int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_partial_sums_kernel(const float* __restrict__ x, int N, int C, int HW, int S,
+                                                                      int R, float* __restrict__ partial) {
+    const int c = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
+    const int per = (HW / VEC + R - 1) / R;                 // VEC-wide elements per slice
+    const int lo = r * per, hi = min(HW / VEC, lo + per);
+    float sum = 0.f, ssum = 0.f;
+    for (int n = s; n < N; n += S) {
+        const float* plane = x + ((size_t)n * C + c) * HW;
+        for (int i = lo + threadIdx.x; i < hi; i += BN_THREADS) {
+            if constexpr (VEC == 4) {
+                const float4 v = reinterpret_cast<const float4*>(plane)[i];
+                sum += (v.x + v.y) + (v.z + v.w);
+                ssum = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ssum))));
+            } else {
+                const float v = plane[i];
+                sum += v;
+                ssum = fmaf(v, v, ssum);
+            }
+        }
+    }
+    __shared__ float red[2][BN_THREADS / 64];
+    sum = wave_sum(sum);
+    ssum = wave_sum(ssum);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sum;
+        red[1][threadIdx.x >> 6] = ssum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < BN_THREADS / 64; ++w) {
+            a += red[0][w];
+            b += red[1][w];
+        }
+        float* dst = partial + ((size_t)c * (S * R) + (s * R + r)) * 2;
+        dst[0] = a;
+        dst[1] = b;
+    }
+}
+
+// sums[c] = sum, sums[C + c] = sum of squares; sums[2C] + 4096 * sums[2C + 1] = element count per channel (two exact
+// floats, so that the count rides through the same float all-reduce as the sums)
+__global__ void bn_combine_kernel(const float* __restrict__ partial, int C, int P, long long count, float* __restrict__ sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        double a = 0.0, b = 0.0;   // P values per channel: the order is fixed, the extra width costs nothing
+        for (int p = 0; p < P; ++p) {
+            a += (double)partial[((size_t)c * P + p) * 2];
+            b += (double)partial[((size_t)c * P + p) * 2 + 1];
+        }
+        sums[c] = (float)a;
+        sums[C + c] = (float)b;
+    }
+    if (c == 0) {
+        sums[2 * C] = (float)(count % 4096);
+        sums[2 * C + 1] = (float)(count / 4096);
+    }
+}
+
+// mode 0: the replicas' path (batchnorm.py:110-125): inv_std = clamp(biased var, eps) ^ -0.5
+// mode 1: the single-replica path F.batch_norm(training=True) (batchnorm.py:48-53): inv_std = 1 / sqrt(biased var + eps)
+// mode 2: evaluation: running statistics, nothing updated
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float eps, float momentum, int mode,
+                                   const float* __restrict__ weight, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ mean_out, float* __restrict__ scale_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float w = weight != nullptr ? weight[c] : 1.f;
+    if (mode == 2) {
+        mean_out[c] = running_mean[c];
+        scale_out[c] = w / sqrtf(running_var[c] + eps);
+        return;
+    }
+    const float size = sums[2 * C] + 4096.f * sums[2 * C + 1];
+    const float sum = sums[c], ssum = sums[C + c];
+    float mean, unbias_var, inv_std;
+    if (mode == 0) {   // the reference's float32 operations, in its order (batchnorm.py:113-125)
+        mean = sum / size;
+        const float sumvar = ssum - sum * mean;
+        unbias_var = sumvar / (size - 1.f);
+        const float bias_var = sumvar / size;
+        inv_std = powf(fmaxf(bias_var, eps), -0.5f);
+    } else {           // ATen accumulates the batch statistics of a float tensor in double
+        const double m = (double)sum / (double)size;
+        const double sumvar = (double)ssum - (double)sum * m;
+        mean = (float)m;
+        unbias_var = (float)(sumvar / ((double)size - 1.0));
+        inv_std = (float)(1.0 / sqrt(sumvar / (double)size + (double)eps));
+    }
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbias_var;
+    mean_out[c] = mean;
+    scale_out[c] = inv_std * w;
+}
+
+// y = (x - mean[c]) * scale[c] + bias[c]     (batchnorm.py:74-79); grid (N*C planes, slices)
+template <int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                               const float* __restrict__ scale, const float* __restrict__ bias,
+                                                               int C, int HW, float* __restrict__ y) {
+    const int plane = blockIdx.x, c = plane % C;
+    const float m = mean[c], s = scale[c], b = bias != nullptr ? bias[c] : 0.f;
+    const float* src = x + (size_t)plane * HW;
+    float* dst = y + (size_t)plane * HW;
+    for (int i = blockIdx.y * BN_THREADS + threadIdx.x; i < HW / VEC; i += gridDim.y * BN_THREADS) {
+        if constexpr (VEC == 4) {
+            float4 v = reinterpret_cast<const float4*>(src)[i];
+            v.x = fmaf(v.x - m, s, b); v.y = fmaf(v.y - m, s, b);
+            v.z = fmaf(v.z - m, s, b); v.w = fmaf(v.w - m, s, b);
+            reinterpret_cast<float4*>(dst)[i] = v;
+        } else {
+            dst[i] = fmaf(src[i] - m, s, b);
+        }
+    }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------
+void bn_plan(int N, int C, int HW, int* S, int* R) {
+    // >= ~2048 blocks when the tensor allows it, each with at least ~4 K elements
+    const long long per_channel = (long long)N * HW;
+    int want = (int)std::max<long long>(1, std::min<long long>(2048 / std::max(1, C) + 1, per_channel / 4096));
+    *S = std::max(1, std::min(N, want));
+    *R = std::max(1, std::min((want + *S - 1) / *S, std::max(1, HW / 1024)));
+}
+
+size_t bn_workspace_floats(int N, int C, int HW) {
+    int S, R;
+    bn_plan(N, C, HW, &S, &R);
+    return (size_t)C * S * R * 2;
+}
+
+hipError_t bn_local_sums_launch(const float* x, int N, int C, int HW, float* sums, float* workspace, hipStream_t s) {
+    int S, R;
+    bn_plan(N, C, HW, &S, &R);
+    const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(bn_partial_sums_kernel<4>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, N, C, HW, S, R, workspace);
+    else
+        hipLaunchKernelGGL(bn_partial_sums_kernel<1>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, N, C, HW, S, R, workspace);
+    hipLaunchKernelGGL(bn_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, C, S * R, (long long)N * HW, sums);
+    return hipGetLastError();
+}
+
+hipError_t bn_finalize_launch(const float* sums, int C, float eps, float momentum, int mode, const float* weight,
+                              float* running_mean, float* running_var, float* mean, float* scale, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, eps, momentum, mode, weight,
+                       running_mean, running_var, mean, scale);
+    return hipGetLastError();
+}
+
+hipError_t bn_apply_launch(const float* x, const float* mean, const float* scale, const float* bias, int N, int C, int HW,
+                           float* y, hipStream_t s) {
+    const bool vec = (HW % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+    const int per = vec ? HW / 4 : HW;
+    const int slices = std::max(1, std::min(64, (per + 4 * BN_THREADS - 1) / (4 * BN_THREADS)));
+    if (vec)
+        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(N * C, slices), dim3(BN_THREADS), 0, s, x, mean, scale, bias, C, HW, y);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(N * C, slices), dim3(BN_THREADS), 0, s, x, mean, scale, bias, C, HW, y);
+    return hipGetLastError();
+}
+
+}  // namespace eamm

@@ -30,7 +30,7 @@ struct eamm_ctx : eamm::CtxBase {
     std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
     std::vector<WinoLayer> w4res1, w4res2; // Winograd F(4x4,3x3) packing (bottleneck maps with sides divisible by 4)
     int wino_tile = 4;                     // preferred output tile (EAMM_WINO_TILE): 4 -> F(4x4) where it applies, 2 -> F(2x2)
-    int wino4_variant = 0;                 // wino4_gemm_kernel pipeline variant
+    int wino4_variant = 3;                 // wino4_gemm_kernel pipeline variant (3: one DMA piece per 8 MFMAs; 2.062 -> 2.047 ms per step vs one per 4)
     float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] (F(2x2)) or [36][F*hf*wf/16][Cb] transformed activations
     float* wino_z = nullptr;               // [24][F*hf*wf/16][Cb] x-folded products of the split F(4x4) form (few tiles)
     int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd F(2x2) form
@@ -45,6 +45,7 @@ struct eamm_ctx : eamm::CtxBase {
     float* final_part = nullptr;   // [F,H,W,32] (dx,co) partial products of the final 7x7 conv
     float* final_w_swz = nullptr;  // the 7x1 weights in LDS-DMA layout for the column-patch kernel (conv_col7.hip)
     int col7 = 1;                  // EAMM_COL7: 0 = im2col-style kernel for the final convolution
+    int head_col7_min_tiles = 128; // fewest 16x16 tiles for which the flow head uses the column-patch kernel (EAMM_HEAD_COL7_MIN_TILES)
 
     // source cache (exportable): feat [S,hf,wf,Cb], src_small [S,h,w,4], src_full [S,3,H,W]
     float *feat = nullptr, *src_small = nullptr, *src_full = nullptr;
@@ -178,6 +179,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->wino_variant = env_int("EAMM_WINO_VARIANT", c->wino_variant);   // pipeline variant of wino_gemm_kernel (EAMM_WINO_MIN_M < 0 disables the Winograd bottleneck)
     c->wino_tile = env_int("EAMM_WINO_TILE", c->wino_tile);
     c->col7 = env_int("EAMM_COL7", c->col7);
+    c->head_col7_min_tiles = env_int("EAMM_HEAD_COL7_MIN_TILES", c->head_col7_min_tiles);
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
     c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);
@@ -536,7 +538,10 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         float* defo = c->deformation;
         if (c->head_nc) {
             head.Cout = 128;  // partial products written with a 128-float pixel stride (7*nc used)
-            if (c->head_w_swz)
+            // the column-patch kernel runs one workgroup per 16x16-pixel tile: below ~half a chip of tiles (4 frames at
+            // 64x64) the split-K im2col kernel is faster (measured: 1 frame 0.122 -> 0.073 ms, 4 frames 0.122 -> 0.094 ms)
+            const int head_tiles = n * ((h + 15) / 16) * ((w + 15) / 16);
+            if (c->head_w_swz && head_tiles >= c->head_col7_min_tiles)
                 HIP_TRY(c, conv_col7s_launch(io.in0, head.C0, io.in1, head.C1, n, h, w, c->head_w_swz, 3, c->logits, 128, s));
             else
                 HIP_TRY(c, conv_launch(head, io, s));

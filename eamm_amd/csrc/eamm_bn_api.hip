@@ -1,0 +1,62 @@
+// C ABI of the training-mode BatchNorm forward (include/eamm_hip.h, "N4, first slice"; kernels in batchnorm.hip).
+// Stateless: the caller owns every buffer and selects the device; errors are reported per thread.
+#include "../../include/eamm_hip.h"
+#include "kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+using namespace eamm;
+
+namespace {
+thread_local std::string g_bn_error;
+
+int bn_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_bn_error = buf;
+    return code;
+}
+
+int bn_check(hipError_t e, const char* what) {
+    return e == hipSuccess ? EAMM_OK : bn_fail(EAMM_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+}
+}  // namespace
+
+extern "C" {
+
+const char* eamm_bn_last_error(void) { return g_bn_error.c_str(); }
+
+size_t eamm_bn_workspace_floats(int N, int C, int HW) {
+    if (N < 1 || C < 1 || HW < 1) return 0;
+    return bn_workspace_floats(N, C, HW);
+}
+
+int eamm_bn_local_sums(const float* x, int N, int C, int HW, float* sums, float* workspace, void* stream) {
+    if (!x || !sums || !workspace) return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (N < 1 || C < 1 || HW < 1) return bn_fail(EAMM_ERR_ARG, "empty tensor [%d,%d,%d]", N, C, HW);
+    if ((long long)N * HW >= (1ll << 36)) return bn_fail(EAMM_ERR_ARG, "more than 2^36 elements per channel");
+    return bn_check(bn_local_sums_launch(x, N, C, HW, sums, workspace, reinterpret_cast<hipStream_t>(stream)), "bn_local_sums");
+}
+
+int eamm_bn_finalize(const float* sums, int C, float eps, float momentum, int mode, const float* weight, float* running_mean,
+                     float* running_var, float* mean, float* scale, void* stream) {
+    if (!running_mean || !running_var || !mean || !scale || (mode != EAMM_BN_EVAL && !sums))
+        return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (C < 1 || mode < 0 || mode > 2) return bn_fail(EAMM_ERR_ARG, "bad channel count or mode");
+    return bn_check(bn_finalize_launch(sums, C, eps, momentum, mode, weight, running_mean, running_var, mean, scale,
+                                       reinterpret_cast<hipStream_t>(stream)), "bn_finalize");
+}
+
+int eamm_bn_apply(const float* x, const float* mean, const float* scale, const float* bias, int N, int C, int HW, float* y,
+                  void* stream) {
+    if (!x || !mean || !scale || !y) return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (N < 1 || C < 1 || HW < 1) return bn_fail(EAMM_ERR_ARG, "empty tensor [%d,%d,%d]", N, C, HW);
+    return bn_check(bn_apply_launch(x, mean, scale, bias, N, C, HW, y, reinterpret_cast<hipStream_t>(stream)), "bn_apply");
+}
+
+}  // extern "C"

@@ -166,6 +166,14 @@ hipError_t nchw_to_nhwc_pad_launch(const float* src /*[B,C,H,W]*/, int B, int C,
 hipError_t kp_head_launch(const float* logits /*[B,h,w,Cs]*/, int B, int K, int njm, int h, int w, int Cs, int pad,
                           float temperature, float* value /*[B,K,2]*/, float* jacobian /*[B,K,2,2] or null*/,
                           float* heatmap /*[B,K,h-6+2pad,w-6+2pad] or null*/, hipStream_t s);
+// ---- training-mode BatchNorm forward (batchnorm.hip; SURVEY.md 8f row N4, first slice)
+size_t bn_workspace_floats(int N, int C, int HW);
+hipError_t bn_local_sums_launch(const float* x /*[N,C,HW]*/, int N, int C, int HW, float* sums /*[2C+2]*/, float* workspace,
+                                hipStream_t s);
+hipError_t bn_finalize_launch(const float* sums, int C, float eps, float momentum, int mode, const float* weight,
+                              float* running_mean, float* running_var, float* mean, float* scale, hipStream_t s);
+hipError_t bn_apply_launch(const float* x, const float* mean, const float* scale, const float* bias, int N, int C, int HW,
+                           float* y, hipStream_t s);
 hipError_t to_u8_launch(const float* pred /*[n,3,H,W]*/, int n, int H, int W, uint8_t* out /*[n,H,W,3]*/,
                         hipStream_t s);
 

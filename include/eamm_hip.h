@@ -205,6 +205,33 @@ int eamm_deconv_finalize_weights(eamm_deconv_ctx* ctx);
 int eamm_deconv_forward(eamm_deconv_ctx* ctx, const float* x, int B, float* out, void* stream);
 
 /*
+ * ---- N4, first slice: training-mode BatchNorm forward ------------------------------------------------------
+ * Replaces the arithmetic of _SynchronizedBatchNorm.forward (reference sync_batchnorm/batchnorm.py:46-125) on NCHW
+ * float32 device tensors; the reduction over replicas (ReduceAddCoalesced / Broadcast, batchnorm.py:102-105) is the
+ * caller's all-reduce of `sums` between eamm_bn_local_sums and eamm_bn_finalize (torch.distributed / RCCL).
+ * Stateless: the caller owns every buffer and makes the tensors' device current; work is enqueued on `stream`.
+ *   eamm_bn_local_sums   sums[c] = sum over (N, HW) of x[:, c], sums[C + c] = sum of squares (batchnorm.py:61-64);
+ *                        sums[2C] + 4096 * sums[2C+1] = N * HW as two exact floats, so that element counts add up
+ *                        through the same float all-reduce.  workspace: eamm_bn_workspace_floats(N, C, HW) floats.
+ *   eamm_bn_finalize     mean[c], scale[c] = inv_std * weight[c] and the running-statistics update (momentum, unbiased
+ *                        variance) of _compute_mean_std (batchnorm.py:110-125).  mode EAMM_BN_SYNC: the replicas' path,
+ *                        inv_std = clamp(biased var, eps)^-0.5; EAMM_BN_SINGLE: F.batch_norm(training=True)
+ *                        (batchnorm.py:48-53), inv_std = 1/sqrt(biased var + eps); EAMM_BN_EVAL: running statistics,
+ *                        nothing updated (sums may be NULL).  weight may be NULL (affine=False).
+ *   eamm_bn_apply        y = (x - mean[c]) * scale[c] + bias[c] (batchnorm.py:74-79); bias may be NULL.
+ */
+#define EAMM_BN_SYNC 0
+#define EAMM_BN_SINGLE 1
+#define EAMM_BN_EVAL 2
+size_t eamm_bn_workspace_floats(int N, int C, int HW);
+int eamm_bn_local_sums(const float* x, int N, int C, int HW, float* sums /*[2C+2]*/, float* workspace, void* stream);
+int eamm_bn_finalize(const float* sums, int C, float eps, float momentum, int mode, const float* weight,
+                     float* running_mean, float* running_var, float* mean /*[C]*/, float* scale /*[C]*/, void* stream);
+int eamm_bn_apply(const float* x, const float* mean, const float* scale, const float* bias, int N, int C, int HW, float* y,
+                  void* stream);
+const char* eamm_bn_last_error(void);
+
+/*
  * Stage timing for roofline accounting (bench.py): while enabled, every eamm_forward_frames call
  * records HIP events on the caller's stream at its stage boundaries and around every bottleneck launch
  * (up to 256 calls between reads).  eamm_profile_read waits for the recorded calls and returns

@@ -247,3 +247,42 @@ def animate_clip(sd, cfg, source_image, kp_source, kp_driving_seq):
             out = generator_forward(sd, cfg, source_image, kp_d, kp_source)
             frames.append(out["prediction"][0].permute(1, 2, 0).contiguous().numpy())
     return frames
+
+
+def sync_batchnorm_forward(shards, weight, bias, running_mean, running_var, eps=1e-5, momentum=0.1, training=True,
+                           parallel=None):
+    """`_SynchronizedBatchNorm.forward` (reference sync_batchnorm/batchnorm.py:46-125) for the list of per-replica
+    inputs `shards` ([N_r,C,H,W] each).  Returns (outputs per replica, new running_mean, new running_var).
+
+    * evaluation, or one replica that is not "parallel": F.batch_norm (batchnorm.py:48-53);
+    * several replicas (`parallel`, default len(shards) > 1): per-replica sum / sum of squares (:61-64), added over the
+      replicas in order (:102 ReduceAddCoalesced), `_compute_mean_std` (:110-125: mean, unbiased variance into the running
+      statistics, inv_std = clamp(biased variance, eps) ** -0.5), then (x - mean) * (inv_std * weight) + bias (:74-79)."""
+    parallel = len(shards) > 1 if parallel is None else parallel
+    rm, rv = running_mean.clone(), running_var.clone()
+    if not (parallel and training):
+        assert len(shards) == 1
+        out = F.batch_norm(shards[0], rm, rv, weight, bias, training, momentum, eps)   # updates rm, rv in place when training
+        return [out], rm, rv
+    c = shards[0].shape[1]
+    flat = [x.reshape(x.shape[0], c, -1) for x in shards]
+    size = sum(v.shape[0] * v.shape[2] for v in flat)
+    sum_ = ssum = None
+    for v in flat:                                                        # device order, as ReduceAddCoalesced adds them
+        s1, s2 = v.sum(dim=0).sum(dim=-1), (v ** 2).sum(dim=0).sum(dim=-1)
+        sum_, ssum = (s1, s2) if sum_ is None else (sum_ + s1, ssum + s2)
+    assert size > 1, 'BatchNorm computes unbiased standard-deviation, which requires size > 1.'
+    mean = sum_ / size
+    sumvar = ssum - sum_ * mean
+    unbias_var, bias_var = sumvar / (size - 1), sumvar / size
+    rm = (1 - momentum) * rm + momentum * mean
+    rv = (1 - momentum) * rv + momentum * unbias_var
+    inv_std = bias_var.clamp(eps) ** -0.5
+    outs = []
+    for x, v in zip(shards, flat):
+        if weight is not None:
+            o = (v - mean[None, :, None]) * (inv_std * weight)[None, :, None] + bias[None, :, None]
+        else:
+            o = (v - mean[None, :, None]) * inv_std[None, :, None]
+        outs.append(o.view(x.shape))
+    return outs, rm, rv

@@ -303,7 +303,82 @@ def deconv_tail_case():
     print("deconv_tail", rep)
 
 
+def batchnorm_case():
+    """Fixture for the training-mode BatchNorm forward (N4, first slice): the reference's own SynchronizedBatchNorm2d
+    (sync_batchnorm/batchnorm.py) -- evaluation, training on one replica (F.batch_norm branch), and training on two
+    replicas with UNEQUAL shards.  The two-replica case runs the reference's real protocol: a master and a slave copy
+    registered through __data_parallel_replicate__, the two forwards on two threads talking through SyncMaster; only the
+    two CUDA-only transport functions (ReduceAddCoalesced / Broadcast) are replaced by their CPU meaning (add / copy)."""
+    import copy
+    import threading
+    import_reference()
+    import sync_batchnorm.batchnorm as ref_bn  # type: ignore
+    from sync_batchnorm.replicate import CallbackContext  # type: ignore
+
+    def reduce_add(dest, n, *ts):   # sum of the per-device groups, in device order
+        groups = [ts[i:i + n] for i in range(0, len(ts), n)]
+        return tuple(sum(g[k] for g in groups[1:]) + groups[0][k] if len(groups) > 1 else groups[0][k] for k in range(n))
+
+    ref_bn.ReduceAddCoalesced = type("ReduceAddCoalesced", (), {"apply": staticmethod(reduce_add)})
+    ref_bn.Broadcast = type("Broadcast", (), {"apply": staticmethod(lambda gpus, *ts: tuple(t.clone() for _ in gpus for t in ts))})
+    rs = np.random.RandomState(5)
+    c, h, w = 40, 12, 16
+    x = torch.from_numpy((rs.standard_normal((6, c, h, w)) * rs.uniform(0.5, 2.0, (1, c, 1, 1)) +
+                          rs.standard_normal((1, c, 1, 1))).astype(np.float32))
+    params = {"weight": torch.from_numpy(rs.uniform(0.5, 1.5, c).astype(np.float32)),
+              "bias": torch.from_numpy((0.2 * rs.standard_normal(c)).astype(np.float32)),
+              "running_mean": torch.from_numpy((0.3 * rs.standard_normal(c)).astype(np.float32)),
+              "running_var": torch.from_numpy(rs.uniform(0.5, 2.0, c).astype(np.float32))}
+
+    def fresh():
+        m = ref_bn.SynchronizedBatchNorm2d(c)
+        with torch.no_grad():
+            m.weight.copy_(params["weight"]); m.bias.copy_(params["bias"])
+            m.running_mean.copy_(params["running_mean"]); m.running_var.copy_(params["running_var"])
+        return m
+
+    blob = {"x": x.numpy(), **{k: v.numpy() for k, v in params.items()}, "split": np.int64(4)}
+    with torch.no_grad():
+        m = fresh().eval()
+        blob["eval_out"] = m(x).numpy()
+        m = fresh().train()
+        blob["single_out"] = m(x).numpy()
+        blob["single_running_mean"], blob["single_running_var"] = m.running_mean.numpy().copy(), m.running_var.numpy().copy()
+        master = fresh().train()
+        slave = copy.deepcopy(master)
+        ctx = CallbackContext()
+        master.__data_parallel_replicate__(ctx, 0)
+        slave.__data_parallel_replicate__(ctx, 1)
+        outs = [None, None]
+
+        def run(i, mod, inp):
+            with torch.no_grad():
+                outs[i] = mod(inp)
+
+        threads = [threading.Thread(target=run, args=(0, master, x[:4])), threading.Thread(target=run, args=(1, slave, x[4:]))]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        blob["sync_out"] = torch.cat(outs, 0).numpy()
+        blob["sync_running_mean"], blob["sync_running_var"] = master.running_mean.numpy().copy(), master.running_var.numpy().copy()
+        # the oracle must reproduce all three
+        o, _, _ = orc.sync_batchnorm_forward([x], params["weight"], params["bias"], params["running_mean"], params["running_var"], training=False)
+        assert float((o[0] - torch.from_numpy(blob["eval_out"])).abs().max()) <= 1e-6
+        o, rm, rv = orc.sync_batchnorm_forward([x], params["weight"], params["bias"], params["running_mean"], params["running_var"])
+        assert float((o[0] - torch.from_numpy(blob["single_out"])).abs().max()) <= 1e-6
+        assert float((rv - torch.from_numpy(blob["single_running_var"])).abs().max()) <= 1e-6
+        o, rm, rv = orc.sync_batchnorm_forward([x[:4], x[4:]], params["weight"], params["bias"], params["running_mean"], params["running_var"])
+        d = float((torch.cat(o, 0) - torch.from_numpy(blob["sync_out"])).abs().max())
+        assert d == 0.0 and torch.equal(rm, torch.from_numpy(blob["sync_running_mean"])) and torch.equal(rv, torch.from_numpy(blob["sync_running_var"])), d
+    assert float(np.abs(blob["sync_out"] - blob["single_out"]).max()) < 1e-4   # same statistics, two formulas for inv_std
+    np.savez_compressed(os.path.join(GOLDEN, "batchnorm_train.npz"), **blob)
+    print("batchnorm_train: wrote", {k: v.shape for k, v in blob.items() if hasattr(v, "shape")})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "batchnorm":
+        os.makedirs(GOLDEN, exist_ok=True)
+        batchnorm_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "smooth":
         os.makedirs(GOLDEN, exist_ok=True)
         smoothing_case()
@@ -339,6 +414,7 @@ def main():
     kp_detector_cases()
     deconv_tail_case()
     smoothing_case()
+    batchnorm_case()
     with open(os.path.join(GOLDEN, "summary.json"), "w") as f:
         json.dump({"torch": torch.__version__, "cases": summary}, f, indent=1, sort_keys=True)
     for name, rep in summary.items():
