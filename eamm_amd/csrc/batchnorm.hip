@@ -19,7 +19,7 @@ namespace eamm {
 namespace {
 constexpr int BN_THREADS = 256;
 
-__device__ __forceinline__ float wave_sum(float v) {
+__device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
@@ -30,26 +30,28 @@ __device__ __forceinline__ float wave_sum(float v) {
 // VEC = 4 needs HW % 4 == 0 (planes then start 16-byte aligned whenever x does).
 template <int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_partial_sums_kernel(const float* __restrict__ x, int N, int C, int HW, int S,
-                                                                      int R, float* __restrict__ partial) {
+                                                                      int R, double* __restrict__ partial) {
     const int c = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
     const int per = (HW / VEC + R - 1) / R;                 // VEC-wide elements per slice
     const int lo = r * per, hi = min(HW / VEC, lo + per);
-    float sum = 0.f, ssum = 0.f;
+    // double accumulators: the kernel is HBM-bound (the fp64 adds ride along), and sum / sum of squares in float lose
+    // the variance of a channel whose mean dwarfs its spread -- ATen's single-replica statistics (mode 1) do not
+    double sum = 0.0, ssum = 0.0;
     for (int n = s; n < N; n += S) {
         const float* plane = x + ((size_t)n * C + c) * HW;
         for (int i = lo + threadIdx.x; i < hi; i += BN_THREADS) {
             if constexpr (VEC == 4) {
                 const float4 v = reinterpret_cast<const float4*>(plane)[i];
-                sum += (v.x + v.y) + (v.z + v.w);
-                ssum = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ssum))));
+                sum += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+                ssum += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
             } else {
                 const float v = plane[i];
-                sum += v;
-                ssum = fmaf(v, v, ssum);
+                sum += (double)v;
+                ssum += (double)v * v;
             }
         }
     }
-    __shared__ float red[2][BN_THREADS / 64];
+    __shared__ double red[2][BN_THREADS / 64];
     sum = wave_sum(sum);
     ssum = wave_sum(ssum);
     if ((threadIdx.x & 63) == 0) {
@@ -58,30 +60,35 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_sums_kernel(const float
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float a = 0.f, b = 0.f;
+        double a = 0.0, b = 0.0;
 #pragma unroll
         for (int w = 0; w < BN_THREADS / 64; ++w) {
             a += red[0][w];
             b += red[1][w];
         }
-        float* dst = partial + ((size_t)c * (S * R) + (s * R + r)) * 2;
+        double* dst = partial + ((size_t)c * (S * R) + (s * R + r)) * 2;
         dst[0] = a;
         dst[1] = b;
     }
 }
 
-// sums[c] = sum, sums[C + c] = sum of squares; sums[2C] + 4096 * sums[2C + 1] = element count per channel (two exact
-// floats, so that the count rides through the same float all-reduce as the sums)
-__global__ void bn_combine_kernel(const float* __restrict__ partial, int C, int P, long long count, float* __restrict__ sums) {
+// sums[c] = sum, sums[C + c] = sum of squares as floats (what the replicas exchange, as the reference does);
+// sums[2C] + 4096 * sums[2C + 1] = element count per channel (two exact floats, so that the count rides through the same
+// float all-reduce as the sums); behind them, at float index 2C + 2, the same 2C totals in double for the
+// single-replica statistics
+__global__ void bn_combine_kernel(const double* __restrict__ partial, int C, int P, long long count, float* __restrict__ sums) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) {
-        double a = 0.0, b = 0.0;   // P values per channel: the order is fixed, the extra width costs nothing
+        double a = 0.0, b = 0.0;   // P values per channel, added in a fixed order
         for (int p = 0; p < P; ++p) {
-            a += (double)partial[((size_t)c * P + p) * 2];
-            b += (double)partial[((size_t)c * P + p) * 2 + 1];
+            a += partial[((size_t)c * P + p) * 2];
+            b += partial[((size_t)c * P + p) * 2 + 1];
         }
         sums[c] = (float)a;
         sums[C + c] = (float)b;
+        double* exact = reinterpret_cast<double*>(sums + 2 * C + 2);
+        exact[c] = a;
+        exact[C + c] = b;
     }
     if (c == 0) {
         sums[2 * C] = (float)(count % 4096);
@@ -112,9 +119,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float 
         unbias_var = sumvar / (size - 1.f);
         const float bias_var = sumvar / size;
         inv_std = powf(fmaxf(bias_var, eps), -0.5f);
-    } else {           // ATen accumulates the batch statistics of a float tensor in double
-        const double m = (double)sum / (double)size;
-        const double sumvar = (double)ssum - (double)sum * m;
+    } else {           // ATen accumulates the batch statistics of a float tensor in double: use the double totals
+        const double* exact = reinterpret_cast<const double*>(sums + 2 * C + 2);
+        const double m = exact[c] / (double)size;
+        const double sumvar = exact[C + c] - exact[c] * m;
         mean = (float)m;
         unbias_var = (float)(sumvar / ((double)size - 1.0));
         inv_std = (float)(1.0 / sqrt(sumvar / (double)size + (double)eps));
@@ -158,18 +166,19 @@ void bn_plan(int N, int C, int HW, int* S, int* R) {
 size_t bn_workspace_floats(int N, int C, int HW) {
     int S, R;
     bn_plan(N, C, HW, &S, &R);
-    return (size_t)C * S * R * 2;
+    return (size_t)C * S * R * 2 * 2;   // (sum, sum of squares) in double per (channel, slice)
 }
 
 hipError_t bn_local_sums_launch(const float* x, int N, int C, int HW, float* sums, float* workspace, hipStream_t s) {
     int S, R;
     bn_plan(N, C, HW, &S, &R);
     const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    double* part = reinterpret_cast<double*>(workspace);   // 8-byte aligned: the caller's allocation is
     if (vec)
-        hipLaunchKernelGGL(bn_partial_sums_kernel<4>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, N, C, HW, S, R, workspace);
+        hipLaunchKernelGGL(bn_partial_sums_kernel<4>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, N, C, HW, S, R, part);
     else
-        hipLaunchKernelGGL(bn_partial_sums_kernel<1>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, N, C, HW, S, R, workspace);
-    hipLaunchKernelGGL(bn_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, C, S * R, (long long)N * HW, sums);
+        hipLaunchKernelGGL(bn_partial_sums_kernel<1>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, N, C, HW, S, R, part);
+    hipLaunchKernelGGL(bn_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, C, S * R, (long long)N * HW, sums);
     return hipGetLastError();
 }
 

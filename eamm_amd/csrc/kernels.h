@@ -168,7 +168,7 @@ hipError_t kp_head_launch(const float* logits /*[B,h,w,Cs]*/, int B, int K, int 
                           float* heatmap /*[B,K,h-6+2pad,w-6+2pad] or null*/, hipStream_t s);
 // ---- training-mode BatchNorm forward (batchnorm.hip; SURVEY.md 8f row N4, first slice)
 size_t bn_workspace_floats(int N, int C, int HW);
-hipError_t bn_local_sums_launch(const float* x /*[N,C,HW]*/, int N, int C, int HW, float* sums /*[2C+2]*/, float* workspace,
+hipError_t bn_local_sums_launch(const float* x /*[N,C,HW]*/, int N, int C, int HW, float* sums /*[6C+2]*/, float* workspace,
                                 hipStream_t s);
 hipError_t bn_finalize_launch(const float* sums, int C, float eps, float momentum, int mode, const float* weight,
                               float* running_mean, float* running_var, float* mean, float* scale, hipStream_t s);

@@ -52,7 +52,7 @@ class HipBatchNormOps:
         n, c = x.shape[0], x.shape[1]
         hw = x.numel() // (n * c)
         L = _lib.lib()
-        sums = torch.empty(2 * c + 2, dtype=torch.float32, device=x.device)
+        sums = torch.empty(6 * c + 2, dtype=torch.float32, device=x.device)   # [2C+2] exchanged floats + 2C doubles
         work = torch.empty(max(1, L.eamm_bn_workspace_floats(n, c, hw)), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _check(L.eamm_bn_local_sums(C.c_void_p(x.data_ptr()), n, c, hw, C.c_void_p(sums.data_ptr()),
@@ -120,7 +120,7 @@ class SynchronizedBatchNorm2d(_BatchNorm):
         parallel = world > 1 if self.sync is None else bool(self.sync)
         sums = self._ops.local_sums(x)                                   # batchnorm.py:61-64
         if world > 1 and parallel:                                       # batchnorm.py:66-70, 102-105
-            self._all_reduce(sums)
+            self._all_reduce(sums[:2 * self.num_features + 2])
         mean, scale = self._ops.finalize(sums, self, BN_SYNC if parallel else BN_SINGLE)   # batchnorm.py:110-125
         return self._ops.apply(x, mean, scale, self.bias)                # batchnorm.py:72-79
 
@@ -137,4 +137,4 @@ class SynchronizedBatchNorm2d(_BatchNorm):
         else:                                                            # gloo (tests): staged through the host
             h = sums.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.process_group)
-            sums.copy_(h)
+            sums.copy_(h)                                                # (a view of the first 2C+2 floats: in place)

@@ -212,7 +212,9 @@ int eamm_deconv_forward(eamm_deconv_ctx* ctx, const float* x, int B, float* out,
  * Stateless: the caller owns every buffer and makes the tensors' device current; work is enqueued on `stream`.
  *   eamm_bn_local_sums   sums[c] = sum over (N, HW) of x[:, c], sums[C + c] = sum of squares (batchnorm.py:61-64);
  *                        sums[2C] + 4096 * sums[2C+1] = N * HW as two exact floats, so that element counts add up
- *                        through the same float all-reduce.  workspace: eamm_bn_workspace_floats(N, C, HW) floats.
+ *                        through the same float all-reduce -- all-reduce THESE 2C+2 floats.  `sums` holds 6C+2 floats:
+ *                        behind the exchanged part sit the same 2C totals in double (8-byte aligned), which
+ *                        EAMM_BN_SINGLE uses.  workspace: eamm_bn_workspace_floats(N, C, HW) floats, 8-byte aligned.
  *   eamm_bn_finalize     mean[c], scale[c] = inv_std * weight[c] and the running-statistics update (momentum, unbiased
  *                        variance) of _compute_mean_std (batchnorm.py:110-125).  mode EAMM_BN_SYNC: the replicas' path,
  *                        inv_std = clamp(biased var, eps)^-0.5; EAMM_BN_SINGLE: F.batch_norm(training=True)
@@ -224,7 +226,7 @@ int eamm_deconv_forward(eamm_deconv_ctx* ctx, const float* x, int B, float* out,
 #define EAMM_BN_SINGLE 1
 #define EAMM_BN_EVAL 2
 size_t eamm_bn_workspace_floats(int N, int C, int HW);
-int eamm_bn_local_sums(const float* x, int N, int C, int HW, float* sums /*[2C+2]*/, float* workspace, void* stream);
+int eamm_bn_local_sums(const float* x, int N, int C, int HW, float* sums /*[6C+2]*/, float* workspace, void* stream);
 int eamm_bn_finalize(const float* sums, int C, float eps, float momentum, int mode, const float* weight,
                      float* running_mean, float* running_var, float* mean /*[C]*/, float* scale /*[C]*/, void* stream);
 int eamm_bn_apply(const float* x, const float* mean, const float* scale, const float* bias, int N, int C, int HW, float* y,

@@ -49,7 +49,8 @@ class OracleOps:
         c = x.shape[1]
         v = x.reshape(x.shape[0], c, -1)
         n = v.shape[0] * v.shape[2]
-        return torch.cat([v.sum(0).sum(-1), (v ** 2).sum(0).sum(-1), torch.tensor([float(n % 4096), float(n // 4096)])])
+        return torch.cat([v.sum(0).sum(-1), (v ** 2).sum(0).sum(-1), torch.tensor([float(n % 4096), float(n // 4096)]),
+                          torch.zeros(4 * c)])
 
     def finalize(self, sums, mod, mode):
         c = mod.num_features
