@@ -30,8 +30,9 @@ struct eamm_ctx : eamm::CtxBase {
     std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
     std::vector<WinoLayer> w4res1, w4res2; // Winograd F(4x4,3x3) packing (bottleneck maps with sides divisible by 4)
     int bneck_chains = 1;                  // 2: bottleneck as two half-batch chains on two streams (EAMM_BNECK_CHAINS)
-    hipStream_t side_stream = nullptr;     // second chain's stream + fork / join events
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipStream_t> side_streams; // the other chains' streams + fork / join events
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
     int wino_tile = 4;                     // preferred output tile (EAMM_WINO_TILE): 4 -> F(4x4) where it applies, 2 -> F(2x2)
     int wino4_variant = 3;                 // wino4_gemm_kernel pipeline variant (3: one DMA piece per 8 MFMAs; 2.062 -> 2.047 ms per step vs one per 4)
     float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] (F(2x2)) or [36][F*hf*wf/16][Cb] transformed activations
@@ -198,8 +199,8 @@ void eamm_destroy(eamm_ctx* c) {
     free_owned(c);
     for (auto& e : c->prof_events) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    for (auto& e : c->ev_join) (void)hipEventDestroy(e);
+    for (auto& st : c->side_streams) (void)hipStreamDestroy(st);
     delete c;
 }
 
@@ -405,10 +406,17 @@ int eamm_finalize_weights(eamm_ctx* c) {
         ff += 9.0 * hwf * c->Cb;  // bilinear feature warp + occlusion multiply
         c->flops_frame = ff;
     }
-    if (c->bneck_chains == 2) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    if (c->bneck_chains > 1) {
+        c->bneck_chains = std::min(c->bneck_chains, 16);
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        for (int k = 1; k < c->bneck_chains; ++k) {
+            hipStream_t st = nullptr;
+            hipEvent_t ev = nullptr;
+            HIP_TRY(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            c->side_streams.push_back(st);
+            HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->ev_join.push_back(ev);
+        }
     }
     c->sd.clear();
     HIP_TRY(c, hipDeviceSynchronize());
@@ -603,25 +611,29 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
             }
         w4g = env_int("EAMM_WINO4_GROUPS", w4g);
     }
-    // Two chains: the frames of a call are independent, so the bottleneck can run as two half-batches on two streams.
-    // Each chain alternates an HBM-bound input transform with an MFMA-bound GEMM that fills half the chip; out of step,
-    // one chain's transform streams through HBM while the other chain's GEMM owns the matrix pipes (EAMM_BNECK_CHAINS).
-    const int chains = (wino4 && w4g == 1 && c->bneck_chains == 2 && c->side_stream && n >= 2 &&
-                        ((n / 2) * (hf / 4) * (wf / 4)) % 64 == 0) ? 2 : 1;
-    if (chains == 2) {
+    // Chains: the frames of a call are independent, so the bottleneck can run as K groups of frames on K streams.  Each
+    // chain alternates an HBM-bound input transform with an MFMA-bound GEMM that fills 1/K of the chip; the chains drift
+    // out of step, so one chain's transform streams through HBM while the others' GEMMs own the matrix pipes -- the
+    // transform time of a chain shrinks with its share of the data instead of idling the whole chip (EAMM_BNECK_CHAINS).
+    int chains = 1;
+    if (wino4 && w4g == 1 && c->bneck_chains > 1 && !c->side_streams.empty()) {
+        chains = std::min<int>(c->bneck_chains, (int)c->side_streams.size() + 1);
+        while (chains > 1 && (n % chains != 0 || ((n / chains) * (hf / 4) * (wf / 4)) % 64 != 0)) --chains;
+    }
+    if (chains > 1) {
         sub = nullptr;   // per-kernel events would time overlapped launches
         const size_t per_frame = (size_t)hf * wf * c->Cb;
+        const int nk = n / chains;
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-        const int n0 = n / 2;
+        for (int k = 1; k < chains; ++k) HIP_TRY(c, hipStreamWaitEvent(c->side_streams[k - 1], c->ev_fork, 0));
         for (int i = 0; i < nr; ++i) {
-            for (int k = 0; k < 2; ++k) {
-                hipStream_t sk = k ? c->side_stream : s;
-                const int f0 = k ? n0 : 0, nk = k ? n - n0 : n0;
+            for (int k = 0; k < chains; ++k) {
+                hipStream_t sk = k ? c->side_streams[k - 1] : s;
+                const size_t f0 = (size_t)k * nk;
                 float* xk = x + f0 * per_frame;
                 float* xnk = xn + f0 * per_frame;
                 float* tk = c->tmp + f0 * per_frame;
-                float* vk = c->wino_v + (size_t)k * 2 * c->cfg.max_frames * per_frame;
+                float* vk = c->wino_v + (size_t)k * 4 * nk * per_frame;   // 2.25 nk frames used of the 4 nk reserved
                 HIP_TRY(c, wino4_transform_launch(xk, c->pre_s[i], c->pre_t[i], nk, hf, wf, c->Cb, vk, sk));
                 HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], vk, nk, hf, wf, ACT_RELU, nullptr, tk, sk, c->wino4_variant, 1, nullptr));
                 HIP_TRY(c, wino4_transform_launch(tk, nullptr, nullptr, nk, hf, wf, c->Cb, vk, sk));
@@ -629,8 +641,10 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
             }
             std::swap(x, xn);
         }
-        HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
-        HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+        for (int k = 1; k < chains; ++k) {
+            HIP_TRY(c, hipEventRecord(c->ev_join[k - 1], c->side_streams[k - 1]));
+            HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0));
+        }
     }
     for (int i = 0; i < nr && wino && chains == 1; ++i) {
         // conv1(relu(norm1(x))): the pre-activation rides on the input transform; norm2 + relu in the epilogue
