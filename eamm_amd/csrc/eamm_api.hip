@@ -618,22 +618,25 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     int chains = 1;
     if (wino4 && w4g == 1 && c->bneck_chains > 1 && !c->side_streams.empty()) {
         chains = std::min<int>(c->bneck_chains, (int)c->side_streams.size() + 1);
-        while (chains > 1 && (n % chains != 0 || ((n / chains) * (hf / 4) * (wf / 4)) % 64 != 0)) --chains;
+        // every chain gets whole frames and a whole number of 64-tile GEMM blocks (frames may be split unevenly)
+        const int tiles_pf = (hf / 4) * (wf / 4);
+        while (chains > 1 && (n < chains || ((n / chains) * tiles_pf) % 64 != 0 || ((n / chains + 1) * tiles_pf) % 64 != 0)) --chains;
     }
     if (chains > 1) {
         sub = nullptr;   // per-kernel events would time overlapped launches
         const size_t per_frame = (size_t)hf * wf * c->Cb;
-        const int nk = n / chains;
+        const int nbase = n / chains, nrem = n % chains;   // the first nrem chains take one more frame
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         for (int k = 1; k < chains; ++k) HIP_TRY(c, hipStreamWaitEvent(c->side_streams[k - 1], c->ev_fork, 0));
         for (int i = 0; i < nr; ++i) {
             for (int k = 0; k < chains; ++k) {
                 hipStream_t sk = k ? c->side_streams[k - 1] : s;
-                const size_t f0 = (size_t)k * nk;
+                const int nk = nbase + (k < nrem ? 1 : 0);
+                const size_t f0 = (size_t)k * nbase + std::min(k, nrem);
                 float* xk = x + f0 * per_frame;
                 float* xnk = xn + f0 * per_frame;
                 float* tk = c->tmp + f0 * per_frame;
-                float* vk = c->wino_v + (size_t)k * 4 * nk * per_frame;   // 2.25 nk frames used of the 4 nk reserved
+                float* vk = c->wino_v + 4 * f0 * per_frame;   // 2.25 nk frames used of the 4 nk reserved for this chain
                 HIP_TRY(c, wino4_transform_launch(xk, c->pre_s[i], c->pre_t[i], nk, hf, wf, c->Cb, vk, sk));
                 HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], vk, nk, hf, wf, ACT_RELU, nullptr, tk, sk, c->wino4_variant, 1, nullptr));
                 HIP_TRY(c, wino4_transform_launch(tk, nullptr, nullptr, nk, hf, wf, c->Cb, vk, sk));
