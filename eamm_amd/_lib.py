@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeamm_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EAMM_OK = 0
 ERR_ARG, ERR_STATE, ERR_KEY, ERR_HIP, ERR_NUMERIC = -1, -2, -3, -4, -5
@@ -73,6 +73,7 @@ SIGNATURES = {
     "eamm_flops_per_frame": (C.c_double, [C.c_void_p]),
     "eamm_bottleneck_form": (C.c_int, [C.c_void_p, C.c_int]),
     "eamm_encode_flops": (C.c_double, [C.c_void_p]),
+    "eamm_bottleneck_chains": (C.c_int, [C.c_void_p, C.c_int]),
     "eamm_kp_create": (C.c_int, [C.POINTER(EammKpConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "eamm_kp_destroy": (None, [C.c_void_p]),
     "eamm_kp_last_error": (C.c_char_p, [C.c_void_p]),

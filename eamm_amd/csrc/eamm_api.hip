@@ -29,7 +29,7 @@ struct eamm_ctx : eamm::CtxBase {
     std::vector<LayerSet> down, hg_enc, hg_dec, res1, res2, up;
     std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
     std::vector<WinoLayer> w4res1, w4res2; // Winograd F(4x4,3x3) packing (bottleneck maps with sides divisible by 4)
-    int bneck_chains = 1;                  // 2: bottleneck as two half-batch chains on two streams (EAMM_BNECK_CHAINS)
+    int bneck_chains = 2;                  // bottleneck as this many chains of frames on as many streams (EAMM_BNECK_CHAINS; 1 = off)
     std::vector<hipStream_t> side_streams; // the other chains' streams + fork / join events
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
@@ -70,7 +70,7 @@ struct eamm_ctx : eamm::CtxBase {
     double flops_frame = 0, flops_encode = 0;
 
     // optional stage timing with HIP events on the caller's stream (bench.py roofline leg)
-    static constexpr int NSTAGE = 9;       // front, hg_enc, hg_dec, head, warp, bneck_transform, bneck_conv, up, final
+    static constexpr int NSTAGE = 10;      // front, hg_enc, hg_dec, head, warp, bneck_transform, bneck_conv, up, final + bneck_gemm_kernel
     static constexpr int NMARK = 8;        // stage boundaries recorded per call (bottleneck is split from sub-events)
     static constexpr int NSUB = 64;        // per-launch events inside the bottleneck (4 per res-block + 1)
     static constexpr int PROF_CALLS = 256; // event sets kept before the host must read them
@@ -472,6 +472,33 @@ static int bottleneck_form(const eamm_ctx* c, int n) {
     return (px >= (size_t)c->wino_min_m && !(hf & 1) && !(wf & 1)) ? 2 : 0;
 }
 
+// F(4x4) with few tiles: split the six rows of transform points over 2, 3 or 6 workgroups per (tile, cout) block --
+// the largest split that still fits one round of the chip (64 x 64 blocks, one per CU)
+static int wino4_groups(const eamm_ctx* c, int n) {
+    const int nb = ((n * (c->hf / 4) * (c->wf / 4) + 63) / 64) * ((c->Cb + 63) / 64);
+    int cus = 256, w4g = 1;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    for (int gsel : {6, 3, 2})
+        if (nb * gsel <= cus) {
+            w4g = gsel;
+            break;
+        }
+    return env_int("EAMM_WINO4_GROUPS", w4g);
+}
+
+// Chains: the frames of a call are independent, so the F(4x4) bottleneck can run as K groups of frames on K streams.
+// Each chain alternates an HBM-bound input transform with an MFMA-bound GEMM that fills 1/K of the chip; while one
+// chain's transform streams through HBM the other chains' GEMMs own the matrix pipes, and a chain's transform moves only
+// its share of the data -- measured at 16 frames, 256x256: bottleneck 2.74 -> 2.50 ms per step with K = 2 (K = 3, 4 lose
+// it again to launch / queue overheads).  Every chain gets whole frames and a whole number of 64-tile GEMM blocks.
+static int bottleneck_chains(const eamm_ctx* c, int n) {
+    if (bottleneck_form(c, n) != 4 || c->bneck_chains < 2 || c->side_streams.empty() || wino4_groups(c, n) != 1) return 1;
+    int chains = std::min<int>(c->bneck_chains, (int)c->side_streams.size() + 1);
+    const int tiles_pf = (c->hf / 4) * (c->wf / 4);
+    while (chains > 1 && (n < chains || ((n / chains) * tiles_pf) % 64 != 0 || ((n / chains + 1) * tiles_pf) % 64 != 0)) --chains;
+    return chains;
+}
+
 int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd_jac, const float* ks_val,
                         const float* ks_jac, const eamm_outputs* o, void* stream_) {
     if (!c || !kd_val || !ks_val || !o || !o->prediction) return fail(c, EAMM_ERR_ARG, "null argument");
@@ -597,33 +624,9 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         if (sub) HIP_TRY(c, hipEventRecord(sub[nsub++], s));     \
     } while (0)
     const bool wino4 = form == 4;
-    // F(4x4) with few tiles: split the six rows of transform points over 2, 3 or 6 workgroups per (tile, cout) block --
-    // the largest split that still fits one round of the chip (64 x 64 blocks, one per CU)
-    int w4g = 1;
-    if (wino4) {
-        const int nb = ((n * (hf / 4) * (wf / 4) + 63) / 64) * ((c->Cb + 63) / 64);
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-        for (int gsel : {6, 3, 2})
-            if (nb * gsel <= cus) {
-                w4g = gsel;
-                break;
-            }
-        w4g = env_int("EAMM_WINO4_GROUPS", w4g);
-    }
-    // Chains: the frames of a call are independent, so the bottleneck can run as K groups of frames on K streams.  Each
-    // chain alternates an HBM-bound input transform with an MFMA-bound GEMM that fills 1/K of the chip; the chains drift
-    // out of step, so one chain's transform streams through HBM while the others' GEMMs own the matrix pipes -- the
-    // transform time of a chain shrinks with its share of the data instead of idling the whole chip (EAMM_BNECK_CHAINS).
-    int chains = 1;
-    if (wino4 && w4g == 1 && c->bneck_chains > 1 && !c->side_streams.empty()) {
-        chains = std::min<int>(c->bneck_chains, (int)c->side_streams.size() + 1);
-        // every chain gets whole frames and a whole number of 64-tile GEMM blocks (frames may be split unevenly)
-        const int tiles_pf = (hf / 4) * (wf / 4);
-        while (chains > 1 && (n < chains || ((n / chains) * tiles_pf) % 64 != 0 || ((n / chains + 1) * tiles_pf) % 64 != 0)) --chains;
-    }
+    const int w4g = wino4 ? wino4_groups(c, n) : 1;
+    const int chains = bottleneck_chains(c, n);
     if (chains > 1) {
-        sub = nullptr;   // per-kernel events would time overlapped launches
         const size_t per_frame = (size_t)hf * wf * c->Cb;
         const int nbase = n / chains, nrem = n % chains;   // the first nrem chains take one more frame
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
@@ -637,13 +640,20 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
                 float* xnk = xn + f0 * per_frame;
                 float* tk = c->tmp + f0 * per_frame;
                 float* vk = c->wino_v + 4 * f0 * per_frame;   // 2.25 nk frames used of the 4 nk reserved for this chain
+                // events around the main stream's (chain 0's) kernels only: they time those launches while the other
+                // chains' run beside them
+                if (k == 0) SUB_MARK();
                 HIP_TRY(c, wino4_transform_launch(xk, c->pre_s[i], c->pre_t[i], nk, hf, wf, c->Cb, vk, sk));
+                if (k == 0) SUB_MARK();
                 HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], vk, nk, hf, wf, ACT_RELU, nullptr, tk, sk, c->wino4_variant, 1, nullptr));
+                if (k == 0) SUB_MARK();
                 HIP_TRY(c, wino4_transform_launch(tk, nullptr, nullptr, nk, hf, wf, c->Cb, vk, sk));
+                if (k == 0) SUB_MARK();
                 HIP_TRY(c, wino4_gemm_launch(c->w4res2[i], vk, nk, hf, wf, ACT_NONE, xk, xnk, sk, c->wino4_variant, 1, nullptr));
             }
             std::swap(x, xn);
         }
+        SUB_MARK();
         for (int k = 1; k < chains; ++k) {
             HIP_TRY(c, hipEventRecord(c->ev_join[k - 1], c->side_streams[k - 1]));
             HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0));
@@ -671,7 +681,7 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         }
         std::swap(x, xn);
     }
-    SUB_MARK();
+    if (chains == 1) SUB_MARK();
 #undef SUB_MARK
     if (sub) c->prof_sub.back() = nsub;
     for (int i = 0; i < nr && !wino; ++i) {
@@ -785,6 +795,11 @@ int eamm_profile_read(eamm_ctx* c, double* stage_ms, int nstage, int64_t* calls,
             }
             ms_set[5] += tr;
             ms_set[6] -= tr;
+            for (int i = 1; ok && i + 1 < nsub; i += 2) {   // the GEMM kernels' own durations on the main stream
+                float ms = 0.f;
+                ok = hipEventElapsedTime(&ms, sub[i], sub[i + 1]) == hipSuccess;
+                ms_set[9] += ms;
+            }
         }
         if (!ok) {
             (void)hipGetLastError();
@@ -864,6 +879,7 @@ int eamm_import_source_cache(eamm_ctx* c, const void* src, int ns, void* stream_
 double eamm_flops_per_frame(const eamm_ctx* c) { return c ? c->flops_frame : 0.0; }
 
 int eamm_bottleneck_form(const eamm_ctx* c, int n) { return (c && n > 0) ? bottleneck_form(c, n) : EAMM_ERR_ARG; }
+int eamm_bottleneck_chains(const eamm_ctx* c, int n) { return (c && n > 0) ? bottleneck_chains(c, n) : EAMM_ERR_ARG; }
 double eamm_encode_flops(const eamm_ctx* c) { return c ? c->flops_encode : 0.0; }
 
 int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int up,

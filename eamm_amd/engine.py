@@ -185,7 +185,7 @@ class Engine:
         self.cache_generation += 1
 
     # -- stage timing (HIP events inside the library, on the stream the kernels run on) -----------------
-    STAGES = ("front", "hg_enc", "hg_dec", "head", "warp", "bneck_transform", "bneck_conv", "up", "final")
+    STAGES = ("front", "hg_enc", "hg_dec", "head", "warp", "bneck_transform", "bneck_conv", "up", "final", "bneck_gemm_kernel")
 
     def profile(self, on: bool = True):
         _lib.check(self._L.eamm_profile_enable(self._ctx, int(on)), self._ctx)
@@ -205,6 +205,10 @@ class Engine:
     def bottleneck_form(self, frames: int) -> int:
         """0 = direct, 2 = Winograd F(2x2,3x3), 4 = Winograd F(4x4,3x3) for a call of ``frames`` frames."""
         return self._L.eamm_bottleneck_form(self._ctx, int(frames))
+
+    def bottleneck_chains(self, frames: int) -> int:
+        """Concurrent launch sequences (streams) the bottleneck of a call of ``frames`` frames is split into."""
+        return self._L.eamm_bottleneck_chains(self._ctx, int(frames))
 
     @property
     def encode_flops(self) -> float:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EAMM_ABI_VERSION 1
+#define EAMM_ABI_VERSION 2
 
 typedef enum eamm_status {
     EAMM_OK = 0,
@@ -136,6 +136,9 @@ double eamm_encode_flops(const eamm_ctx* ctx);
 /* Form the bottleneck ResBlock2d convolutions take for a call of n frames: 0 = direct, 2 = Winograd F(2x2,3x3),
  * 4 = Winograd F(4x4,3x3) (executed multiplies = 1, 4/9, 1/4 of the reference's; negative on a bad handle). */
 int eamm_bottleneck_form(const eamm_ctx* ctx, int n);
+/* Chains the bottleneck of a call of n frames is split into (1 = one launch sequence on the caller's stream; K > 1 =
+ * K groups of whole frames on K streams forked from and joined back into the caller's stream inside the call). */
+int eamm_bottleneck_chains(const eamm_ctx* ctx, int n);
 
 /*
  * ---- key-point detectors -----------------------------------------------
@@ -239,10 +242,12 @@ const char* eamm_bn_last_error(void);
  * (up to 256 calls between reads).  eamm_profile_read waits for the recorded calls and returns
  * accumulated milliseconds per stage: 0 key points + motion front end, 1 hourglass encoder, 2 hourglass
  * decoder, 3 flow head, 4 feature warp, 5 bottleneck Winograd input transforms (0 in the direct form),
- * 6 bottleneck convolution kernels (2 x num_bottleneck_blocks launches), 7 up blocks, 8 final 7x7 +
- * sigmoid (+ uint8 packing).
+ * 6 rest of the bottleneck stage (the convolution kernels; with several chains: the stage's wall time minus the main
+ * stream's transforms), 7 up blocks, 8 final 7x7 + sigmoid (+ uint8 packing) -- stages 0..8 add up to the call --
+ * and 9 the bottleneck GEMM kernels' own durations on the main stream (2 x num_bottleneck_blocks launches per call;
+ * with K chains each of those launches covers 1/K of the frames and runs beside the other chains' launches).
  */
-#define EAMM_NSTAGE 9
+#define EAMM_NSTAGE 10
 int eamm_profile_enable(eamm_ctx* ctx, int on);
 int eamm_profile_read(eamm_ctx* ctx, double* stage_ms, int nstage, int64_t* calls, int64_t* frames, int reset);
 
