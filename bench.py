@@ -58,7 +58,7 @@ def kernel_source_digest(form):
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def measured_traffic(form, size, batch):
+def measured_traffic(form, size, batch, chains=1):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 per the
     gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE) -- (bytes, source) or (None, reason).  A record counts only for
     the (size, batch) it was taken at and while the kernel's source file is byte-identical to the profiled one."""
@@ -67,9 +67,9 @@ def measured_traffic(form, size, batch):
             table = json.load(f)
     except (OSError, ValueError):
         return None, f"{os.path.relpath(TRAFFIC_FILE, ROOT)} missing"
-    rec = table.get(f"form{form}_{size}x{size}_b{batch}")
+    rec = table.get(f"form{form}_{size}x{size}_b{batch}_c{chains}")
     if rec is None:
-        return None, f"no PMC record for form {form} at {size}x{size} batch {batch}"
+        return None, f"no PMC record for form {form} at {size}x{size} batch {batch} with {chains} chain(s)"
     if rec.get("source_sha256_16") != kernel_source_digest(form):
         return None, f"PMC record of {rec.get('files')} predates the current {KERNEL_SOURCES[form]}"
     return int((rec["fetch_size_kb"] * 2 + rec["write_size_kb"]) * 1024), rec.get("files")
@@ -277,18 +277,28 @@ def main():
         form = eng.bottleneck_form(B)          # 0 direct, 2 Winograd F(2x2,3x3), 4 Winograd F(4x4,3x3)
         algo_flop = 2.0 * (B * hf * hf) * cb * (9 * cb)
         exec_flop = algo_flop * {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0}[form]
-        # With K chains (eamm_bottleneck_chains) a bottleneck launch on the main stream covers 1/K of the frames and runs
-        # beside the other chains' launches, each on its share of the CUs: the chip-level rate of the dominant kernel is
-        # the K concurrent launches' work over one launch's duration.
+        # With K chains (eamm_bottleneck_chains) a bottleneck launch on the main stream covers 1/K of the frames and may run
+        # beside the other chains' launches.  The Winograd GEMM runs one 64x64 block per CU, so a launch of fewer blocks
+        # than CUs can use at most blocks/CUs of the chip's matrix pipes: `peak` is scaled to the CUs the launch can
+        # occupy (256x256, batch 16, 2 chains: 128 blocks = half the chip, the other half runs the other chain).
         chains = eng.bottleneck_chains(B)
         kernel_ms = prof["ms"].pop("bneck_gemm_kernel")          # GEMM kernels' own durations (not a stage of the sum)
         ms_conv = (kernel_ms if form != 0 else prof["ms"]["bneck_conv"]) / launches if prof["calls"] else float("nan")
+        algo_flop /= chains                                       # per launch
+        exec_flop /= chains
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        if form == 4:
+            blocks = -(-(B // chains) * (hf // 4) * (hf // 4) // 64) * -(-cb // 64)
+        else:
+            blocks = cus
+        cu_share = min(1.0, blocks / cus)
+        peak = FP32_MFMA_PEAK_TFLOPS * cu_share
         ms_tr = prof["ms"]["bneck_transform"] / launches if prof["calls"] else 0.0
         achieved = exec_flop / (ms_conv * 1e-3) / 1e12
         ms_stage = (prof["ms"]["bneck_conv"] + prof["ms"]["bneck_transform"]) / launches if prof["calls"] else float("nan")
-        algo = algo_flop / (ms_stage * 1e-3) / 1e12
+        algo = algo_flop * chains / (ms_stage * 1e-3) / 1e12     # whole bottleneck stage (all chains, transforms included)
         total_ms = sum(prof["ms"].values())
-        traffic, traffic_src = measured_traffic(form, S, B)
+        traffic, traffic_src = measured_traffic(form, S, B, chains)
         which = "configs[2]" if (S, B) == (256, 16) else ("configs[4]" if (S, B) == (512, 8) else "a non-BASELINE size")
         line = {
             "metric": "256x256 frames/sec (dense-motion + generator forward)" if S == 256 else f"{S}x{S} frames/sec",
@@ -303,17 +313,19 @@ def main():
                          "kernel": {4: f"wino4_gemm_kernel<2,4,2,...> (bottleneck 3x3 {cb}->{cb} @{hf}x{hf} in Winograd F(4x4,3x3) form)",
                                     2: f"wino_gemm_kernel<1,2,4,2> (bottleneck 3x3 {cb}->{cb} @{hf}x{hf} in Winograd F(2x2,3x3) form)",
                                     0: f"conv_mfma_dma_kernel<3,3,...> (bottleneck 3x3 {cb}->{cb} @{hf}x{hf}, direct)"}[form],
-                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "achieved": round(achieved, 2), "peak": round(peak, 2), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4),
+                         "chip_peak": FP32_MFMA_PEAK_TFLOPS, "launch_blocks": blocks, "cus": cus,
                          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "avg_launch_ms": round(ms_conv, 4), "concurrent_launches": chains,
-                         "executed_gflop_per_launch": round(exec_flop / chains / 1e9, 2),
-                         "note": (f"{chains} launches run concurrently (one per chain of {B // chains} frames, each on its share of the "
-                                  f"CUs); achieved = {chains} x executed_gflop_per_launch / avg_launch_ms") if chains > 1 else
+                         "avg_launch_ms": round(ms_conv, 4), "chains": chains,
+                         "executed_gflop_per_launch": round(exec_flop / 1e9, 2),
+                         "note": (f"achieved = executed_gflop_per_launch / avg_launch_ms of the main stream's launches ({B // chains} "
+                                  f"frames each, {blocks} one-per-CU blocks); peak = chip_peak x min(1, launch_blocks / cus); the other "
+                                  f"{chains - 1} chain(s) run on their own streams beside it") if chains > 1 else
                                  "one launch at a time; achieved = executed_gflop_per_launch / avg_launch_ms",
                          "achieved_algorithmic": round(algo, 2),
-                         "frac_algorithmic": round(algo / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "algorithmic_gflop_per_launch": round(algo_flop / chains / 1e9, 2),
+                         "frac_algorithmic": round(algo / FP32_MFMA_PEAK_TFLOPS, 4),   # whole stage vs the CHIP peak
+                         "algorithmic_gflop_per_launch": round(algo_flop / 1e9, 2),
                          "avg_input_transform_ms": round(ms_tr, 4),
                          "bottleneck_stage_ms_per_conv": round(ms_stage, 4),
                          "whole_path_tflops_algorithmic": round(fps / world * eng.flops_per_frame / 1e12, 2)},

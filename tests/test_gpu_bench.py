@@ -32,7 +32,9 @@ def test_bench_single_gpu_line():
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - 10 * 16 / (d["ms_per_step"] * 10e-3)) / d["value"] < 0.01   # value == frames / timed seconds
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["chip_peak"] == 157.3
+    assert abs(r["peak"] - 157.3 * min(1.0, r["launch_blocks"] / r["cus"])) < 0.01          # the CUs one launch can occupy
+    assert abs(r["achieved"] - r["executed_gflop_per_launch"] / r["avg_launch_ms"]) / r["achieved"] < 0.01
     assert 0.3 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(sum(d["stage_ms_per_step"].values()) - d["ms_per_step"]) / d["ms_per_step"] < 0.05  # events ~ wall clock
     w = d["roofline_warp"]

@@ -4,7 +4,7 @@ MI355X_MICROARCH.md "rocprofv3 PMC slots") into profiles/pmc_traffic.json, the t
 from.  A record is keyed by (bottleneck form, size, batch) and carries the digest of the dominant kernel's source file,
 so bench.py can tell whether the kernel it is running is the one that was profiled.
 
-    python tools/pmc_traffic.py <fetch_results.db> <write_results.db> <size> <batch> [label] [out.json]
+    python tools/pmc_traffic.py <fetch_results.db> <write_results.db> <size> <batch> [label] [out.json] [chains]
 
 Run on the GPU box after tools/gpu_profile.sh (which makes the two passes); commit the json with the summaries.
 """
@@ -32,6 +32,7 @@ def main():
     fetch_db, write_db, size, batch = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     label = sys.argv[5] if len(sys.argv) > 5 else ""
     out = sys.argv[6] if len(sys.argv) > 6 else OUT   # on the GPU box only gpurun_out/ travels back: write there, copy later
+    chains = int(sys.argv[7]) if len(sys.argv) > 7 else 1   # bottleneck chains of the profiled run (frames per launch = batch / chains)
     fetch, write = counters(fetch_db, "FETCH_SIZE"), counters(write_db, "WRITE_SIZE")
     table = {}
     if os.path.exists(OUT):
@@ -44,7 +45,8 @@ def main():
         name = max(names, key=lambda k: fetch[k][0] * fetch[k][2])   # the variant that took the most time
         with open(os.path.join(ROOT, "eamm_amd", "csrc", src), "rb") as f:
             digest = hashlib.sha256(f.read()).hexdigest()[:16]
-        table[f"form{form}_{size}x{size}_b{batch}"] = {
+        table[f"form{form}_{size}x{size}_b{batch}_c{chains}"] = {
+            "frames_per_launch": batch // chains if form != 0 else None,
             "kernel": name, "launches_profiled": fetch[name][0],
             "fetch_size_kb": round(fetch[name][1], 1), "write_size_kb": round(write[name][1], 1),
             "hbm_bytes_per_launch": int((fetch[name][1] * 2 + write[name][1]) * 1024),
