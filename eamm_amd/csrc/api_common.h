@@ -33,6 +33,8 @@ thread_local std::string g_create_error;
 // big-tile kernel; conv launches pick by problem size (see pick()).
 struct LayerSet {
     ConvLayer base, dma, big;
+    ConvLayer skinny32, skinny64;   // S.dma's weights (N tile 128) behind the 32- / 64-row LDS-DMA tiles: M <= 32 / 64
+    bool has_skinny = false;
     PatchLayer patch;           // UpBlock2d layers only: spatial-patch kernel (conv_mfma_patch.hip)
     bool has_dma = false, has_big = false, has_patch = false;
 };
@@ -51,6 +53,7 @@ struct CtxBase {
     int big_min_m = 49152;      // ... and for which Cout % 256 == 0 layers use the 256x256 tile (>= 192 M tiles)
     int dma_cfg_n256 = 2, dma_cfg_n128 = 2, dma_cfg_n64 = 3;
     int patch_wino = 1;         // up blocks on the patch kernel in Winograd F(2x2,2x2) form (EAMM_PATCH_WINO)
+    int skinny_max_m = 64;      // largest per-phase pixel count served by the 32- / 64-row tiles (EAMM_SKINNY_MAX_M; 0 = off)
     int patch_min_blocks = 192; // fewest workgroups for which UpBlock2d layers use the spatial-patch kernel (< 0: never)
 };
 
@@ -271,6 +274,15 @@ int build_set(CtxBase* c, const std::vector<FoldSpec>& parts, int C0_real, int C
         rc = build_layer(c, parts, 3, C0_real, C0_packed, C1_real, C1_packed, &S->dma, mode, nullptr, cfg);
         if (rc) return rc;
         S->has_dma = true;
+        if (S->dma.BN == 128 && c->skinny_max_m > 0) {   // same packed weights, small-M tiles (conv_dma_tile ids 4, 5)
+            S->skinny32 = S->dma;
+            S->skinny64 = S->dma;
+            S->skinny32.dma_cfg = 4;
+            S->skinny64.dma_cfg = 5;
+            conv_dma_tile(4, &S->skinny32.BM, &S->skinny32.BN);
+            conv_dma_tile(5, &S->skinny64.BM, &S->skinny64.BN);
+            S->has_skinny = true;
+        }
         if (Cout % 256 == 0 && cfg != 1 && c->big_min_m >= 0) {
             rc = build_layer(c, parts, 3, C0_real, C0_packed, C1_real, C1_packed, &S->big, mode, nullptr, 1);
             if (rc) return rc;
@@ -322,6 +334,8 @@ int build_wino(CtxBase* c, const std::string& conv, const std::string& norm, int
 }
 
 const ConvLayer& pick(const CtxBase* c, const LayerSet& S, size_t M) {
+    // skinny GEMMs (deep hourglass levels at small batches): the weight stream is the cost, so tiles without padding rows
+    if (S.has_skinny && M <= (size_t)c->skinny_max_m) return M <= 32 ? S.skinny32 : S.skinny64;
     if (S.has_big && M >= (size_t)c->big_min_m) return S.big;
     return (S.has_dma && M >= (size_t)c->dma_min_m) ? S.dma : S.base;
 }
@@ -361,6 +375,7 @@ inline void read_tile_knobs(CtxBase* c) {
     c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);
     c->dma_cfg_n64 = env_int("EAMM_DMA_CFG_N64", c->dma_cfg_n64);
     c->patch_min_blocks = env_int("EAMM_PATCH_MIN_BLOCKS", c->patch_min_blocks);
+    c->skinny_max_m = env_int("EAMM_SKINNY_MAX_M", c->skinny_max_m);
 }
 
 inline void free_owned(CtxBase* c) {

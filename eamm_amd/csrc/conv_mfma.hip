@@ -256,6 +256,8 @@ bool conv_dma_tile(int dma_cfg, int* BM, int* BN) {
         case 1: *BM = 256; *BN = 256; return true;   // 8 waves, 64x128 per wave
         case 2: *BM = 256; *BN = 128; return true;   // 8 waves, 64x64 per wave
         case 3: *BM = 512; *BN = 64; return true;    // 8 waves, 64x64 per wave
+        case 4: *BM = 32; *BN = 128; return true;    // 4 waves, 32x32 per wave: skinny GEMMs (M <= 32: weights streamed once,
+        case 5: *BM = 64; *BN = 128; return true;    //          64x32 per wave: M <= 64   no MFMA passes over padding rows)
         default: return false;
     }
 }
@@ -319,7 +321,7 @@ ConvPlan conv_plan(const ConvLayer& L, int M, int force_splits) {
     } else if (blocks < 192) {
         // deep hourglass levels / small batches: too few output tiles for 256 CUs -> slice K instead
         splits = (256 + blocks - 1) / blocks;
-        splits = std::min(splits, std::max(1, L.nchunks / 8));
+        splits = std::min(splits, std::max(1, L.nchunks / (BM <= 64 ? 4 : 8)));   // skinny tiles: short K slices are fine
     }
     splits = std::max(1, std::min(splits, L.nchunks));
     pl.chunks_per_split = (L.nchunks + splits - 1) / splits;

@@ -138,9 +138,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_dma_kernel(const ConvAr
     // MFMAs of chunk `st`; when `more`, the DMA pieces of the NEXT chunk are issued one every PIECE_EVERY MFMAs
     // from the start of the chunk: they hide in the matrix pipe's shadow instead of idling it after the
     // barrier, and the rest of the chunk's MFMAs cover their flight time before the vmcnt(0).
-    constexpr int HALF_MFMAS = 2 * 4 * MT * NT;
-    constexpr int PIECE_EVERY = HALF_MFMAS / NPIECE < 4 ? HALF_MFMAS / NPIECE : 4;
-    static_assert(PIECE_EVERY >= 2, "DMA pieces must fit in the first half of the chunk");
+    // (the skinny tiles have few MFMAs per chunk: their pieces spread over the whole chunk)
+    constexpr int HALF_MFMAS = 2 * 4 * MT * NT, ALL_MFMAS = 2 * HALF_MFMAS;
+    constexpr int PIECE_EVERY = HALF_MFMAS / NPIECE >= 2 ? (HALF_MFMAS / NPIECE < 4 ? HALF_MFMAS / NPIECE : 4) : ALL_MFMAS / NPIECE;
+    static_assert(PIECE_EVERY >= 1 && PIECE_EVERY * NPIECE <= ALL_MFMAS, "DMA pieces must fit in the chunk");
     auto compute = [&](int st, bool more) {
         const float* a_base = As + st * A_STAGE + (wm * MT * 32 + l31) * BK;
         const float* b_base = Bs + st * B_STAGE + (wn * NT * 32 + l31) * BK;
@@ -214,6 +215,8 @@ static hipError_t launch_dma_tile(int BM, int BN, const ConvArgs& a, int blocks,
     if (BM == 256 && BN == 256) return launch_dma_cfg<KH, KW, 2, 4, 4, 2, PHASE>(a, blocks, stream);
     if (BM == 256 && BN == 128) return launch_dma_cfg<KH, KW, 2, 2, 4, 2, PHASE>(a, blocks, stream);
     if (BM == 512 && BN == 64) return launch_dma_cfg<KH, KW, 2, 2, 8, 1, PHASE>(a, blocks, stream);
+    if (BM == 32 && BN == 128) return launch_dma_cfg<KH, KW, 1, 1, 1, 4, PHASE>(a, blocks, stream);
+    if (BM == 64 && BN == 128) return launch_dma_cfg<KH, KW, 2, 1, 1, 4, PHASE>(a, blocks, stream);
     return hipErrorInvalidValue;  // keep in sync with conv_dma_tile()
 }
 

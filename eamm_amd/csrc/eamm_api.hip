@@ -368,6 +368,10 @@ int eamm_finalize_weights(eamm_ctx* c) {
             upd1(S.base, M);
             if (S.has_dma) upd1(S.dma, M);
             if (S.has_big) upd1(S.big, M);
+            if (S.has_skinny) {
+                upd1(S.skinny32, M);
+                upd1(S.skinny64, M);
+            }
         };
         for (size_t f = 1; f <= S; ++f) {
             upd1(c->first, f * HW);

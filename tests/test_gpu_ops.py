@@ -93,6 +93,14 @@ CASES = {
     "dma256x128_up":     dict(B=1, H=16, W=16, C0=64, C1=0, Cout=128, ks=3, up=1, act=1, tile_n=1002),
     "dma512x64":         dict(B=2, H=16, W=20, C0=32, C1=0, Cout=64, ks=3, act=1, tile_n=1003),
     "dma512x64_up":      dict(B=1, H=16, W=16, C0=128, C1=0, Cout=64, ks=3, up=1, act=1, tile_n=1003),
+    # skinny LDS-DMA tiles (1004: 32x128, 1005: 64x128) of the deep hourglass levels at small batches
+    "skinny32_enc4_like":  dict(B=1, H=4, W=4, C0=256, C1=0, Cout=256, ks=3, act=1, pool=1, tile_n=1004),
+    "skinny32_dec0_like":  dict(B=2, H=2, W=2, C0=128, C1=0, Cout=256, ks=3, up=1, act=1, tile_n=1004),
+    "skinny32_dec1_like":  dict(B=1, H=4, W=4, C0=128, C1=64, Cout=128, ks=3, up=1, act=1, tile_n=1004),
+    "skinny32_mtail":      dict(B=1, H=5, W=5, C0=32, C1=0, Cout=136, ks=3, act=1, tile_n=1004),
+    "skinny64_enc3_like":  dict(B=1, H=8, W=8, C0=128, C1=0, Cout=256, ks=3, act=1, pool=1, tile_n=1005),
+    "skinny64_dec2_like":  dict(B=1, H=8, W=8, C0=64, C1=64, Cout=128, ks=3, up=1, act=1, tile_n=1005),
+    "skinny64_splitk5":    dict(B=3, H=4, W=4, C0=160, C1=0, Cout=128, ks=3, resid=True, splitk=5, tile_n=1005),
     "dma256_bottleneck": dict(B=4, H=64, W=64, C0=256, C1=0, Cout=256, ks=3, resid=True, tile_n=1001),
     # column-patch kernel of the final layer's 7x1 convolution (tile_n = 4000): N = 32-float pixel stride
     "col7_final_like":   dict(B=2, H=32, W=32, C0=64, C1=0, Cout=32, ks=7, kw=1, tile_n=4000, zero_bias=True),
