@@ -30,6 +30,8 @@ struct eamm_ctx : eamm::CtxBase {
     std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
     std::vector<WinoLayer> w4res1, w4res2; // Winograd F(4x4,3x3) packing (bottleneck maps with sides divisible by 4)
     int bneck_chains = 2;                  // bottleneck as this many chains of frames on as many streams (EAMM_BNECK_CHAINS; 1 = off)
+    int pass_chains = 2;                   // the whole per-frame pass as this many chains (EAMM_PASS_CHAINS; 1 = off)
+    int pass_chains_min_frames = 8;        // ... from this many frames per call (EAMM_PASS_CHAINS_MIN_FRAMES)
     std::vector<hipStream_t> side_streams; // the other chains' streams + fork / join events
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
@@ -184,6 +186,8 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->wino_tile = env_int("EAMM_WINO_TILE", c->wino_tile);
     c->col7 = env_int("EAMM_COL7", c->col7);
     c->bneck_chains = env_int("EAMM_BNECK_CHAINS", c->bneck_chains);
+    c->pass_chains = env_int("EAMM_PASS_CHAINS", c->pass_chains);
+    c->pass_chains_min_frames = env_int("EAMM_PASS_CHAINS_MIN_FRAMES", c->pass_chains_min_frames);
     c->head_col7_min_tiles = env_int("EAMM_HEAD_COL7_MIN_TILES", c->head_col7_min_tiles);
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
@@ -387,8 +391,8 @@ int eamm_finalize_weights(eamm_ctx* c) {
             for (int i = 0; i < c->nd; ++i) upd(c->up[i], f * (hwf << (2 * i)));
             upd1(c->final_conv, f * HW);
         }
-        c->partial_elems = need;
-        if ((rc = dev_alloc(c, &c->partial, c->partial_elems))) return rc;
+        c->partial_elems = need;   // one slab per whole-pass chain
+        if ((rc = dev_alloc(c, &c->partial, c->partial_elems * (size_t)std::max(1, std::min(env_int("EAMM_PASS_CHAINS", c->pass_chains), 4))))) return rc;
     }
 
     // ---- algorithmic FLOPs (reference layer shapes, real channel counts)
@@ -410,10 +414,11 @@ int eamm_finalize_weights(eamm_ctx* c) {
         ff += 9.0 * hwf * c->Cb;  // bilinear feature warp + occlusion multiply
         c->flops_frame = ff;
     }
-    if (c->bneck_chains > 1) {
-        c->bneck_chains = std::min(c->bneck_chains, 16);
+    c->bneck_chains = std::max(1, std::min(c->bneck_chains, 16));
+    c->pass_chains = std::max(1, std::min(c->pass_chains, 4));
+    if (std::max(c->bneck_chains, c->pass_chains) > 1) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        for (int k = 1; k < c->bneck_chains; ++k) {
+        for (int k = 1; k < std::max(c->bneck_chains, c->pass_chains); ++k) {
             hipStream_t st = nullptr;
             hipEvent_t ev = nullptr;
             HIP_TRY(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -503,32 +508,89 @@ static int bottleneck_chains(const eamm_ctx* c, int n) {
     return chains;
 }
 
-int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd_jac, const float* ks_val,
-                        const float* ks_jac, const eamm_outputs* o, void* stream_) {
-    if (!c || !kd_val || !ks_val || !o || !o->prediction) return fail(c, EAMM_ERR_ARG, "null argument");
-    if (!c->finalized) return fail(c, EAMM_ERR_STATE, "call eamm_finalize_weights first");
-    if (c->ns_cached < 1) return fail(c, EAMM_ERR_STATE, "no source cached: call eamm_encode_source first");
-    if (n < 1 || n > c->cfg.max_frames) return fail(c, EAMM_ERR_ARG, "n=%d outside [1,%d]", n, c->cfg.max_frames);
-    if (kd_jac != nullptr && ks_jac == nullptr)
-        return fail(c, EAMM_ERR_ARG, "kp_driving jacobian given without kp_source jacobian");
-    const int ns = c->ns_cached;
-    if (ns != 1 && ns != n) return fail(c, EAMM_ERR_ARG, "%d cached sources cannot serve %d frames (need 1 or n)", ns, n);
-    if ((o->occlusion_map) && !c->cfg.estimate_occlusion_map)
-        return fail(c, EAMM_ERR_ARG, "occlusion_map requested but estimate_occlusion_map is off");
-    DeviceGuard guard(c->device);
-    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+// The slice of the per-frame workspace one launch sequence works on: frames [f0, f0 + n) of a call (every per-frame
+// buffer is frame-major, so a slice is a pointer offset) with its own split-K slab and Winograd buffers.
+struct FrameView {
+    int n = 0, ns = 1;
+    const float *kd_val = nullptr, *kd_jac = nullptr, *ks_val = nullptr, *ks_jac = nullptr;
+    const float *feat = nullptr, *src_small = nullptr, *src_full = nullptr;
+    float *kp_rec = nullptr, *hg_in = nullptr, *logits = nullptr, *deformation = nullptr, *occlusion = nullptr;
+    float *xa = nullptr, *xb = nullptr, *act = nullptr, *tmp = nullptr, *final_part = nullptr;
+    std::vector<float*> e_buf, u_buf, up_buf;
+    float* partial = nullptr;
+    size_t partial_elems = 0;
+    float *wino_v = nullptr, *wino_z = nullptr;
+    eamm_outputs out{};
+};
+
+static FrameView make_view(const eamm_ctx* c, int f0, int n, int ns_call, int slab, const float* kd_val, const float* kd_jac,
+                           const float* ks_val, const float* ks_jac, const eamm_outputs* o) {
+    FrameView v;
+    const size_t F = (size_t)f0, K = c->K;
+    const size_t HW = (size_t)c->H * c->W, hw = (size_t)c->h * c->w, hwf = (size_t)c->hf * c->wf;
+    const size_t sf = ns_call > 1 ? F : 0;   // per-frame sources (the module's batch contract) move with the frames
+    v.n = n;
+    v.ns = ns_call > 1 ? n : 1;
+    v.kd_val = kd_val + F * K * 2;
+    v.kd_jac = kd_jac ? kd_jac + F * K * 4 : nullptr;
+    v.ks_val = ks_val + sf * K * 2;
+    v.ks_jac = ks_jac ? ks_jac + sf * K * 4 : nullptr;
+    v.feat = c->feat + sf * hwf * c->Cb;
+    v.src_small = c->src_small + sf * hw * 4;
+    v.src_full = c->src_full + sf * 3 * HW;
+    v.kp_rec = c->kp_rec + F * K * KP_STRIDE;
+    v.hg_in = c->hg_in + F * hw * c->Cp0;
+    for (int i = 0; i < c->nb; ++i) {
+        v.e_buf.push_back(c->e_buf[i] + F * (hw >> (2 * (i + 1))) * c->enc_c[i]);
+        v.u_buf.push_back(c->u_buf[i] + F * (hw >> (2 * (c->nb - 1 - i))) * c->dec_c[i]);
+    }
+    v.logits = c->logits + F * hw * (c->head_nc ? 128 : 32);
+    v.deformation = c->deformation + F * hw * 2;
+    v.occlusion = c->occlusion + F * hw;
+    v.xa = c->xa + F * hwf * c->Cb;
+    v.xb = c->xb + F * hwf * c->Cb;
+    v.act = c->act + F * hwf * c->Cb;
+    v.tmp = c->tmp + F * hwf * c->Cb;
+    for (int i = 0; i < c->nd; ++i) v.up_buf.push_back(c->up_buf[i] + F * (hwf << (2 * (i + 1))) * c->up_c[i]);
+    v.final_part = c->final_part + F * HW * 32;
+    v.partial = c->partial + (size_t)slab * c->partial_elems;
+    v.partial_elems = c->partial_elems;
+    v.wino_v = c->wino_v ? c->wino_v + 4 * F * hwf * c->Cb : nullptr;                  // sized 4 x activations per frame
+    v.wino_z = c->wino_z ? c->wino_z + 24 * (F * hwf / 16) * c->Cb : nullptr;
+    v.out = *o;
+    if (o->prediction) v.out.prediction = o->prediction + F * 3 * HW;
+    if (o->mask) v.out.mask = o->mask + F * (K + 1) * hw;
+    if (o->sparse_deformed) v.out.sparse_deformed = o->sparse_deformed + F * (K + 1) * 3 * hw;
+    if (o->occlusion_map) v.out.occlusion_map = o->occlusion_map + F * hw;
+    if (o->deformed) v.out.deformed = o->deformed + F * 3 * HW;
+    if (o->deformation) v.out.deformation = o->deformation + F * hw * 2;
+    if (o->frames_u8) v.out.frames_u8 = o->frames_u8 + F * HW * 3;
+    return v;
+}
+
+// Chains over the WHOLE per-frame pass: the frames of a call are independent, so a call of n frames can run as K launch
+// sequences of n/K frames on K streams.  The sequences drift apart (the host enqueues them one after the other), and the
+// chip then runs one chain's HBM- or latency-bound kernels (input transforms, warps, the small-grid deep hourglass levels
+// and their split-K reductions) beside the other chain's MFMA-bound ones.  Needs the F(4x4) bottleneck with whole 64-tile
+// GEMM blocks per chain; EAMM_PASS_CHAINS (0 / 1 = off).
+static int pass_chains(const eamm_ctx* c, int n) {
+    if (c->pass_chains < 2 || (int)c->side_streams.size() + 1 < c->pass_chains) return 1;
+    const int K = c->pass_chains;
+    const int tiles_pf = (c->hf / 4) * (c->wf / 4);
+    if (n < c->pass_chains_min_frames || n < K) return 1;
+    for (int k = 0; k < 2; ++k) {   // both chain sizes (n/K and n/K + 1 when n % K != 0)
+        const int nk = n / K + k;
+        if (k == 1 && n % K == 0) break;
+        if (bottleneck_form(c, nk) != 4 || (nk * tiles_pf) % 64 != 0) return 1;
+    }
+    return K;
+}
+
+// One launch sequence over the frames of `v` on stream s.  `chained`: another sequence runs beside this one.
+static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent_t* ev, bool chained) {
+    const int n = v.n, ns = v.ns;
     const int h = c->h, w = c->w, hf = c->hf, wf = c->wf, K = c->K;
     const bool occ = c->cfg.estimate_occlusion_map != 0;
-
-    hipEvent_t* ev = nullptr;  // stage boundaries, recorded only while profiling
-    if (c->profiling && c->prof_used < eamm_ctx::PROF_CALLS) {
-        ev = c->prof_events.data() + (size_t)c->prof_used * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB);
-        c->prof_n.push_back(n);
-        c->prof_sub.push_back(0);
-        c->prof_marks.push_back(0);
-        ++c->prof_used;
-    }
 #define STAGE_MARK(i)                                  \
     do {                                               \
         if (ev) {                                      \
@@ -538,74 +600,74 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     } while (0)
     STAGE_MARK(0);
     // key-point records; 'jacobian' missing from kp_driving => identity (dense_motion.py:55)
-    HIP_TRY(c, kp_prepare_launch(kd_val, kd_jac, ks_val, kd_jac ? ks_jac : nullptr, n, ns, K, c->kp_rec, c->bad_flag, s));
+    HIP_TRY(c, kp_prepare_launch(v.kd_val, v.kd_jac, v.ks_val, v.kd_jac ? v.ks_jac : nullptr, n, ns, K, v.kp_rec, c->bad_flag, s));
     // heat-maps + sparse motions + K+1 warped sources -> hourglass input     dense_motion.py:88-94
-    HIP_TRY(c, motion_front_launch(c->kp_rec, c->src_small, n, ns, K, h, w, c->cfg.kp_variance, c->Cp0, c->hg_in,
-                                   o->sparse_deformed, s));
+    HIP_TRY(c, motion_front_launch(v.kp_rec, v.src_small, n, ns, K, h, w, c->cfg.kp_variance, c->Cp0, v.hg_in,
+                                   v.out.sparse_deformed, s));
     STAGE_MARK(1);
     // hourglass encoder                                                       util.py:956-960
     for (int i = 0; i < c->nb; ++i) {
         ConvIO io{};
-        io.in0 = i == 0 ? c->hg_in : c->e_buf[i - 1];
+        io.in0 = i == 0 ? v.hg_in : v.e_buf[i - 1];
         io.B = n;
         io.Hin = h >> i;
         io.Win = w >> i;
         io.act = ACT_RELU;
         io.pool = 1;
-        io.out = c->e_buf[i];
-        io.partial = c->partial;
-        io.partial_cap = c->partial_elems;
+        io.out = v.e_buf[i];
+        io.partial = v.partial;
+        io.partial_cap = v.partial_elems;
         HIP_TRY(c, conv_launch(pick(c, c->hg_enc[i], (size_t)n * io.Hin * io.Win), io, s));
     }
     STAGE_MARK(2);
     // hourglass decoder: nearest x2 and the skip concatenation are folded into the operand loader
     for (int i = 0; i < c->nb; ++i) {
         ConvIO io{};
-        io.in0 = i == 0 ? c->e_buf[c->nb - 1] : c->u_buf[i - 1];
-        io.in1 = i == 0 ? nullptr : c->e_buf[c->nb - 1 - i];
+        io.in0 = i == 0 ? v.e_buf[c->nb - 1] : v.u_buf[i - 1];
+        io.in1 = i == 0 ? nullptr : v.e_buf[c->nb - 1 - i];
         io.B = n;
         io.Hin = h >> (c->nb - i);
         io.Win = w >> (c->nb - i);
         io.act = ACT_RELU;
-        io.out = c->u_buf[i];
-        io.partial = c->partial;
-        io.partial_cap = c->partial_elems;
+        io.out = v.u_buf[i];
+        io.partial = v.partial;
+        io.partial_cap = v.partial_elems;
         if (int urc = launch_up(c, c->hg_dec[i], io, s)) return urc;
     }
     STAGE_MARK(3);
     // mask / occlusion logits, then softmax + flow combine + sigmoid         dense_motion.py:98-111
     {
         ConvIO io{};
-        io.in0 = c->u_buf[c->nb - 1];
-        io.in1 = c->hg_in;
+        io.in0 = v.u_buf[c->nb - 1];
+        io.in1 = v.hg_in;
         io.B = n;
         io.Hin = h;
         io.Win = w;
         io.act = ACT_NONE;
-        io.out = c->logits;
-        io.partial = c->partial;
-        io.partial_cap = c->partial_elems;
+        io.out = v.logits;
+        io.partial = v.partial;
+        io.partial_cap = v.partial_elems;
         ConvLayer head = c->head;
-        float* defo = c->deformation;
+        float* defo = v.deformation;
         if (c->head_nc) {
             head.Cout = 128;  // partial products written with a 128-float pixel stride (7*nc used)
             // the column-patch kernel runs one workgroup per 16x16-pixel tile: below ~half a chip of tiles (4 frames at
             // 64x64) the split-K im2col kernel is faster (measured: 1 frame 0.122 -> 0.073 ms, 4 frames 0.122 -> 0.094 ms)
             const int head_tiles = n * ((h + 15) / 16) * ((w + 15) / 16);
             if (c->head_w_swz && head_tiles >= c->head_col7_min_tiles)
-                HIP_TRY(c, conv_col7s_launch(io.in0, head.C0, io.in1, head.C1, n, h, w, c->head_w_swz, 3, c->logits, 128, s));
+                HIP_TRY(c, conv_col7s_launch(io.in0, head.C0, io.in1, head.C1, n, h, w, c->head_w_swz, 3, v.logits, 128, s));
             else
                 HIP_TRY(c, conv_launch(head, io, s));
-            HIP_TRY(c, motion_head_rowsplit_launch(c->logits, 128, c->head_nc, c->head_bias, c->kp_rec, n, K, h, w,
-                                                   occ ? 1 : 0, defo, c->occlusion, o->mask, o->occlusion_map, s));
+            HIP_TRY(c, motion_head_rowsplit_launch(v.logits, 128, c->head_nc, c->head_bias, v.kp_rec, n, K, h, w,
+                                                   occ ? 1 : 0, defo, v.occlusion, v.out.mask, v.out.occlusion_map, s));
         } else {
             head.Cout = 32;  // logits are written with a 32-float pixel stride; channels >= K+2 have zero weights
             HIP_TRY(c, conv_launch(head, io, s));
-            HIP_TRY(c, motion_head_launch(c->logits, c->kp_rec, n, K, h, w, occ ? 1 : 0, defo, c->occlusion, o->mask,
-                                          o->occlusion_map, s));
+            HIP_TRY(c, motion_head_launch(v.logits, v.kp_rec, n, K, h, w, occ ? 1 : 0, defo, v.occlusion, v.out.mask,
+                                          v.out.occlusion_map, s));
         }
-        if (o->deformation)
-            HIP_TRY(c, hipMemcpyAsync(o->deformation, defo, (size_t)n * h * w * 2 * sizeof(float),
+        if (v.out.deformation)
+            HIP_TRY(c, hipMemcpyAsync(v.out.deformation, defo, (size_t)n * h * w * 2 * sizeof(float),
                                       hipMemcpyDeviceToDevice, s));
     }
     STAGE_MARK(4);
@@ -614,13 +676,13 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     const int form = bottleneck_form(c, n);
     const bool wino = form != 0;
     // feature warp x occlusion (+ r0's pre-activation for the direct form)       generator.py:79-84
-    HIP_TRY(c, warp_features_launch(c->feat, c->deformation, occ ? c->occlusion : nullptr, n, ns, hf, wf, c->Cb, h, w,
-                                    c->xa, wino ? nullptr : c->act, c->pre_s[0], c->pre_t[0], s));
-    if (o->deformed)                                                         // generator.py:86
-        HIP_TRY(c, warp_image_launch(c->src_full, c->deformation, n, ns, c->H, c->W, h, w, o->deformed, s));
+    HIP_TRY(c, warp_features_launch(v.feat, v.deformation, occ ? v.occlusion : nullptr, n, ns, hf, wf, c->Cb, h, w,
+                                    v.xa, wino ? nullptr : v.act, c->pre_s[0], c->pre_t[0], s));
+    if (v.out.deformed)                                                         // generator.py:86
+        HIP_TRY(c, warp_image_launch(v.src_full, v.deformation, n, ns, c->H, c->W, h, w, v.out.deformed, s));
     STAGE_MARK(5);
     // bottleneck                                                               generator.py:89
-    float *x = c->xa, *xn = c->xb;
+    float *x = v.xa, *xn = v.xb;
     hipEvent_t* sub = (ev && wino && 4 * nr + 1 <= eamm_ctx::NSUB) ? ev + eamm_ctx::NMARK + 1 : nullptr;
     int nsub = 0;
 #define SUB_MARK()                                               \
@@ -628,8 +690,8 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         if (sub) HIP_TRY(c, hipEventRecord(sub[nsub++], s));     \
     } while (0)
     const bool wino4 = form == 4;
-    const int w4g = wino4 ? wino4_groups(c, n) : 1;
-    const int chains = bottleneck_chains(c, n);
+    const int w4g = (wino4 && !chained) ? wino4_groups(c, n) : 1;   // a chained view shares the chip: never split the point rows
+    const int chains = chained ? 1 : bottleneck_chains(c, n);
     if (chains > 1) {
         const size_t per_frame = (size_t)hf * wf * c->Cb;
         const int nbase = n / chains, nrem = n % chains;   // the first nrem chains take one more frame
@@ -642,8 +704,8 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
                 const size_t f0 = (size_t)k * nbase + std::min(k, nrem);
                 float* xk = x + f0 * per_frame;
                 float* xnk = xn + f0 * per_frame;
-                float* tk = c->tmp + f0 * per_frame;
-                float* vk = c->wino_v + 4 * f0 * per_frame;   // 2.25 nk frames used of the 4 nk reserved for this chain
+                float* tk = v.tmp + f0 * per_frame;
+                float* vk = v.wino_v + 4 * f0 * per_frame;   // 2.25 nk frames used of the 4 nk reserved for this chain
                 // events around the main stream's (chain 0's) kernels only: they time those launches while the other
                 // chains' run beside them
                 if (k == 0) SUB_MARK();
@@ -667,21 +729,21 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         // conv1(relu(norm1(x))): the pre-activation rides on the input transform; norm2 + relu in the epilogue
         SUB_MARK();
         if (wino4) {
-            HIP_TRY(c, wino4_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, c->wino_v, s));
+            HIP_TRY(c, wino4_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, v.wino_v, s));
             SUB_MARK();
-            HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], c->wino_v, n, hf, wf, ACT_RELU, nullptr, c->tmp, s, c->wino4_variant, w4g, c->wino_z));
+            HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], v.wino_v, n, hf, wf, ACT_RELU, nullptr, v.tmp, s, c->wino4_variant, w4g, v.wino_z));
             SUB_MARK();
-            HIP_TRY(c, wino4_transform_launch(c->tmp, nullptr, nullptr, n, hf, wf, c->Cb, c->wino_v, s));
+            HIP_TRY(c, wino4_transform_launch(v.tmp, nullptr, nullptr, n, hf, wf, c->Cb, v.wino_v, s));
             SUB_MARK();
-            HIP_TRY(c, wino4_gemm_launch(c->w4res2[i], c->wino_v, n, hf, wf, ACT_NONE, x, xn, s, c->wino4_variant, w4g, c->wino_z));   // out += x
+            HIP_TRY(c, wino4_gemm_launch(c->w4res2[i], v.wino_v, n, hf, wf, ACT_NONE, x, xn, s, c->wino4_variant, w4g, v.wino_z));   // out += x
         } else {
-            HIP_TRY(c, wino_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, c->wino_v, s));
+            HIP_TRY(c, wino_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, v.wino_v, s));
             SUB_MARK();
-            HIP_TRY(c, wino_gemm_launch(c->wres1[i], c->wino_v, n, hf, wf, ACT_RELU, nullptr, c->tmp, s, c->wino_variant));
+            HIP_TRY(c, wino_gemm_launch(c->wres1[i], v.wino_v, n, hf, wf, ACT_RELU, nullptr, v.tmp, s, c->wino_variant));
             SUB_MARK();
-            HIP_TRY(c, wino_transform_launch(c->tmp, nullptr, nullptr, n, hf, wf, c->Cb, c->wino_v, s));
+            HIP_TRY(c, wino_transform_launch(v.tmp, nullptr, nullptr, n, hf, wf, c->Cb, v.wino_v, s));
             SUB_MARK();
-            HIP_TRY(c, wino_gemm_launch(c->wres2[i], c->wino_v, n, hf, wf, ACT_NONE, x, xn, s, c->wino_variant));   // out += x
+            HIP_TRY(c, wino_gemm_launch(c->wres2[i], v.wino_v, n, hf, wf, ACT_NONE, x, xn, s, c->wino_variant));   // out += x
         }
         std::swap(x, xn);
     }
@@ -690,17 +752,17 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     if (sub) c->prof_sub.back() = nsub;
     for (int i = 0; i < nr && !wino; ++i) {
         ConvIO a{};
-        a.in0 = c->act;
+        a.in0 = v.act;
         a.B = n;
         a.Hin = hf;
         a.Win = wf;
         a.act = ACT_RELU;  // conv1 -> norm2 (folded) -> relu
-        a.out = c->tmp;
-        a.partial = c->partial;
-        a.partial_cap = c->partial_elems;
+        a.out = v.tmp;
+        a.partial = v.partial;
+        a.partial_cap = v.partial_elems;
         HIP_TRY(c, conv_launch(pick(c, c->res1[i], (size_t)n * hf * wf), a, s));
         ConvIO b{};
-        b.in0 = c->tmp;
+        b.in0 = v.tmp;
         b.B = n;
         b.Hin = hf;
         b.Win = wf;
@@ -708,12 +770,12 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         b.resid = x;       // out += x
         b.out = xn;
         if (i + 1 < nr) {  // next block's relu(norm1(.))
-            b.out2 = c->act;
+            b.out2 = v.act;
             b.s2 = c->pre_s[i + 1];
             b.t2 = c->pre_t[i + 1];
         }
-        b.partial = c->partial;
-        b.partial_cap = c->partial_elems;
+        b.partial = v.partial;
+        b.partial_cap = v.partial_elems;
         HIP_TRY(c, conv_launch(pick(c, c->res2[i], (size_t)n * hf * wf), b, s));
         std::swap(x, xn);
     }
@@ -727,11 +789,11 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         io.Hin = hf << i;
         io.Win = wf << i;
         io.act = ACT_RELU;
-        io.out = c->up_buf[i];
-        io.partial = c->partial;
-        io.partial_cap = c->partial_elems;
+        io.out = v.up_buf[i];
+        io.partial = v.partial;
+        io.partial_cap = v.partial_elems;
         if (int urc = launch_up(c, c->up[i], io, s)) return urc;
-        cur = c->up_buf[i];
+        cur = v.up_buf[i];
     }
     STAGE_MARK(7);
     // final 7x7 + sigmoid, written NCHW straight into the caller's buffer      generator.py:92-93
@@ -742,20 +804,68 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         io.Hin = c->H;
         io.Win = c->W;
         io.act = ACT_NONE;
-        io.out = c->final_part;
-        io.partial = c->partial;
-        io.partial_cap = c->partial_elems;
+        io.out = v.final_part;
+        io.partial = v.partial;
+        io.partial_cap = v.partial_elems;
         ConvLayer fl = c->final_conv;
         fl.Cout = 32;  // 32-float pixel stride; channels >= 21 have zero weights
         if (c->final_w_swz && fl.BN == 32)
-            HIP_TRY(c, conv_col7_launch(cur, fl.C0, n, c->H, c->W, c->final_w_swz, c->final_part, s));
+            HIP_TRY(c, conv_col7_launch(cur, fl.C0, n, c->H, c->W, c->final_w_swz, v.final_part, s));
         else
             HIP_TRY(c, conv_launch(fl, io, s));
-        HIP_TRY(c, final_shift_sum_launch(c->final_part, c->final_bias, n, c->H, c->W, o->prediction, s));
+        HIP_TRY(c, final_shift_sum_launch(v.final_part, c->final_bias, n, c->H, c->W, v.out.prediction, s));
     }
-    if (o->frames_u8) HIP_TRY(c, to_u8_launch(o->prediction, n, c->H, c->W, o->frames_u8, s));
-    STAGE_MARK(8);
+    if (v.out.frames_u8) HIP_TRY(c, to_u8_launch(v.out.prediction, n, c->H, c->W, v.out.frames_u8, s));
 #undef STAGE_MARK
+    return EAMM_OK;   // (the caller records the last stage mark, after joining the chains)
+}
+
+
+int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd_jac, const float* ks_val,
+                        const float* ks_jac, const eamm_outputs* o, void* stream_) {
+    if (!c || !kd_val || !ks_val || !o || !o->prediction) return fail(c, EAMM_ERR_ARG, "null argument");
+    if (!c->finalized) return fail(c, EAMM_ERR_STATE, "call eamm_finalize_weights first");
+    if (c->ns_cached < 1) return fail(c, EAMM_ERR_STATE, "no source cached: call eamm_encode_source first");
+    if (n < 1 || n > c->cfg.max_frames) return fail(c, EAMM_ERR_ARG, "n=%d outside [1,%d]", n, c->cfg.max_frames);
+    if (kd_jac != nullptr && ks_jac == nullptr)
+        return fail(c, EAMM_ERR_ARG, "kp_driving jacobian given without kp_source jacobian");
+    const int ns = c->ns_cached;
+    if (ns != 1 && ns != n) return fail(c, EAMM_ERR_ARG, "%d cached sources cannot serve %d frames (need 1 or n)", ns, n);
+    if ((o->occlusion_map) && !c->cfg.estimate_occlusion_map)
+        return fail(c, EAMM_ERR_ARG, "occlusion_map requested but estimate_occlusion_map is off");
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+
+    hipEvent_t* ev = nullptr;  // stage boundaries (of the main stream's sequence), recorded only while profiling
+    if (c->profiling && c->prof_used < eamm_ctx::PROF_CALLS) {
+        ev = c->prof_events.data() + (size_t)c->prof_used * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB);
+        c->prof_n.push_back(n);
+        c->prof_sub.push_back(0);
+        c->prof_marks.push_back(0);
+        ++c->prof_used;
+    }
+    const int chains = pass_chains(c, n);
+    if (chains == 1) {
+        if (int rc = forward_view(c, make_view(c, 0, n, ns, 0, kd_val, kd_jac, ks_val, ks_jac, o), s, ev, false)) return rc;
+    } else {
+        const int nbase = n / chains, nrem = n % chains;   // the first nrem chains take one more frame
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+        for (int k = 1; k < chains; ++k) HIP_TRY(c, hipStreamWaitEvent(c->side_streams[k - 1], c->ev_fork, 0));
+        for (int k = 0; k < chains; ++k) {
+            const int nk = nbase + (k < nrem ? 1 : 0), f0 = k * nbase + std::min(k, nrem);
+            const FrameView v = make_view(c, f0, nk, ns, k, kd_val, kd_jac, ks_val, ks_jac, o);
+            if (int rc = forward_view(c, v, k ? c->side_streams[k - 1] : s, k ? nullptr : ev, true)) return rc;
+        }
+        for (int k = 1; k < chains; ++k) {
+            HIP_TRY(c, hipEventRecord(c->ev_join[k - 1], c->side_streams[k - 1]));
+            HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0));
+        }
+    }
+    if (ev) {   // the last stage ends where the call ends (after the join)
+        HIP_TRY(c, hipEventRecord(ev[eamm_ctx::NMARK], s));
+        c->prof_marks.back() = eamm_ctx::NMARK + 1;
+    }
     return EAMM_OK;
 }
 
@@ -883,7 +993,11 @@ int eamm_import_source_cache(eamm_ctx* c, const void* src, int ns, void* stream_
 double eamm_flops_per_frame(const eamm_ctx* c) { return c ? c->flops_frame : 0.0; }
 
 int eamm_bottleneck_form(const eamm_ctx* c, int n) { return (c && n > 0) ? bottleneck_form(c, n) : EAMM_ERR_ARG; }
-int eamm_bottleneck_chains(const eamm_ctx* c, int n) { return (c && n > 0) ? bottleneck_chains(c, n) : EAMM_ERR_ARG; }
+int eamm_bottleneck_chains(const eamm_ctx* c, int n) {
+    if (!c || n <= 0) return EAMM_ERR_ARG;
+    const int whole = pass_chains(c, n);   // chains over the whole pass take precedence over chains inside the bottleneck
+    return whole > 1 ? whole : bottleneck_chains(c, n);
+}
 double eamm_encode_flops(const eamm_ctx* c) { return c ? c->flops_encode : 0.0; }
 
 int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int up,
