@@ -30,7 +30,8 @@ struct eamm_ctx : eamm::CtxBase {
     std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
     std::vector<WinoLayer> w4res1, w4res2; // Winograd F(4x4,3x3) packing (bottleneck maps with sides divisible by 4)
     int bneck_chains = 2;                  // bottleneck as this many chains of frames on as many streams (EAMM_BNECK_CHAINS; 1 = off)
-    int pass_chains = 2;                   // the whole per-frame pass as this many chains (EAMM_PASS_CHAINS; 1 = off)
+    int pass_chains = 1;                   // the whole per-frame pass as this many chains (EAMM_PASS_CHAINS; 1 = off, the default:
+                                           // measured 256x256 -- 16 frames 3381 vs 3370 frames/s, 12 frames 2633 vs 2765, 8 frames 2744 vs 2197)
     int pass_chains_min_frames = 8;        // ... from this many frames per call (EAMM_PASS_CHAINS_MIN_FRAMES)
     std::vector<hipStream_t> side_streams; // the other chains' streams + fork / join events
     hipEvent_t ev_fork = nullptr;
