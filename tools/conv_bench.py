@@ -62,7 +62,7 @@ def main():
                 continue
             if tile in (3000, 3001) and (not up or resid):
                 continue
-            if 1000 < tile < 2000 and {1001: 256, 1002: 128, 1003: 64}[tile] > max(Cout, 64) * 2:
+            if 1000 < tile < 2000 and {1001: 256, 1002: 128, 1003: 64, 1004: 128, 1005: 128}[tile] > max(Cout, 64) * 2:
                 continue
             ms = C.c_float()
             rc = L.eamm_op_conv(0, in0.data_ptr(), C0, in1.data_ptr() if C1 else None, C1, B, H, W, up, w.data_ptr(),
