@@ -53,7 +53,9 @@ struct CtxBase {
     int big_min_m = 49152;      // ... and for which Cout % 256 == 0 layers use the 256x256 tile (>= 192 M tiles)
     int dma_cfg_n256 = 2, dma_cfg_n128 = 2, dma_cfg_n64 = 3;
     int patch_wino = 1;         // up blocks on the patch kernel in Winograd F(2x2,2x2) form (EAMM_PATCH_WINO)
-    int skinny_max_m = 256;     // largest per-phase pixel count served by the 32- / 64-row tiles (EAMM_SKINNY_MAX_M; 0 = off)
+    int skinny_max_m = 16384;   // largest per-phase pixel count served by the 32- / 64-row tiles (EAMM_SKINNY_MAX_M; 0 = off):
+                                // 64x128 tiles need no split-K where 256x128 ones do (measured 256x256: 1 frame 753 -> 785, 4 frames 1969 -> 2067,
+                                // 8 frames 2756 -> 2782 frames/s; 16 frames unchanged)
     int patch_min_blocks = 192; // fewest workgroups for which UpBlock2d layers use the spatial-patch kernel (< 0: never)
 };
 
