@@ -94,13 +94,15 @@ void expected_keys(const eamm_ctx* c, std::vector<std::string>* keys) {
     const std::string dm = "dense_motion_network.";
     for (int i = 0; i < c->nb; ++i) block(dm + "hourglass.encoder.down_blocks." + std::to_string(i));
     for (int i = 0; i < c->nb; ++i) block(dm + "hourglass.decoder.up_blocks." + std::to_string(i));
-    keys->push_back(dm + "mask.weight");
-    keys->push_back(dm + "mask.bias");
-    if (c->cfg.estimate_occlusion_map) {
-        keys->push_back(dm + "occlusion.weight");
-        keys->push_back(dm + "occlusion.bias");
+    if (c->nb > 0) {
+        keys->push_back(dm + "mask.weight");
+        keys->push_back(dm + "mask.bias");
+        if (c->cfg.estimate_occlusion_map) {
+            keys->push_back(dm + "occlusion.weight");
+            keys->push_back(dm + "occlusion.bias");
+        }
+        if (c->cfg.dm_inv_scale != 1) keys->push_back(dm + "down.weight");
     }
-    if (c->cfg.dm_inv_scale != 1) keys->push_back(dm + "down.weight");
     block("first");
     for (int i = 0; i < c->nd; ++i) block("down_blocks." + std::to_string(i));
     for (int i = 0; i < c->nd; ++i) block("up_blocks." + std::to_string(i));
@@ -132,15 +134,18 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     const eamm_config& g = *cfg;
     if (g.num_channels != 3) return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 3 (got %d)", g.num_channels);
     if (g.num_kp < 1 || g.num_kp + 2 > 32) return fail(nullptr, EAMM_ERR_ARG, "num_kp out of range");
-    if (g.dm_num_blocks < 1) return fail(nullptr, EAMM_ERR_ARG, "dense_motion_params are required");
-    if (!is_pow2(g.dm_inv_scale) || g.dm_inv_scale > 4 || g.dm_inv_scale == 3)
+    // dm_num_blocks == 0: a generator without a motion network (dense_motion_params=None, generator.py:22-23)
+    const bool has_dm = g.dm_num_blocks > 0;
+    if (g.dm_num_blocks < 0) return fail(nullptr, EAMM_ERR_ARG, "dm_num_blocks < 0");
+    if (has_dm && (!is_pow2(g.dm_inv_scale) || g.dm_inv_scale > 4 || g.dm_inv_scale == 3))
         return fail(nullptr, EAMM_ERR_ARG, "1/scale_factor must be 1, 2 or 4");
-    if (g.block_expansion % 32 || g.max_features % 32 || g.dm_block_expansion % 32 || g.dm_max_features % 32)
+    if (!has_dm && g.estimate_occlusion_map) return fail(nullptr, EAMM_ERR_ARG, "estimate_occlusion_map needs a motion network");
+    if (g.block_expansion % 32 || g.max_features % 32 || (has_dm && (g.dm_block_expansion % 32 || g.dm_max_features % 32)))
         return fail(nullptr, EAMM_ERR_ARG, "channel widths must be multiples of 32");
     if (g.num_down_blocks < 1 || g.num_bottleneck_blocks < 1)
         return fail(nullptr, EAMM_ERR_ARG, "need at least one down block and one bottleneck block");
     if (g.max_frames < 1 || g.max_sources < 1) return fail(nullptr, EAMM_ERR_ARG, "max_frames / max_sources < 1");
-    const int div_g = 1 << g.num_down_blocks, div_m = g.dm_inv_scale << g.dm_num_blocks;
+    const int div_g = 1 << g.num_down_blocks, div_m = has_dm ? g.dm_inv_scale << g.dm_num_blocks : 1;
     if (g.height % div_g || g.width % div_g || g.height % div_m || g.width % div_m)
         return fail(nullptr, EAMM_ERR_ARG, "frame %dx%d not divisible for %d down blocks / %d hourglass levels",
                     g.height, g.width, g.num_down_blocks, g.dm_num_blocks);
@@ -164,8 +169,9 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->device = device;
     c->H = g.height;
     c->W = g.width;
-    c->h = c->H / g.dm_inv_scale;
-    c->w = c->W / g.dm_inv_scale;
+    if (!has_dm) c->cfg.dm_inv_scale = 1;
+    c->h = c->H / c->cfg.dm_inv_scale;
+    c->w = c->W / c->cfg.dm_inv_scale;
     c->nd = g.num_down_blocks;
     c->nb = g.dm_num_blocks;
     c->K = g.num_kp;
@@ -243,7 +249,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
         if ((rc = build_set(c, {{p + ".conv", p + ".norm"}}, c0, c0, c1, c1, &c->hg_dec[i], MODE_PHASE))) return rc;
     }
     // flow head: mask (K+1) and occlusion (1) 7x7 convolutions share one launch (dense_motion.py:98,110)
-    {
+    if (c->nb > 0) {
         std::vector<FoldSpec> parts = {{dm + "mask", ""}};
         if (g.estimate_occlusion_map) parts.push_back({dm + "occlusion", ""});
         const int nc = c->K + 1 + (g.estimate_occlusion_map ? 1 : 0);
@@ -344,16 +350,16 @@ int eamm_finalize_weights(eamm_ctx* c) {
     if ((rc = dev_alloc(c, &c->kp_rec, F * c->K * KP_STRIDE))) return rc;
     if ((rc = dev_alloc(c, &c->bad_flag, 1))) return rc;
     HIP_TRY(c, hipMemset(c->bad_flag, 0, sizeof(int)));
-    if ((rc = dev_alloc(c, &c->hg_in, F * hw * c->Cp0))) return rc;
+    if (c->nb > 0 && (rc = dev_alloc(c, &c->hg_in, F * hw * c->Cp0))) return rc;
     c->e_buf.resize(c->nb);
     c->u_buf.resize(c->nb);
     for (int i = 0; i < c->nb; ++i) {
         if ((rc = dev_alloc(c, &c->e_buf[i], F * (hw >> (2 * (i + 1))) * c->enc_c[i]))) return rc;
         if ((rc = dev_alloc(c, &c->u_buf[i], F * (hw >> (2 * (c->nb - 1 - i))) * c->dec_c[i]))) return rc;
     }
-    if ((rc = dev_alloc(c, &c->logits, F * hw * (c->head_nc ? 128 : 32)))) return rc;
-    if ((rc = dev_alloc(c, &c->deformation, F * hw * 2))) return rc;
-    if ((rc = dev_alloc(c, &c->occlusion, F * hw))) return rc;
+    if (c->nb > 0 && (rc = dev_alloc(c, &c->logits, F * hw * (c->head_nc ? 128 : 32)))) return rc;
+    if (c->nb > 0 && (rc = dev_alloc(c, &c->deformation, F * hw * 2))) return rc;
+    if (c->nb > 0 && (rc = dev_alloc(c, &c->occlusion, F * hw))) return rc;
     if ((rc = dev_alloc(c, &c->xa, F * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->xb, F * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->act, F * hwf * c->Cb))) return rc;
@@ -387,7 +393,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
                 upd(c->hg_enc[i], f * (hw >> (2 * i)));
                 upd(c->hg_dec[i], f * (hw >> (2 * (c->nb - i))));
             }
-            upd1(c->head, f * hw);
+            if (c->nb > 0) upd1(c->head, f * hw);
             upd(c->res1[0], f * hwf);
             for (int i = 0; i < c->nd; ++i) upd(c->up[i], f * (hwf << (2 * i)));
             upd1(c->final_conv, f * HW);
@@ -407,12 +413,12 @@ int eamm_finalize_weights(eamm_ctx* c) {
             const int ci = c->hg_dec[i].base.C0 + c->hg_dec[i].base.C1;
             ff += conv_flops(3, ci, c->dec_c[i], (double)(hw >> (2 * (c->nb - 1 - i))));
         }
-        ff += conv_flops(7, c->dec_c.back() + cin0, c->K + 1 + (g.estimate_occlusion_map ? 1 : 0), (double)hw);
+        if (c->nb > 0) ff += conv_flops(7, c->dec_c.back() + cin0, c->K + 1 + (g.estimate_occlusion_map ? 1 : 0), (double)hw);
         ff += 2.0 * nr * conv_flops(3, c->Cb, c->Cb, (double)hwf);
         for (int i = 0; i < c->nd; ++i)
             ff += conv_flops(3, i == 0 ? c->Cb : c->up_c[i - 1], c->up_c[i], (double)(hwf << (2 * (i + 1))));
         ff += conv_flops(7, c->up_c.back(), 3, (double)HW);
-        ff += 9.0 * hwf * c->Cb;  // bilinear feature warp + occlusion multiply
+        if (c->nb > 0) ff += 9.0 * hwf * c->Cb;  // bilinear feature warp + occlusion multiply
         c->flops_frame = ff;
     }
     c->bneck_chains = std::max(1, std::min(c->bneck_chains, 16));
@@ -540,14 +546,14 @@ static FrameView make_view(const eamm_ctx* c, int f0, int n, int ns_call, int sl
     v.src_small = c->src_small + sf * hw * 4;
     v.src_full = c->src_full + sf * 3 * HW;
     v.kp_rec = c->kp_rec + F * K * KP_STRIDE;
-    v.hg_in = c->hg_in + F * hw * c->Cp0;
+    v.hg_in = c->hg_in ? c->hg_in + F * hw * c->Cp0 : nullptr;            // (no motion network: these four do not exist)
     for (int i = 0; i < c->nb; ++i) {
         v.e_buf.push_back(c->e_buf[i] + F * (hw >> (2 * (i + 1))) * c->enc_c[i]);
         v.u_buf.push_back(c->u_buf[i] + F * (hw >> (2 * (c->nb - 1 - i))) * c->dec_c[i]);
     }
-    v.logits = c->logits + F * hw * (c->head_nc ? 128 : 32);
-    v.deformation = c->deformation + F * hw * 2;
-    v.occlusion = c->occlusion + F * hw;
+    v.logits = c->logits ? c->logits + F * hw * (c->head_nc ? 128 : 32) : nullptr;
+    v.deformation = c->deformation ? c->deformation + F * hw * 2 : nullptr;
+    v.occlusion = c->occlusion ? c->occlusion + F * hw : nullptr;
     v.xa = c->xa + F * hwf * c->Cb;
     v.xb = c->xb + F * hwf * c->Cb;
     v.act = c->act + F * hwf * c->Cb;
@@ -599,6 +605,14 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
             c->prof_marks.back() = (i) + 1;            \
         }                                              \
     } while (0)
+    const int nr = c->cfg.num_bottleneck_blocks;
+    const int form = bottleneck_form(c, n);
+    const bool wino = form != 0;
+    if (c->nb == 0) {   // no motion network (generator.py:64 is false): the encoder features enter the bottleneck as they are
+        STAGE_MARK(0); STAGE_MARK(1); STAGE_MARK(2); STAGE_MARK(3); STAGE_MARK(4);
+        HIP_TRY(c, broadcast_features_launch(v.feat, n, ns, hf, wf, c->Cb, v.xa, wino ? nullptr : v.act, c->pre_s[0], c->pre_t[0], s));
+        STAGE_MARK(5);
+    } else {
     STAGE_MARK(0);
     // key-point records; 'jacobian' missing from kp_driving => identity (dense_motion.py:55)
     HIP_TRY(c, kp_prepare_launch(v.kd_val, v.kd_jac, v.ks_val, v.kd_jac ? v.ks_jac : nullptr, n, ns, K, v.kp_rec, c->bad_flag, s));
@@ -672,16 +686,13 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
                                       hipMemcpyDeviceToDevice, s));
     }
     STAGE_MARK(4);
-    // Bottleneck form: Winograd F(2x2,3x3) when there are enough tiles to fill the chip, else direct.
-    const int nr = c->cfg.num_bottleneck_blocks;
-    const int form = bottleneck_form(c, n);
-    const bool wino = form != 0;
     // feature warp x occlusion (+ r0's pre-activation for the direct form)       generator.py:79-84
     HIP_TRY(c, warp_features_launch(v.feat, v.deformation, occ ? v.occlusion : nullptr, n, ns, hf, wf, c->Cb, h, w,
                                     v.xa, wino ? nullptr : v.act, c->pre_s[0], c->pre_t[0], s));
     if (v.out.deformed)                                                         // generator.py:86
         HIP_TRY(c, warp_image_launch(v.src_full, v.deformation, n, ns, c->H, c->W, h, w, v.out.deformed, s));
     STAGE_MARK(5);
+    }
     // bottleneck                                                               generator.py:89
     float *x = v.xa, *xn = v.xb;
     hipEvent_t* sub = (ev && wino && 4 * nr + 1 <= eamm_ctx::NSUB) ? ev + eamm_ctx::NMARK + 1 : nullptr;
@@ -834,6 +845,8 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     if (ns != 1 && ns != n) return fail(c, EAMM_ERR_ARG, "%d cached sources cannot serve %d frames (need 1 or n)", ns, n);
     if ((o->occlusion_map) && !c->cfg.estimate_occlusion_map)
         return fail(c, EAMM_ERR_ARG, "occlusion_map requested but estimate_occlusion_map is off");
+    if (c->nb == 0 && (o->mask || o->sparse_deformed || o->deformed || o->deformation))
+        return fail(c, EAMM_ERR_ARG, "this generator has no motion network: only 'prediction' exists (generator.py:64-95)");
     DeviceGuard guard(c->device);
     if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);

@@ -152,6 +152,8 @@ hipError_t warp_features_launch(const float* feat /*[ns,hf,wf,C]*/, const float*
                                 const float* occlusion /*[n,h,w] or null*/, int n, int ns, int hf, int wf, int C,
                                 int h, int w, float* out, float* out2, const float* s2, const float* t2,
                                 hipStream_t s);
+hipError_t broadcast_features_launch(const float* feat /*[ns,hf,wf,C]*/, int n, int ns, int hf, int wf, int C, float* out,
+                                     float* out2, const float* s2, const float* t2, hipStream_t s);
 hipError_t warp_image_launch(const float* src /*[ns,3,H,W]*/, const float* deformation /*[n,h,w,2]*/, int n, int ns,
                              int H, int W, int h, int w, float* out /*[n,3,H,W]*/, hipStream_t s);
 hipError_t source_prepare_launch(const float* src /*[ns,3,H,W]*/, const float* aa_w /*[3,13,13] dev*/, int ns, int H,

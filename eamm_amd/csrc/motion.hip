@@ -551,6 +551,37 @@ hipError_t warp_image_launch(const float* src, const float* deformation, int n, 
     return hipGetLastError();
 }
 
+// A generator built without a motion network (dense_motion_params=None, generator.py:22-23, 64): the encoder features go
+// to the bottleneck unwarped -- frame i gets source i (or the one cached source); second output relu(x*s + t) is the first
+// res-block's pre-activation for the direct convolution form.
+__global__ void broadcast_features_kernel(const float4* __restrict__ feat, int ns, size_t per_frame4, int C4, size_t total4,
+                                          float4* __restrict__ out, float4* __restrict__ out2, const float4* __restrict__ s2,
+                                          const float4* __restrict__ t2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / per_frame4, r = i - f * per_frame4;
+        const float4 v = feat[(ns == 1 ? 0 : f) * per_frame4 + r];
+        out[i] = v;
+        if (out2 != nullptr) {
+            const float4 s = s2[r % C4], t = t2[r % C4];
+            float4 a;
+            a.x = fmaxf(fmaf(v.x, s.x, t.x), 0.f); a.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
+            a.z = fmaxf(fmaf(v.z, s.z, t.z), 0.f); a.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
+            out2[i] = a;
+        }
+    }
+}
+
+hipError_t broadcast_features_launch(const float* feat, int n, int ns, int hf, int wf, int C, float* out, float* out2,
+                                     const float* s2, const float* t2, hipStream_t s) {
+    if (C & 3) return hipErrorInvalidValue;
+    const size_t per_frame4 = (size_t)hf * wf * C / 4, total4 = per_frame4 * n;
+    const int blocks = (int)std::min<size_t>((total4 + 255) / 256, (size_t)1 << 16);
+    hipLaunchKernelGGL(broadcast_features_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(feat), ns,
+                       per_frame4, C / 4, total4, reinterpret_cast<float4*>(out), reinterpret_cast<float4*>(out2),
+                       reinterpret_cast<const float4*>(s2), reinterpret_cast<const float4*>(t2));
+    return hipGetLastError();
+}
+
 hipError_t source_prepare_launch(const float* src, const float* aa_w, int ns, int H, int W, int inv_scale, int Cpad,
                                  float* src_nhwc, float* src_small, hipStream_t s) {
     const size_t t1 = (size_t)ns * H * W * (Cpad / 4);

@@ -18,9 +18,8 @@ _OUTPUT_KEYS = ("prediction", "mask", "sparse_deformed", "occlusion_map", "defor
 def config_struct(cfg: dict, height: int, width: int, max_frames: int, max_sources: int) -> _lib.EammConfig:
     """Constructor kwargs of OcclusionAwareGenerator (reference generator.py:14-15) -> eamm_config."""
     dm = cfg.get("dense_motion_params")
-    if dm is None:
-        raise ValueError("dense_motion_params=None (a generator without a motion network) is outside the "
-                         "accelerated path; every shipped config sets it (config/*.yaml generator_params)")
+    if dm is None:   # a generator without a motion network (generator.py:22-23): dm_num_blocks = 0 tells the library
+        dm = {"block_expansion": 0, "max_features": 0, "num_blocks": 0, "scale_factor": 1}
     scale = dm.get("scale_factor", 1)
     inv = int(round(1.0 / scale))
     if abs(inv * scale - 1.0) > 1e-6:
@@ -32,7 +31,8 @@ def config_struct(cfg: dict, height: int, width: int, max_frames: int, max_sourc
     s.max_features = cfg["max_features"]
     s.num_down_blocks = cfg["num_down_blocks"]
     s.num_bottleneck_blocks = cfg["num_bottleneck_blocks"]
-    s.estimate_occlusion_map = int(bool(cfg.get("estimate_occlusion_map", False)))
+    # (without a motion network the reference never reads estimate_occlusion_map: the map is that network's output)
+    s.estimate_occlusion_map = int(bool(cfg.get("estimate_occlusion_map", False)) and cfg.get("dense_motion_params") is not None)
     s.dm_block_expansion = dm["block_expansion"]
     s.dm_max_features = dm["max_features"]
     s.dm_num_blocks = dm["num_blocks"]
@@ -66,6 +66,7 @@ class Engine:
         self.inv_scale = self._cs.dm_inv_scale
         self.h, self.w = self.height // self.inv_scale, self.width // self.inv_scale
         self.has_occlusion = bool(self._cs.estimate_occlusion_map)
+        self.has_motion = self._cs.dm_num_blocks > 0
         ctx = C.c_void_p()
         _lib.check(self._L.eamm_create(C.byref(self._cs), self.device.index, C.byref(ctx)), None)
         self._ctx = ctx
@@ -145,6 +146,8 @@ class Engine:
             raise KeyError(f"unknown output(s) {sorted(unknown)}")
         if "occlusion_map" in want and not self.has_occlusion:
             want.discard("occlusion_map")
+        if not self.has_motion and want != {"prediction"}:
+            raise KeyError(f"this generator has no motion network: only 'prediction' exists, not {sorted(want - {'prediction'})}")
         shapes = {"prediction": (n, 3, H, W), "mask": (n, K + 1, h, w), "sparse_deformed": (n, K + 1, 3, h, w),
                   "occlusion_map": (n, 1, h, w), "deformed": (n, 3, H, W), "deformation": (n, h, w, 2)}
         res = {k: torch.empty(shapes[k], dtype=torch.float32, device=self.device) for k in _OUTPUT_KEYS if k in want}

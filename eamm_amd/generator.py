@@ -83,15 +83,17 @@ class OcclusionAwareGenerator(nn.Module):
                  num_bottleneck_blocks, estimate_occlusion_map=False, dense_motion_params=None,
                  estimate_jacobian=False, max_frames=16, cache_source=True):
         super().__init__()
-        if dense_motion_params is None:
-            raise ValueError("dense_motion_params=None is outside the accelerated path (every shipped config sets it)")
         self._cfg = dict(num_channels=num_channels, num_kp=num_kp, block_expansion=block_expansion,
                          max_features=max_features, num_down_blocks=num_down_blocks,
                          num_bottleneck_blocks=num_bottleneck_blocks, estimate_occlusion_map=estimate_occlusion_map,
-                         dense_motion_params=dict(dense_motion_params), estimate_jacobian=estimate_jacobian)
-        self.dense_motion_network = _DenseMotionHolder(num_kp=num_kp, num_channels=num_channels,
-                                                       estimate_occlusion_map=estimate_occlusion_map,
-                                                       **dense_motion_params)
+                         dense_motion_params=None if dense_motion_params is None else dict(dense_motion_params),
+                         estimate_jacobian=estimate_jacobian)
+        if dense_motion_params is not None:                      # generator.py:18-23
+            self.dense_motion_network = _DenseMotionHolder(num_kp=num_kp, num_channels=num_channels,
+                                                           estimate_occlusion_map=estimate_occlusion_map,
+                                                           **dense_motion_params)
+        else:
+            self.dense_motion_network = None
         down, up, bott = generator_channels(self._cfg)
         self.first = _ConvNorm(num_channels, block_expansion, 7)
         self.down_blocks = nn.ModuleList([_ConvNorm(ci, co, 3) for ci, co in down])
@@ -153,11 +155,16 @@ class OcclusionAwareGenerator(nn.Module):
             e.encode_source(source_image)
             self._src_ref, self._src_version, self._src_engine = source_image, source_image._version, e
             self._src_generation = e.cache_generation
-        want = ["prediction", "mask", "sparse_deformed", "deformed"]
-        if self.estimate_occlusion_map:
-            want.append("occlusion_map")
-        kd = {k: kp_driving[k] for k in ("value", "jacobian") if k in kp_driving}
-        ks = {k: kp_source[k] for k in ("value", "jacobian") if k in kp_source}
+        want = ["prediction"]
+        if self.dense_motion_network is not None:                # generator.py:64-86
+            want += ["mask", "sparse_deformed", "deformed"]
+            if self.estimate_occlusion_map:
+                want.append("occlusion_map")
+        if self.dense_motion_network is None:    # the reference never looks at the key points then (generator.py:64)
+            kd = ks = {"value": torch.zeros(b, self._cfg["num_kp"], 2, dtype=torch.float32, device=source_image.device)}
+        else:
+            kd = {k: kp_driving[k] for k in ("value", "jacobian") if k in kp_driving}
+            ks = {k: kp_source[k] for k in ("value", "jacobian") if k in kp_source}
         if kd["value"].shape[0] != b or ks["value"].shape[0] != b:
             raise RuntimeError("key-point batch size does not match source_image batch size")
         out = e.forward_frames(kd, ks, outputs=want)

@@ -108,6 +108,27 @@ def case(OAG, name, cfg, size, n_frames, seed_w, stride, with_jacobian=True, per
     return report
 
 
+def no_motion_case(OAG):
+    """The reference generator built WITHOUT a motion network (dense_motion_params=None, generator.py:18-23): forward is
+    encoder -> bottleneck -> up blocks -> final, 'prediction' is the only output and the key points are never read."""
+    cfg = tiny_config()
+    cfg["dense_motion_params"] = None
+    cfg["estimate_occlusion_map"] = False
+    sd = synthetic_state_dict(cfg, seed=77)
+    gen = OAG(**cfg).eval()
+    gen.load_state_dict(sd, strict=True)
+    src = synthetic_source(64, seed=3, batch=2)
+    with torch.no_grad():
+        ref = gen(src, kp_source=None, kp_driving=None)
+        mine = orc.generator_forward(sd, cfg, src, None, None)
+    assert sorted(ref) == ["prediction"] and sorted(mine) == ["prediction"]
+    d = float((mine["prediction"] - ref["prediction"]).abs().max())
+    assert d <= 2e-6, d
+    np.savez_compressed(os.path.join(GOLDEN, "tiny64_nomotion.npz"), weight_seed=np.int64(77), source_seed=np.int64(3),
+                        prediction=ref["prediction"].numpy())
+    print("tiny64_nomotion: oracle-vs-reference", d, "keys", len(sd))
+
+
 def reference_function(path, name, namespace):
     """Pull ONE function out of a reference file that cannot be imported as a module (demo.py loads dlib
     models at import time) and compile it as the reference wrote it."""
@@ -375,6 +396,10 @@ def batchnorm_case():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "nomotion":
+        os.makedirs(GOLDEN, exist_ok=True)
+        no_motion_case(import_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "batchnorm":
         os.makedirs(GOLDEN, exist_ok=True)
         batchnorm_case()
@@ -409,6 +434,7 @@ def main():
     summary["tiny64_nojac"] = case(OAG, "tiny64_nojac", tiny, 64, 2, 1234, 1, with_jacobian=False)
     summary["full256_clip2"] = case(OAG, "full256_clip2", full, 256, 2, 1234, 4)
     summary["full512_clip1"] = case(OAG, "full512_clip1", full, 512, 1, 1234, 8)
+    no_motion_case(OAG)
     normalize_kp_case()
     emotion_case()
     kp_detector_cases()

@@ -98,8 +98,10 @@ def test_strict_load_and_error_behaviour():
         gen(torch.zeros(1, 3, 64, 64), {"value": torch.zeros(1, 10, 2)}, {"value": torch.zeros(1, 10, 2)})
     # constructor accepts (and ignores) estimate_jacobian like the reference (generator.py:15)
     OcclusionAwareGenerator(**{**cfg, "estimate_jacobian": False})
-    with pytest.raises(ValueError):
-        OcclusionAwareGenerator(**{**cfg, "dense_motion_params": None})
+    # ... and dense_motion_params=None: a generator without a motion network (generator.py:18-23), fewer checkpoint keys
+    plain = OcclusionAwareGenerator(**{**cfg, "dense_motion_params": None, "estimate_occlusion_map": False})
+    assert plain.dense_motion_network is None
+    assert sorted(plain.state_dict()) == sorted(k for k in gen.state_dict() if not k.startswith("dense_motion_network."))
 
 
 def test_product_package_does_not_import_the_oracle():

@@ -321,3 +321,35 @@ def test_source_cache_export_import_roundtrip():
     with pytest.raises(RuntimeError):
         Engine(cfg, 64, 64, 4, 1, torch.device(DEV)).forward_frames(cuda(kp_d), cuda(kp_s))  # nothing encoded
     a.close(); b.close()
+
+
+def test_generator_without_motion_network():
+    """dense_motion_params=None (reference generator.py:18-23, 64): the module has no dense_motion_network, forward
+    returns 'prediction' only and never reads the key points; against the reference's own output (fixture)."""
+    cfg = tiny_config()
+    cfg["dense_motion_params"], cfg["estimate_occlusion_map"] = None, False
+    fx = load_case("tiny64_nomotion")
+    sd = synthetic_state_dict(cfg, seed=int(fx["weight_seed"]))
+    gen = OcclusionAwareGenerator(**cfg)
+    assert gen.dense_motion_network is None and not any(k.startswith("dense_motion_network") for k in gen.state_dict())
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    src = synthetic_source(64, seed=int(fx["source_seed"]), batch=2).to(DEV)
+    out = gen(src, kp_driving=None, kp_source=None)
+    assert sorted(out) == ["prediction"]
+    err = float((out["prediction"].cpu() - torch.from_numpy(fx["prediction"])).abs().max())
+    report("no motion network", {"prediction": err})
+    assert err <= TOL["prediction"]
+    with pytest.raises(KeyError):
+        gen.engine.forward_frames({"value": torch.zeros(2, 10, 2, device=DEV)}, {"value": torch.zeros(2, 10, 2, device=DEV)},
+                                  outputs=("prediction", "mask"))
+    # the direct convolution form of the bottleneck takes its first pre-activation from the broadcast kernel
+    import os
+    os.environ["EAMM_WINO_MIN_M"] = "-1"
+    try:
+        gen2 = OcclusionAwareGenerator(**cfg)
+        gen2.load_state_dict(sd, strict=True)
+        out2 = gen2.to(DEV).eval()(src, kp_driving=None, kp_source=None)
+    finally:
+        del os.environ["EAMM_WINO_MIN_M"]
+    assert float((out2["prediction"].cpu() - torch.from_numpy(fx["prediction"])).abs().max()) <= TOL["prediction"]

@@ -99,3 +99,16 @@ def test_oracle_edge_semantics():
     kp_bad = {"value": torch.zeros(1, 10, 2), "jacobian": torch.zeros(1, 10, 2, 2)}
     with pytest.raises(RuntimeError):
         orc.generator_forward(sd, cfg, synthetic_source(64), kp_bad, kp_s)
+
+
+def test_oracle_generator_without_motion_network():
+    """dense_motion_params=None (generator.py:18-23, 64): 'prediction' only, against the reference's output."""
+    cfg = tiny_config()
+    cfg["dense_motion_params"], cfg["estimate_occlusion_map"] = None, False
+    fx = load_case("tiny64_nomotion")
+    sd = synthetic_state_dict(cfg, seed=int(fx["weight_seed"]))
+    assert not any(k.startswith("dense_motion_network") for k in sd)
+    with torch.no_grad():
+        out = orc.generator_forward(sd, cfg, synthetic_source(64, seed=int(fx["source_seed"]), batch=2), None, None)
+    assert sorted(out) == ["prediction"]
+    assert float((out["prediction"] - torch.from_numpy(fx["prediction"])).abs().max()) <= 2e-6
