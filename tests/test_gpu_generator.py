@@ -353,3 +353,36 @@ def test_generator_without_motion_network():
     finally:
         del os.environ["EAMM_WINO_MIN_M"]
     assert float((out2["prediction"].cpu() - torch.from_numpy(fx["prediction"])).abs().max()) <= TOL["prediction"]
+
+
+def test_chained_bottleneck_graph_capture_and_equivalence(monkeypatch):
+    """At 16 frames the bottleneck runs as two chains of 8 frames on two streams forked from / joined into the caller's
+    stream (eamm_bottleneck_chains).  (a) The fork / join is capturable: a HIP graph of the call replays bit-exactly.
+    (b) One chain (EAMM_BNECK_CHAINS=1) and two chains launch the same kernels on the same tiles per frame, only the
+    grouping of frames per launch differs: the frames must agree to rounding."""
+    cfg = hot_path_config()
+    gen = generator(hot_path_config)
+    src, kp_s, kp_d = synthetic_source(256, seed=1), synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(16, 10, seed=2)
+    eng = gen.encode_source(src.to(DEV), max_frames=16)
+    assert eng.bottleneck_chains(16) == 2 and eng.bottleneck_chains(2) == 1
+    kd, ks = cuda(kp_d), cuda(kp_s)
+    ref = eng.forward_frames(kd, ks)["prediction"].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eng.forward_frames(kd, ks)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = eng.forward_frames(kd, ks)["prediction"]
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    monkeypatch.setenv("EAMM_BNECK_CHAINS", "1")
+    single = OcclusionAwareGenerator(**cfg)
+    single.load_state_dict(synthetic_state_dict(cfg, seed=1234), strict=True)
+    e1 = single.to(DEV).eval().encode_source(src.to(DEV), max_frames=16)
+    assert e1.bottleneck_chains(16) == 1
+    one = e1.forward_frames(kd, ks)["prediction"]
+    assert float((one - ref).abs().max()) <= 2e-5
