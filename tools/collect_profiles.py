@@ -27,7 +27,7 @@ for size_tag in ("256_b16", "512_b8"):
         table.update(json.load(open(t)))
 r = os.path.join(G, f"r02_{tag}")
 for src, dst in (("bench_256_b16.json", "r02_bench_256_b16.json"), ("bench_512_b8.json", "r02_bench_512_b8.json"),
-                 ("module_latency.txt", "r02_module_latency.txt")):
+                 ("module_latency.txt", "r02_module_latency.txt"), ("bn_bench.txt", "r02_bn_bench.txt")):
     if os.path.exists(os.path.join(r, src)):
         shutil.copy(os.path.join(r, src), os.path.join(P, dst))
 json.dump(table, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
