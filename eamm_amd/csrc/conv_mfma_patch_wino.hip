@@ -294,284 +294,6 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// v2: ONE wave per SIMD.  Same tile, LDS patch image, weight packing, fragment algebra and fold as above, but
-//   * a workgroup has 4 waves and owns TWO of the four output phases (py = pair; px = wave / 2), so the chip runs twice
-//     as many workgroups, each with the whole register file of its SIMD: two product accumulators -- the fold of interval
-//     k runs, four FMAs per MFMA gap, under the MFMAs of interval k + 1 instead of after them;
-//   * the weight ring is four intervals deep (lookahead 3): the stage of interval k + 1 is complete and visible during
-//     interval k, so the first fragments of k + 1 are fetched BEFORE the barrier that ends k and the matrix pipe restarts
-//     without waiting for an LDS round trip;
-//   * the interval body carries no branch: the first interval folds a zero product with zero coefficients, the last one
-//     prefetches an in-range garbage fragment, DMA pieces past the end get an offset the buffer descriptor rejects.
-// ---------------------------------------------------------------------------------------------------------
-namespace {
-constexpr int Q2WAVES = 4;
-constexpr int Q2RING = 4;                                         // weight stages
-constexpr int Q2A_PIECES = (QPAD / 8 + Q2WAVES - 1) / Q2WAVES;    // patch DMA instructions per wave per chunk (11)
-}  // namespace
-
-__global__ __launch_bounds__(Q2WAVES * 64) void conv_patch_wino2_kernel(const PatchWinoArgs p) {
-    constexpr int BK = CONV_BK;
-    constexpr int A_STAGE = QPAD * BK;               // floats
-    constexpr int B_STAGE = 2 * QBN * BK;            // one transform point of two phases
-    constexpr int B_INSTR = 2 * QBN / 8 / Q2WAVES;   // weight DMA instructions per wave per interval (4)
-    constexpr unsigned OOB = 0xFFFFF000u;
-    static_assert(2 * 6 >= Q2A_PIECES + 1 || Q2A_PIECES <= 12, "two patch pieces per interval over six intervals");
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][A_STAGE] [Q2RING][B_STAGE]
-    float* const As = smem;
-    float* const Bs = smem + 2 * A_STAGE;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-
-    int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int pair = L & 1;                          // output row parity py of this workgroup's two phases
-    L >>= 1;
-    const int ntile = L % p.ntiles;
-    L /= p.ntiles;
-    const int tx0 = (L % p.tiles_x) * QT;
-    L /= p.tiles_x;
-    const int ty0 = (L % p.tiles_y) * QT;
-    const int b = L / p.tiles_y;
-    const int cchunks = (p.C0 + p.C1) / BK;
-    const int nint = cchunks * 9;
-
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in0, 0, p.in0_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.in1 ? p.in1 : p.in0), 0, p.in1 ? p.in1_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-
-    // patch piece j of this wave (wave-uniform j): patch pixels (wave + 4 j) * 8 .. + 8 of chunk cc into stage st;
-    // cc >= cchunks (past the end) is sent out of range
-    auto dma_patch_piece = [&](int j, int cc, int st) {
-        const int piece = wave + Q2WAVES * j;
-        const int q = piece * 8 + (lane >> 3);
-        const int hp = q >= QHALF ? 1 : 0, qq = q - hp * QHALF;
-        const int pr = qq / (QW / 2), ch = qq - pr * (QW / 2), pc = 2 * ch + hp;
-        const int y = ty0 + pr - 1, x = tx0 + pc - 1;
-        const bool ok = (q < QPIX) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W) & (cc < cchunks);
-        const int pix = (b * p.H + y) * p.W + x;
-        const int slot = ((lane & 7) ^ patch_swz(pr, ch)) << 2;
-        const int c0 = cc * BK;
-        const bool first = c0 < p.C0;
-        const int C = first ? p.C0 : p.C1;
-        const int coff = first ? c0 : c0 - p.C0;
-        const unsigned off = ok ? (unsigned)(pix * C + coff + slot) * 4u : OOB;
-        if (piece * 8 < QPAD) {
-            float* dst = As + st * A_STAGE + piece * (8 * BK);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (lds_ptr_t)dst, 16, off, 0, 0, 0);
-        }
-    };
-    // weights of interval it (= cc * 9 + xi), this workgroup's two phases: 16 KiB contiguous ([2][64][32])
-    const unsigned w_lane = (unsigned)lane * 16u;
-    auto dma_weight_piece = [&](auto jc, int it, int st) {
-        constexpr int j = decltype(jc)::value;
-        const unsigned so = (unsigned)((((ntile * cchunks * 9 + it) * 4 + 2 * pair) * QBN + (wave * B_INSTR + j) * 8) * BK) * 4u;
-        const unsigned vo = it < nint ? w_lane : OOB;
-        float* dst = Bs + st * B_STAGE + (wave * B_INSTR + j) * (8 * BK);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)dst, 16, vo, so, 0, 0);
-    };
-
-    f32x16 acc[2][QNT];       // product of the interval in flight / of the previous interval (being folded)
-    f32x16 Y[4][QNT];         // the four outputs of each 2x2 tile, o = 2*oy + ox
-    static_for<QNT>([&](auto jc) {
-        static_for<16>([&](auto rc) {
-            constexpr int j = decltype(jc)::value, r = decltype(rc)::value;
-            acc[0][j][r] = 0.f;
-            acc[1][j][r] = 0.f;
-            static_for<4>([&](auto oc) { Y[decltype(oc)::value][j][r] = 0.f; });
-        });
-    });
-
-    // GEMM row of this lane: phase (py, px) = (pair, wave / 2), tile t = 32 (wave % 2) + l31 of the 8x8 tiles
-    const int py = pair, px = wave >> 1;
-    const int tl = (wave & 1) * 32 + l31;
-    const int ty_l = tl >> 3, tx_l = tl & 7;
-
-    // fragment addressing of transform point xi (see the v1 kernel): four patch terms + the weight row
-    struct Frag { int b00, b01, b10, b11; float sj, si, sij; };
-    auto frag_of = [&](int xi) {
-        const int ti = xi / 3, tj = xi - 3 * ti;
-        const int ra = ti == 0 ? 0 : 1, rb = ti == 2 ? 2 : 1, ca = tj == 0 ? 0 : 1, cb = tj == 2 ? 2 : 1;
-        auto term = [&](int a_, int b_) {
-            const int m = py + a_, pb = px + b_;
-            const int r = 2 * ty_l + m, chn = tx_l + (pb >> 1);
-            const int pos = (pb & 1) * QHALF + r * (QW / 2) + chn;
-            return pos * BK + ((half ^ patch_swz(r, chn)) << 2);
-        };
-        Frag f;
-        f.b00 = term(ra, ca); f.b01 = term(ra, cb); f.b10 = term(rb, ca); f.b11 = term(rb, cb);
-        f.si = ti == 1 ? 0.f : -1.f;
-        f.sj = tj == 1 ? 0.f : -1.f;
-        f.sij = f.si * f.sj;
-        return f;
-    };
-    const int bw0 = l31 * BK + ((half ^ ((l31 >> 1) & 7)) << 2);   // weight row of this lane inside a phase block
-
-    f32x4 raw[4], a[2], bb[2][QNT];
-    auto issue = [&](const Frag& f, const float* a_stage, const float* b_stage, int s, int buf) {
-        raw[0] = *reinterpret_cast<const f32x4*>(a_stage + (f.b00 ^ (8 * s)));
-        raw[1] = *reinterpret_cast<const f32x4*>(a_stage + (f.b01 ^ (8 * s)));
-        raw[2] = *reinterpret_cast<const f32x4*>(a_stage + (f.b10 ^ (8 * s)));
-        raw[3] = *reinterpret_cast<const f32x4*>(a_stage + (f.b11 ^ (8 * s)));
-        const float* bt = b_stage + (bw0 ^ (8 * s));
-#pragma unroll
-        for (int j = 0; j < QNT; ++j) bb[buf][j] = *reinterpret_cast<const f32x4*>(bt + j * 32 * BK);
-    };
-    auto combine = [&](const Frag& f, int buf) {
-        f32x4 v = raw[0];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaf(f.sij, raw[3][e], fmaf(f.si, raw[2][e], fmaf(f.sj, raw[1][e], v[e])));
-        a[buf] = v;
-    };
-    // fold coefficients of transform point xi: Y[oy][ox] += A^T[oy][ti] * A^T[ox][tj] * M, A^T = [1 1 0; 0 1 -1]
-    struct Coef { float k0, k1, k2, k3; };
-    auto fold_coef = [&](int xi) {
-        const int ti = xi / 3, tj = xi - 3 * ti;
-        const float r0 = ti < 2 ? 1.f : 0.f, r1 = ti == 0 ? 0.f : (ti == 1 ? 1.f : -1.f);
-        const float c0 = tj < 2 ? 1.f : 0.f, c1 = tj == 0 ? 0.f : (tj == 1 ? 1.f : -1.f);
-        return Coef{r0 * c0, r0 * c1, r1 * c0, r1 * c1};
-    };
-
-    // One interval: product of (chunk cc, point xi) into acc[P], fold of acc[1 - P] (coefficients kprev) under its MFMAs,
-    // DMA of the weights of interval it + 3 and of two pieces of the next chunk's patch, fetch of the next interval's first
-    // fragments.  `cur` describes this interval's fragments (already fetched + combined for step 0), `nxt` the next one's.
-    auto interval = [&](auto pc_, const Frag& cur, const Frag& nxt, int xi, int cc, int it, const Coef kprev,
-                        const float* a_stage, const float* b_stage, const float* a_next, const float* b_next) {
-        constexpr int P = decltype(pc_)::value;
-        const float* bst = b_stage + px * (QBN * BK);
-        const float* bnx = b_next + px * (QBN * BK);
-        static_for<4>([&](auto stc) {
-            constexpr int step = decltype(stc)::value;
-            if constexpr (step + 1 < 4) issue(cur, a_stage, bst, step + 1, (step + 1) & 1);
-            else issue(nxt, a_next, bnx, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<4 * QNT>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                constexpr int t = q / QNT, j = q % QNT;
-                if constexpr (step == 0 && t == 0) {
-                    f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    acc[P][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step & 1][t], bb[step & 1][j][t], zero, 0, 0, 0);
-                } else {
-                    acc[P][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step & 1][t], bb[step & 1][j][t], acc[P][j], 0, 0, 0);
-                }
-                constexpr int g = step * 4 * QNT + q;   // MFMA index within the interval (32 total)
-                // fold of the previous product: elements 4g .. 4g+3 of the 4 outputs x QNT x 16 accumulator lattice
-                static_for<4>([&](auto ec) {
-                    constexpr int idx = g * 4 + decltype(ec)::value;
-                    constexpr int o = idx / (QNT * 16), jj = (idx / 16) % QNT, r = idx % 16;
-                    const float ko = o == 0 ? kprev.k0 : (o == 1 ? kprev.k1 : (o == 2 ? kprev.k2 : kprev.k3));
-                    Y[o][jj][r] = fmaf(ko, acc[1 - P][jj][r], Y[o][jj][r]);
-                });
-                if constexpr (g % 4 == 3 && g / 4 < B_INSTR) {
-                    dma_weight_piece(std::integral_constant<int, g / 4>{}, it + 3, (it + 3) % Q2RING);
-                } else if constexpr (g == 4 * B_INSTR + 3) {
-                    if (xi < 6) dma_patch_piece(2 * xi, cc + 1, (cc + 1) & 1);
-                } else if constexpr (g == 4 * B_INSTR + 7) {
-                    if (xi < 6) dma_patch_piece(2 * xi + 1, cc + 1, (cc + 1) & 1);
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (step + 1 < 4) combine(cur, (step + 1) & 1);
-            else combine(nxt, 0);
-        });
-        // everything but this and the previous interval's pieces has landed: the weights of interval it + 1 (issued two
-        // intervals ago) and, by the end of interval 7 of a chunk, the next chunk's patch
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        __syncthreads();
-    };
-
-    // ---- prologue: patch of chunk 0, weights of intervals 0..2
-    for (int j = 0; j < Q2A_PIECES; ++j) dma_patch_piece(j, 0, 0);
-    for (int k = 0; k < 3; ++k) static_for<B_INSTR>([&](auto jc) { dma_weight_piece(jc, k, k); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    Coef kprev{0.f, 0.f, 0.f, 0.f}, kcur = fold_coef(0);   // coefficients of the product being folded / being computed
-    Frag fc = frag_of(0);
-    issue(fc, As, Bs + px * (QBN * BK), 0, 0);
-    combine(fc, 0);
-    int xi = 0, cc = 0;
-    for (int it = 0; it < nint; it += 2) {
-        // even interval -> acc[0]
-        {
-            int xn = xi + 1, cn = cc;
-            if (xn == 9) { xn = 0; ++cn; }
-            const Frag fn = frag_of(xn);
-            interval(std::integral_constant<int, 0>{}, fc, fn, xi, cc, it, kprev, As + (cc & 1) * A_STAGE,
-                     Bs + (it % Q2RING) * B_STAGE, As + (cn & 1) * A_STAGE, Bs + ((it + 1) % Q2RING) * B_STAGE);
-            kprev = kcur;   // the interval just finished becomes "previous"
-            kcur = fold_coef(xn);
-            fc = fn; xi = xn; cc = cn;
-        }
-        if (it + 1 >= nint) break;
-        // odd interval -> acc[1]
-        {
-            int xn = xi + 1, cn = cc;
-            if (xn == 9) { xn = 0; ++cn; }
-            const Frag fn = frag_of(xn);
-            interval(std::integral_constant<int, 1>{}, fc, fn, xi, cc, it + 1, kprev, As + (cc & 1) * A_STAGE,
-                     Bs + ((it + 1) % Q2RING) * B_STAGE, As + (cn & 1) * A_STAGE, Bs + ((it + 2) % Q2RING) * B_STAGE);
-            kprev = kcur;
-            kcur = fold_coef(xn);
-            fc = fn; xi = xn; cc = cn;
-        }
-    }
-    // the last interval's product is still unfolded: it sits in acc[(nint - 1) & 1] with coefficients kprev
-    auto fold_last = [&](auto pc_) {
-        constexpr int P = decltype(pc_)::value;
-        static_for<4>([&](auto oc) {
-            constexpr int o = decltype(oc)::value;
-            const float ko = o == 0 ? kprev.k0 : (o == 1 ? kprev.k1 : (o == 2 ? kprev.k2 : kprev.k3));
-            static_for<QNT>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                static_for<16>([&](auto rc) { constexpr int r = decltype(rc)::value; Y[o][j][r] = fmaf(ko, acc[P][j][r], Y[o][j][r]); });
-            });
-        });
-    };
-    if ((nint - 1) & 1) fold_last(std::integral_constant<int, 1>{});
-    else fold_last(std::integral_constant<int, 0>{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // out-of-range tail pieces still write zeros into the ring
-    __syncthreads();
-
-    // ---- epilogue: per output (oy,ox) of the tiles, stage the 128 x 64 block through LDS and store 16-byte pieces
-    constexpr int LDO = QBN + 4, C4 = QBN / 4, NTHR = Q2WAVES * 64, ROWS = Q2WAVES * 32, PER = ROWS * C4 / NTHR;
-    const int OH = 2 * p.H, OW = 2 * p.W;
-    static_for<4>([&](auto oc) {
-        constexpr int o = decltype(oc)::value;
-        if (o) __syncthreads();
-        static_for<QNT>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const int col = j * 32 + l31;
-            const float bias = p.bias[ntile * QBN + col];
-            static_for<16>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // (phase, tile) row of the block
-                smem[row * LDO + col] = Y[o][j][r] + bias;
-            });
-        });
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int idx = tid + k * NTHR;
-            const int row = idx / C4, c4 = idx - row * C4;
-            const int rw = row >> 5, rpx = rw >> 1, rt = (rw & 1) * 32 + (row & 31);
-            const int y = ty0 + 2 * (rt >> 3) + (o >> 1), x = tx0 + 2 * (rt & 7) + (o & 1);   // low-resolution pixel
-            const int n = ntile * QBN + c4 * 4;
-            if (y < p.H && x < p.W && n < p.Cout) {
-                float4 v = *reinterpret_cast<const float4*>(smem + row * LDO + c4 * 4);
-                v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
-                v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-                const size_t oo = ((size_t)(b * OH + 2 * y + pair) * OW + 2 * x + rpx) * p.Cout + n;
-                *reinterpret_cast<float4*>(p.out + oo) = v;
-            }
-        }
-    });
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
 size_t patch_wino_packed_elems(int Cin_packed, int Cout) {
@@ -645,16 +367,6 @@ hipError_t patch_wino_launch(const PatchLayer& L, const float* in0, const float*
     static const int yfe = [] { const char* e = getenv("EAMM_PWINO_YOUNG_FIRST"); return e ? atoi(e) : 1; }();
     a.young_first = yfe;
     a.trace = trace;
-    static const int v2 = [] { const char* e = getenv("EAMM_PWINO_V2"); return e ? atoi(e) : 1; }();
-    if (v2 && trace == nullptr) {   // one wave per SIMD, two phases per workgroup
-        constexpr size_t lds2 = sizeof(float) * (2 * QPAD * CONV_BK + Q2RING * 2 * QBN * CONV_BK);
-        static_assert(lds2 <= 160 * 1024 && sizeof(float) * Q2WAVES * 32 * (QBN + 4) <= lds2, "LDS budget");
-        static unsigned long long configured2 = 0;
-        if (hipError_t e = ensure_dynamic_lds(conv_patch_wino2_kernel, lds2, &configured2); e != hipSuccess) return e;
-        const int blocks2 = a.tiles_x * a.tiles_y * B * a.ntiles * 2;
-        hipLaunchKernelGGL(conv_patch_wino2_kernel, dim3(blocks2), dim3(Q2WAVES * 64), lds2, stream, a);
-        return hipGetLastError();
-    }
     constexpr size_t lds_loop = sizeof(float) * 2 * (QPAD * CONV_BK + 4 * QBN * CONV_BK);
     constexpr size_t lds_epi = sizeof(float) * 256 * (QBN + 4);
     constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
