@@ -140,15 +140,15 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
     // exists ONCE (transform point at run time, wave-uniform): nine unrolled copies next to the 128 + 32 accumulator
     // registers are more than the register allocator places without spilling.
     //   (B^T e B)[ti][tj] = sum over rows {ra, rb} x columns {ca, cb} of +-e:  ti = 0: e0 - e1, 1: e1, 2: e1 - e2.
-    // Fragment addresses of transform point xi.  They are computed for the NEXT interval before the barrier that ends
-    // the current one (while the partner wave still has the matrix pipe), so that after the barrier a wave goes straight
-    // to its first LDS reads.
-    struct Frag { int b00, b01, b10, b11; };
-    auto frag_of = [&](int xi) {
+    auto compute = [&](int xi, int a_st, int b_st, int it_next, int cc_next, bool more_w, bool more_a) {
         const int ti = xi / 3, tj = xi - 3 * ti;
         const int ra = ti == 0 ? 0 : 1, rb = ti == 2 ? 2 : 1, ca = tj == 0 ? 0 : 1, cb = tj == 2 ? 2 : 1;
-        int ty_l = tl >> 3, tx_l = tl & 7;     // opaque per interval: keeps the fragment addresses out of loop-invariant VGPRs
-        asm volatile("" : "+v"(ty_l), "+v"(tx_l));
+        const float si = ti == 1 ? 0.f : -1.f, sj = tj == 1 ? 0.f : -1.f;      // weight of the (rb) row / (cb) column
+        const float sij = si * sj;
+        const float* a_stage = As + a_st * A_STAGE;
+        const float* b_stage = Bs + b_st * B_STAGE + ph * (QBN * BK);
+        int ty_l = tl >> 3, tx_l = tl & 7, l31_l = l31;     // opaque per interval: keeps the fragment addresses out of loop-invariant VGPRs
+        asm volatile("" : "+v"(ty_l), "+v"(tx_l), "+v"(l31_l));
         // term (a,b) reads patch pixel (2 Ty + py + a, 2 Tx + px + b) -> position parity*QHALF + row*(QW/2) + half-column
         // LDS float index of a term's 16 bytes at K step s: base ^ (8 s) -- the step only flips bits 1-2 of the
         // XOR-swizzled slot, so one v_xor per read replaces the per-step address arithmetic
@@ -158,19 +158,7 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
             const int pos = (pb & 1) * QHALF + r * (QW / 2) + chn;
             return pos * BK + ((half ^ patch_swz(r, chn)) << 2);
         };
-        Frag f;
-        f.b00 = term(ra, ca); f.b01 = term(ra, cb); f.b10 = term(rb, ca); f.b11 = term(rb, cb);
-        return f;
-    };
-    auto compute = [&](const Frag& fr, int xi, int a_st, int b_st, int it_next, int cc_next, bool more_w, bool more_a) {
-        const int ti = xi / 3, tj = xi - 3 * ti;
-        const float si = ti == 1 ? 0.f : -1.f, sj = tj == 1 ? 0.f : -1.f;      // weight of the (rb) row / (cb) column
-        const float sij = si * sj;
-        const float* a_stage = As + a_st * A_STAGE;
-        const float* b_stage = Bs + b_st * B_STAGE + ph * (QBN * BK);
-        int l31_l = l31;
-        asm volatile("" : "+v"(l31_l));
-        const int b00 = fr.b00, b01 = fr.b01, b10 = fr.b10, b11 = fr.b11;
+        const int b00 = term(ra, ca), b01 = term(ra, cb), b10 = term(rb, ca), b11 = term(rb, cb);
         const int bw0 = l31_l * BK + ((half ^ ((l31_l >> 1) & 7)) << 2);
         f32x4 a[2], bb[2][QNT], raw[4];
         auto issue = [&](auto sc_, int buf) {
@@ -251,15 +239,12 @@ __global__ __launch_bounds__(QWAVES * 64) void conv_patch_wino_kernel(const Patc
     int b_st = 0;
     const int nint = cchunks * 9;
     int cc = 0, xi = 0;
-    Frag fr = frag_of(0);
     for (int it = 0; it < nint; ++it) {
         const int a_st = cc & 1;
         long long ts0 = 0, ts1 = 0;
         if (p.trace) ts0 = __builtin_readcyclecounter();
-        compute(fr, xi, a_st, b_st, it + 1, cc + 1, it + 1 < nint, cc + 1 < cchunks);
+        compute(xi, a_st, b_st, it + 1, cc + 1, it + 1 < nint, cc + 1 < cchunks);
         if (p.trace) ts1 = __builtin_readcyclecounter();
-        fr = frag_of(xi == 8 ? 0 : xi + 1);                                  // next interval's addresses, before the barrier
-        asm volatile("" : "+v"(fr.b00), "+v"(fr.b01), "+v"(fr.b10), "+v"(fr.b11));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (p.trace && blockIdx.x == 0 && lane == 0 && it < 72) {
             long long* d = p.trace + (wave * 72 + it) * 3;
