@@ -239,10 +239,22 @@ __global__ __launch_bounds__(HR_TILE) void motion_head_rowsplit_kernel(const flo
     const int NV = 7 * NC, LD = NV | 1;
     const int x0 = blockIdx.x * HR_TILE, y = blockIdx.y, f = blockIdx.z;
     const float* row = part + ((size_t)(f * h + y) * w) * PS;
-    for (int i = threadIdx.x; i < (HR_TILE + 6) * NV; i += blockDim.x) {
-        const int px = i / NV, c = i - px * NV;
-        const int x = x0 + px - 3;
-        tile[px * LD + c] = (unsigned)x < (unsigned)w ? row[(size_t)x * PS + c] : 0.f;
+    if (((NV | PS) & 3) == 0) {   // 16-byte loads (the pixel stride and the used width are multiples of 4 floats)
+        const int NV4 = NV >> 2;
+        for (int i = threadIdx.x; i < (HR_TILE + 6) * NV4; i += blockDim.x) {
+            const int px = i / NV4, c4 = i - px * NV4;
+            const int x = x0 + px - 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)x < (unsigned)w) v = *reinterpret_cast<const float4*>(row + (size_t)x * PS + 4 * c4);
+            float* d = tile + px * LD + 4 * c4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < (HR_TILE + 6) * NV; i += blockDim.x) {
+            const int px = i / NV, c = i - px * NV;
+            const int x = x0 + px - 3;
+            tile[px * LD + c] = (unsigned)x < (unsigned)w ? row[(size_t)x * PS + c] : 0.f;
+        }
     }
     __syncthreads();
     const int x = x0 + threadIdx.x;
