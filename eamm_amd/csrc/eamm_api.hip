@@ -1063,8 +1063,8 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         if (wd) (void)hipFree(wd);
         return rc;   // bias is not applied here (the gather kernel adds it in the pipeline): callers pass zeros
     }
-    if (tile_n == 3000 || tile_n == 3001 || tile_n == 3002) {   // 3002: 3001 + interval trace into `resid` (diagnostic)  // spatial-patch kernel for the collapsed up-convolution (3001: Winograd F(2x2,2x2) form)
-        const bool pw = tile_n != 3000;
+    if (tile_n == 3000 || tile_n == 3001 || tile_n == 3002 || tile_n == 3003) {   // 3003: polyphase minimal-filtering form   // 3002: 3001 + interval trace into `resid` (diagnostic)  // spatial-patch kernel for the collapsed up-convolution (3001: Winograd F(2x2,2x2) form)
+        const bool pw = tile_n == 3001 || tile_n == 3002, pp = tile_n == 3003;
         long long* trace = tile_n == 3002 ? reinterpret_cast<long long*>(const_cast<float*>(resid)) : nullptr;
         if (tile_n == 3002) resid = nullptr;
         if (kh != 3 || kw != 3 || !up || pool || resid || splitk > 1 || (Cout & 3) || (pw && ((Hin | Win) & 1)))
@@ -1080,6 +1080,10 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
             packed_w.resize(patch_wino_packed_elems(C0 + C1, Cout));
             patch_wino_pack_host(w_host, Cout, C0 + C1, nullptr, C0 + C1, packed_w.data());
         }
+        if (pp) {
+            packed_w.resize(patch_poly_packed_elems(C0 + C1, Cout));
+            patch_poly_pack_host(w_host, Cout, C0 + C1, nullptr, C0 + C1, packed_w.data());
+        }
         std::copy(b_host, b_host + Cout, bias.begin());
         int rc = EAMM_OK;
         auto bad = [&](hipError_t e, const char* what) {
@@ -1090,11 +1094,12 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
             !bad(hipMalloc((void**)&P.bias, bias.size() * sizeof(float)), "hipMalloc") &&
             !bad(hipMemcpy(P.w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
             !bad(hipMemcpy(P.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
-            (!pw || (!bad(hipMalloc((void**)&P.w_wino, packed_w.size() * sizeof(float)), "hipMalloc") &&
-                     !bad(hipMemcpy(P.w_wino, packed_w.data(), packed_w.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")))) {
+            (!(pw || pp) || (!bad(hipMalloc((void**)(pp ? &P.w_poly : &P.w_wino), packed_w.size() * sizeof(float)), "hipMalloc") &&
+                             !bad(hipMemcpy(pp ? P.w_poly : P.w_wino, packed_w.data(), packed_w.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")))) {
             auto run = [&]() {
-                return pw ? patch_wino_launch(P, in0, in1, B, Hin, Win, act, out, s, trace)
-                          : patch_phase_launch(P, in0, in1, B, Hin, Win, act, out, s);
+                return pp ? patch_poly_launch(P, in0, in1, B, Hin, Win, act, out, s)
+                          : pw ? patch_wino_launch(P, in0, in1, B, Hin, Win, act, out, s, trace)
+                               : patch_phase_launch(P, in0, in1, B, Hin, Win, act, out, s);
             };
             if (!bad(run(), "patch launch") && iters > 0 && avg_ms) {
                 hipEvent_t e0, e1;
@@ -1114,6 +1119,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         }
         if (P.w) (void)hipFree(P.w);
         if (P.w_wino) (void)hipFree(P.w_wino);
+        if (P.w_poly) (void)hipFree(P.w_poly);
         if (P.bias) (void)hipFree(P.bias);
         return rc;
     }
