@@ -89,11 +89,13 @@ __global__ __launch_bounds__(YWAVES * 64) void conv_patch_poly_kernel(const Patc
     auto dma_patch_piece = [&](auto jc, int cc, int st) {
         constexpr int j = decltype(jc)::value;
         if ((wave + YWAVES * j) * 8 < YPAD) {
-            const int i = (wave + YWAVES * j) * 8 + (lane >> 3);   // patch pixel
+            int lane_l = lane;                                     // opaque: the piece's address arithmetic is redone per use
+            asm volatile("" : "+v"(lane_l));                       // (hoisted out of the chunk loop it pins ~20 VGPRs -> scratch)
+            const int i = (wave + YWAVES * j) * 8 + (lane_l >> 3);   // patch pixel
             const int pyy = i / YW, pxx = i - pyy * YW;
             const int y = ty0 + pyy - 1, x = tx0 + pxx - 1;
             const bool ok = i < YPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            const int slot = ((lane & 7) ^ ((i >> 1) & 7)) << 2;
+            const int slot = ((lane_l & 7) ^ ((i >> 1) & 7)) << 2;
             const int c0 = cc * BK;
             const bool first = c0 < p.C0;
             const int C = first ? p.C0 : p.C1;
@@ -153,13 +155,17 @@ __global__ __launch_bounds__(YWAVES * 64) void conv_patch_poly_kernel(const Patc
             });
         });
         const float* bt0 = b_stage + S * (YBN * BK);
-        f32x4 raw[NR * NC], a[2], bb[2][YNT];
-        auto fetch = [&](int s, int buf) {
+        // the patch terms of the next step are fetched under the current step's MFMAs (two fragment buffers); the weight
+        // rows are fetched between steps into ONE buffer (the partner wave owns the matrix pipe meanwhile): 8 VGPRs fewer
+        f32x4 raw[NR * NC], a[2], bb[YNT];
+        auto fetch_a = [&](int s) {
 #pragma unroll
             for (int k = 0; k < NR * NC; ++k) raw[k] = *reinterpret_cast<const f32x4*>(a_stage + (ta[k] ^ (8 * s)));
+        };
+        auto fetch_b = [&](int s) {
             const float* bt = bt0 + (bw0_l ^ (8 * s));
 #pragma unroll
-            for (int j = 0; j < YNT; ++j) bb[buf][j] = *reinterpret_cast<const f32x4*>(bt + j * 32 * BK);
+            for (int j = 0; j < YNT; ++j) bb[j] = *reinterpret_cast<const f32x4*>(bt + j * 32 * BK);
         };
         auto combine = [&](int buf) {
             f32x4 v;
@@ -170,22 +176,23 @@ __global__ __launch_bounds__(YWAVES * 64) void conv_patch_poly_kernel(const Patc
         };
         constexpr int NFOLD = (FMASK & 1) + ((FMASK >> 1) & 1) + ((FMASK >> 2) & 1) + ((FMASK >> 3) & 1);
         constexpr int FE = NFOLD * YNT * 16;                        // fold adds of this point
-        fetch(0, 0);
+        fetch_a(0);
+        fetch_b(0);
         combine(0);
         static_for<4>([&](auto stc) {
             constexpr int step = decltype(stc)::value;
-            if constexpr (step + 1 < 4) fetch(step + 1, (step + 1) & 1);
+            if constexpr (step + 1 < 4) fetch_a(step + 1);
             __builtin_amdgcn_sched_barrier(0);
             static_for<4 * YNT>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 constexpr int t = q / YNT, j = q % YNT;
                 if constexpr (DST < 4) {
-                    Y[DST][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step & 1][t], bb[step & 1][j][t], Y[DST][j], 0, 0, 0);
+                    Y[DST][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step & 1][t], bb[j][t], Y[DST][j], 0, 0, 0);
                 } else if constexpr (step == 0 && t == 0) {
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step & 1][t], bb[step & 1][j][t], zero, 0, 0, 0);
+                    M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step & 1][t], bb[j][t], zero, 0, 0, 0);
                 } else {
-                    M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step & 1][t], bb[step & 1][j][t], M[j], 0, 0, 0);
+                    M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step & 1][t], bb[j][t], M[j], 0, 0, 0);
                 }
                 constexpr int g = step * 4 * YNT + q;               // MFMA index within the point (32 total)
                 // this gap's share of the fold: elements [g*FE/32, (g+1)*FE/32) of the (output, n-tile, register) lattice
@@ -209,7 +216,10 @@ __global__ __launch_bounds__(YWAVES * 64) void conv_patch_poly_kernel(const Patc
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (step + 1 < 4) combine((step + 1) & 1);
+            if constexpr (step + 1 < 4) {
+                fetch_b(step + 1);
+                combine((step + 1) & 1);
+            }
         });
     };
 
