@@ -88,7 +88,7 @@ struct PatchLayer {
     int C0 = 0, C1 = 0, Cout = 0;
     float* w = nullptr;     // device, packed [ntile][cchunk][phase][tap][64][32]
     float* w_wino = nullptr;  // device, Winograd F(2x2,2x2) form [ntile][cchunk][xi 9][phase 4][64][32] (conv_mfma_patch_wino.hip)
-    float* w_poly = nullptr;  // device, polyphase minimal-filtering form [ntile][cchunk][i 3][slot 3][64][32] (conv_mfma_patch_poly.hip)
+    float* w_poly = nullptr;  // device, polyphase minimal-filtering form [ntile 32][cchunk][point 9][32][32] (conv_mfma_patch_poly.hip)
     float* bias = nullptr;  // device, [ntiles*64]
 };
 size_t patch_packed_elems(int Cin_packed, int Cout);
