@@ -57,7 +57,7 @@ struct CtxBase {
     int skinny_max_m = 16384;   // largest per-phase pixel count served by the 32- / 64-row tiles (EAMM_SKINNY_MAX_M; 0 = off):
                                 // 64x128 tiles need no split-K where 256x128 ones do (measured 256x256: 1 frame 753 -> 785, 4 frames 1969 -> 2067,
                                 // 8 frames 2756 -> 2782 frames/s; 16 frames unchanged)
-    int patch_min_blocks = 192; // fewest workgroups for which UpBlock2d layers use the spatial-patch kernel (< 0: never)
+    int patch_min_blocks = 128; // fewest workgroups for which UpBlock2d layers use the spatial-patch kernel (< 0: never)
 };
 
 // Every C entry point that touches the device runs under one of these: the handle's device becomes current for
@@ -351,7 +351,7 @@ const ConvLayer& pick(const CtxBase* c, const LayerSet& S, size_t M) {
 // UpBlock2d launch: the spatial-patch kernel when its 16x16-pixel tiles fill the chip, else the im2col-style kernels
 int launch_up(CtxBase* c, const LayerSet& S, const ConvIO& io, hipStream_t s) {
     if (S.has_patch) {
-        const int blocks = ((io.Hin + 15) / 16) * ((io.Win + 15) / 16) * io.B * ((S.patch.Cout + 63) / 64);
+        const int blocks = ((io.Hin + 15) / 16) * ((io.Win + 15) / 16) * io.B * ((S.patch.Cout + 31) / 32);   // of the polyphase kernel
         if (blocks >= c->patch_min_blocks && io.Hin >= 16 && io.Win >= 16 && io.act == ACT_RELU && !io.resid && !io.out2 && !io.pool && !io.nchw) {
             if (S.patch.w_poly)
                 HIP_TRY(c, patch_poly_launch(S.patch, io.in0, io.in1, io.B, io.Hin, io.Win, io.act, io.out, s));
