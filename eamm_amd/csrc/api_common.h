@@ -52,8 +52,7 @@ struct CtxBase {
     int dma_min_m = 1024;       // smallest per-phase M for which an LDS-DMA tile is preferred
     int big_min_m = 49152;      // ... and for which Cout % 256 == 0 layers use the 256x256 tile (>= 192 M tiles)
     int dma_cfg_n256 = 2, dma_cfg_n128 = 2, dma_cfg_n64 = 3;
-    int patch_wino = 1;         // up blocks on the patch kernel in Winograd F(2x2,2x2) form (EAMM_PATCH_WINO)
-    int patch_poly = 1;         // ... in the polyphase minimal-filtering form, which takes precedence (EAMM_PATCH_POLY)
+    int patch_poly = 1;         // up blocks on the patch kernel in the polyphase minimal-filtering form (EAMM_PATCH_POLY; 0: collapsed-phase form)
     int skinny_max_m = 16384;   // largest per-phase pixel count served by the 32- / 64-row tiles (EAMM_SKINNY_MAX_M; 0 = off):
                                 // 64x128 tiles need no split-K where 256x128 ones do (measured 256x256: 1 frame 753 -> 785, 4 frames 1969 -> 2067,
                                 // 8 frames 2756 -> 2782 frames/s; 16 frames unchanged)
@@ -250,21 +249,17 @@ int build_patch(CtxBase* c, const std::string& conv, const std::string& norm, in
     P->C0 = C0_packed;
     P->C1 = C1_packed;
     P->Cout = Cout;
-    std::vector<float> packed(patch_packed_elems(cin_packed, Cout));
-    patch_pack_host(wf.data(), Cout, Cin, map.data(), cin_packed, packed.data());
     std::vector<float> bias_pad((size_t)((Cout + 63) / 64) * 64, 0.f);
     std::copy(bf.begin(), bf.end(), bias_pad.begin());
-    int rc = upload(c, &P->w, packed);
-    if (rc) return rc;
+    int rc = 0;
     if (c->patch_poly) {
         std::vector<float> pp(patch_poly_packed_elems(cin_packed, Cout));
         patch_poly_pack_host(wf.data(), Cout, Cin, map.data(), cin_packed, pp.data());
         if ((rc = upload(c, &P->w_poly, pp))) return rc;
-    }
-    if (c->patch_wino) {
-        std::vector<float> pw(patch_wino_packed_elems(cin_packed, Cout));
-        patch_wino_pack_host(wf.data(), Cout, Cin, map.data(), cin_packed, pw.data());
-        if ((rc = upload(c, &P->w_wino, pw))) return rc;
+    } else {
+        std::vector<float> packed(patch_packed_elems(cin_packed, Cout));
+        patch_pack_host(wf.data(), Cout, Cin, map.data(), cin_packed, packed.data());
+        if ((rc = upload(c, &P->w, packed))) return rc;
     }
     return upload(c, &P->bias, bias_pad);
 }
@@ -355,8 +350,6 @@ int launch_up(CtxBase* c, const LayerSet& S, const ConvIO& io, hipStream_t s) {
         if (blocks >= c->patch_min_blocks && io.Hin >= 16 && io.Win >= 16 && io.act == ACT_RELU && !io.resid && !io.out2 && !io.pool && !io.nchw) {
             if (S.patch.w_poly)
                 HIP_TRY(c, patch_poly_launch(S.patch, io.in0, io.in1, io.B, io.Hin, io.Win, io.act, io.out, s));
-            else if (S.patch.w_wino && !(io.Hin & 1) && !(io.Win & 1))
-                HIP_TRY(c, patch_wino_launch(S.patch, io.in0, io.in1, io.B, io.Hin, io.Win, io.act, io.out, s));
             else
                 HIP_TRY(c, patch_phase_launch(S.patch, io.in0, io.in1, io.B, io.Hin, io.Win, io.act, io.out, s));
             return EAMM_OK;
@@ -380,7 +373,6 @@ inline void read_tile_knobs(CtxBase* c) {
     // tuning knobs (defaults measured on MI355X, profiles/): EAMM_DMA_MIN_M < 0 disables the LDS-DMA kernels
     c->dma_min_m = env_int("EAMM_DMA_MIN_M", c->dma_min_m);
     c->big_min_m = env_int("EAMM_BIG_MIN_M", c->big_min_m);
-    c->patch_wino = env_int("EAMM_PATCH_WINO", c->patch_wino);
     c->patch_poly = env_int("EAMM_PATCH_POLY", c->patch_poly);
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
     c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);

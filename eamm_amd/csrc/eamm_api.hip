@@ -1063,43 +1063,32 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         if (wd) (void)hipFree(wd);
         return rc;   // bias is not applied here (the gather kernel adds it in the pipeline): callers pass zeros
     }
-    if (tile_n == 3000 || tile_n == 3001 || tile_n == 3002 || tile_n == 3003) {   // 3003: polyphase minimal-filtering form   // 3002: 3001 + interval trace into `resid` (diagnostic)  // spatial-patch kernel for the collapsed up-convolution (3001: Winograd F(2x2,2x2) form)
-        const bool pw = tile_n == 3001 || tile_n == 3002, pp = tile_n == 3003;
-        long long* trace = tile_n == 3002 ? reinterpret_cast<long long*>(const_cast<float*>(resid)) : nullptr;
-        if (tile_n == 3002) resid = nullptr;
-        if (kh != 3 || kw != 3 || !up || pool || resid || splitk > 1 || (Cout & 3) || (pw && ((Hin | Win) & 1)))
+    if (tile_n == 3000 || tile_n == 3003) {   // spatial-patch kernels for the up-convolution: 3000 collapsed-phase form, 3003 polyphase minimal-filtering form
+        const bool pp = tile_n == 3003;
+        if (kh != 3 || kw != 3 || !up || pool || resid || splitk > 1 || (Cout & 3))
             return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported patch-kernel configuration");
         PatchLayer P;
         P.C0 = C0;
         P.C1 = C1;
         P.Cout = Cout;
-        std::vector<float> packed(patch_packed_elems(C0 + C1, Cout)), bias((size_t)((Cout + 63) / 64) * 64, 0.f);
-        patch_pack_host(w_host, Cout, C0 + C1, nullptr, C0 + C1, packed.data());
-        std::vector<float> packed_w;
-        if (pw) {
-            packed_w.resize(patch_wino_packed_elems(C0 + C1, Cout));
-            patch_wino_pack_host(w_host, Cout, C0 + C1, nullptr, C0 + C1, packed_w.data());
-        }
-        if (pp) {
-            packed_w.resize(patch_poly_packed_elems(C0 + C1, Cout));
-            patch_poly_pack_host(w_host, Cout, C0 + C1, nullptr, C0 + C1, packed_w.data());
-        }
+        std::vector<float> packed(pp ? patch_poly_packed_elems(C0 + C1, Cout) : patch_packed_elems(C0 + C1, Cout));
+        std::vector<float> bias((size_t)((Cout + 63) / 64) * 64, 0.f);
+        if (pp) patch_poly_pack_host(w_host, Cout, C0 + C1, nullptr, C0 + C1, packed.data());
+        else patch_pack_host(w_host, Cout, C0 + C1, nullptr, C0 + C1, packed.data());
         std::copy(b_host, b_host + Cout, bias.begin());
+        float** wslot = pp ? &P.w_poly : &P.w;
         int rc = EAMM_OK;
         auto bad = [&](hipError_t e, const char* what) {
             if (e != hipSuccess) rc = fail(nullptr, EAMM_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
             return e != hipSuccess;
         };
-        if (!bad(hipMalloc((void**)&P.w, packed.size() * sizeof(float)), "hipMalloc") &&
+        if (!bad(hipMalloc((void**)wslot, packed.size() * sizeof(float)), "hipMalloc") &&
             !bad(hipMalloc((void**)&P.bias, bias.size() * sizeof(float)), "hipMalloc") &&
-            !bad(hipMemcpy(P.w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
-            !bad(hipMemcpy(P.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
-            (!(pw || pp) || (!bad(hipMalloc((void**)(pp ? &P.w_poly : &P.w_wino), packed_w.size() * sizeof(float)), "hipMalloc") &&
-                             !bad(hipMemcpy(pp ? P.w_poly : P.w_wino, packed_w.data(), packed_w.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")))) {
+            !bad(hipMemcpy(*wslot, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
+            !bad(hipMemcpy(P.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")) {
             auto run = [&]() {
                 return pp ? patch_poly_launch(P, in0, in1, B, Hin, Win, act, out, s)
-                          : pw ? patch_wino_launch(P, in0, in1, B, Hin, Win, act, out, s, trace)
-                               : patch_phase_launch(P, in0, in1, B, Hin, Win, act, out, s);
+                          : patch_phase_launch(P, in0, in1, B, Hin, Win, act, out, s);
             };
             if (!bad(run(), "patch launch") && iters > 0 && avg_ms) {
                 hipEvent_t e0, e1;
@@ -1118,7 +1107,6 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
             bad(hipStreamSynchronize(s), "hipStreamSynchronize");
         }
         if (P.w) (void)hipFree(P.w);
-        if (P.w_wino) (void)hipFree(P.w_wino);
         if (P.w_poly) (void)hipFree(P.w_poly);
         if (P.bias) (void)hipFree(P.bias);
         return rc;

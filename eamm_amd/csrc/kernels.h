@@ -87,15 +87,10 @@ hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream,
 struct PatchLayer {
     int C0 = 0, C1 = 0, Cout = 0;
     float* w = nullptr;     // device, packed [ntile][cchunk][phase][tap][64][32]
-    float* w_wino = nullptr;  // device, Winograd F(2x2,2x2) form [ntile][cchunk][xi 9][phase 4][64][32] (conv_mfma_patch_wino.hip)
     float* w_poly = nullptr;  // device, polyphase minimal-filtering form [ntile 32][cchunk][point 9][32][32] (conv_mfma_patch_poly.hip)
     float* bias = nullptr;  // device, [ntiles*64]
 };
 size_t patch_packed_elems(int Cin_packed, int Cout);
-size_t patch_wino_packed_elems(int Cin_packed, int Cout);
-void patch_wino_pack_host(const float* w_oihw_3x3, int Cout, int Cin, const int* cin_map, int cin_packed, float* dst);
-hipError_t patch_wino_launch(const PatchLayer& L, const float* in0, const float* in1, int B, int H, int W, int act,
-                             float* out, hipStream_t stream, long long* trace = nullptr);
 size_t patch_poly_packed_elems(int Cin_packed, int Cout);
 void patch_poly_pack_host(const float* w_oihw_3x3, int Cout, int Cin, const int* cin_map, int cin_packed, float* dst);
 hipError_t patch_poly_launch(const PatchLayer& L, const float* in0, const float* in1, int B, int H, int W, int act,

@@ -115,12 +115,6 @@ CASES = {
     "patch_up_concat":   dict(B=1, H=32, W=16, C0=32, C1=64, Cout=128, ks=3, up=1, act=1, tile_n=3000),
     "patch_up_ragged":   dict(B=2, H=10, W=22, C0=32, C1=0, Cout=40, ks=3, up=1, act=1, tile_n=3000),
     "patch_up1_like":    dict(B=1, H=64, W=64, C0=128, C1=0, Cout=64, ks=3, up=1, act=1, tile_n=3000),
-    # ... in Winograd F(2x2,2x2) form (tile_n = 3001)
-    "pwino_up_basic":    dict(B=2, H=16, W=16, C0=64, C1=0, Cout=64, ks=3, up=1, act=1, tile_n=3001),
-    "pwino_up_concat":   dict(B=1, H=32, W=16, C0=32, C1=64, Cout=128, ks=3, up=1, act=1, tile_n=3001),
-    "pwino_up_ragged":   dict(B=2, H=10, W=22, C0=32, C1=0, Cout=40, ks=3, up=1, act=1, tile_n=3001),
-    "pwino_up1_like":    dict(B=1, H=64, W=64, C0=128, C1=0, Cout=64, ks=3, up=1, act=1, tile_n=3001),
-    "pwino_up0_like":    dict(B=2, H=32, W=32, C0=256, C1=0, Cout=128, ks=3, up=1, act=0, tile_n=3001),
     # ... in polyphase minimal-filtering form (tile_n = 3003)
     "ppoly_up_basic":    dict(B=2, H=16, W=16, C0=64, C1=0, Cout=64, ks=3, up=1, act=1, tile_n=3003),
     "ppoly_up_concat":   dict(B=1, H=32, W=16, C0=32, C1=64, Cout=128, ks=3, up=1, act=1, tile_n=3003),

@@ -60,7 +60,7 @@ def main():
                 continue
             if 2000 <= tile < 2200 and (up or pool or C1 or C0 % 64 or (tile >= 2100 and (H % 4 or W % 4))):
                 continue
-            if tile in (3000, 3001, 3003) and (not up or resid):
+            if tile in (3000, 3003) and (not up or resid):
                 continue
             if 1000 < tile < 2000 and {1001: 256, 1002: 128, 1003: 64, 1004: 128, 1005: 128}[tile] > max(Cout, 64) * 2:
                 continue
