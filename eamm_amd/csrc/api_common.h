@@ -336,6 +336,42 @@ int build_wino(CtxBase* c, const std::string& conv, const std::string& norm, int
     return upload(c, &L->bias, bias_pad);
 }
 
+// F(4x4,3x3) packing of a convolution whose input and output widths differ (hourglass DownBlock2d: conv -> BatchNorm
+// folded; reference modules/util.py:903-921); input channels Cin_real sit first in a Cin_packed-wide activation
+int build_wino4_rect(CtxBase* c, const std::string& conv, const std::string& norm, int Cin_real, int Cin_packed, WinoLayer* L) {
+    const HostTensor *wt = find(c, conv + ".weight"), *bt = find(c, conv + ".bias");
+    if (!wt || !bt || wt->shape.size() != 4 || wt->shape[1] != Cin_real || wt->shape[2] != 3 || wt->shape[3] != 3 ||
+        Cin_packed < Cin_real || Cin_packed % 64)
+        return fail(c, EAMM_ERR_KEY, "%s mis-shaped for the Winograd path", conv.c_str());
+    const int Cout = (int)wt->shape[0];
+    std::vector<float> wf((size_t)Cout * Cin_packed * 9, 0.f), bf(bt->data);
+    const HostTensor *g = nullptr, *be = nullptr, *mu = nullptr, *var = nullptr;
+    if (!norm.empty()) {
+        g = find(c, norm + ".weight"); be = find(c, norm + ".bias");
+        mu = find(c, norm + ".running_mean"); var = find(c, norm + ".running_var");
+        if (!g || !be || !mu || !var) return fail(c, EAMM_ERR_KEY, "BatchNorm entries of %s missing", norm.c_str());
+    }
+    for (int o = 0; o < Cout; ++o) {
+        const double sc = g ? (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5) : 1.0;
+        if (g) bf[o] = (float)(((double)bt->data[o] - (double)mu->data[o]) * sc + (double)be->data[o]);
+        for (int ci = 0; ci < Cin_real; ++ci)
+            for (int k = 0; k < 9; ++k)
+                wf[((size_t)o * Cin_packed + ci) * 9 + k] = (float)((double)wt->data[((size_t)o * Cin_real + ci) * 9 + k] * sc);
+    }
+    L->Cin = Cin_packed;
+    L->Cout = Cout;
+    L->tile = 4;
+    L->BN = 64;
+    L->ntiles = (Cout + L->BN - 1) / L->BN;
+    std::vector<float> packed(wino4_packed_elems(Cout, Cin_packed, L->BN));
+    wino4_pack_host(wf.data(), Cout, Cin_packed, L->BN, packed.data());
+    std::vector<float> bias_pad((size_t)L->ntiles * L->BN, 0.f);
+    std::copy(bf.begin(), bf.end(), bias_pad.begin());
+    int rc = upload(c, &L->u, packed);
+    if (rc) return rc;
+    return upload(c, &L->bias, bias_pad);
+}
+
 const ConvLayer& pick(const CtxBase* c, const LayerSet& S, size_t M) {
     // skinny GEMMs (deep hourglass levels at small batches): the weight stream is the cost, so tiles without padding rows
     if (S.has_skinny && M <= (size_t)c->skinny_max_m) return M <= 32 ? S.skinny32 : S.skinny64;

@@ -469,7 +469,9 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     });
 }
 
-// y fold of the split form: Y[p][q] = sum_i A^T[p][i] Z[i][q] (+ bias, residual, activation) -> the 4x4 output pixels
+// y fold of the split form: Y[p][q] = sum_i A^T[p][i] Z[i][q] (+ bias, residual, activation) -> the 4x4 output pixels;
+// POOL: followed by the 2x2 average of DownBlock2d (reference modules/util.py:903-921) -> 2x2 pixels of [B,H/2,W/2,Cout]
+template <bool POOL>
 __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Z, const float* __restrict__ bias,
                                                                      const float* __restrict__ resid, int Mq, int Cout, int H,
                                                                      int W, int act, float* __restrict__ out) {
@@ -485,6 +487,7 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
         const f32x4_t* z = reinterpret_cast<const f32x4_t*>(Z) + idx;
         const f32x4_t bs = reinterpret_cast<const f32x4_t*>(bias)[c4];
         const float lo = act == ACT_RELU ? 0.f : -INFINITY;
+        f32x4_t colsum[2];   // POOL: the two pooled rows of the current column pair
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4_t zi[6];
@@ -498,11 +501,29 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
             y[3] = d12 + 8.f * d34 + zi[5];
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
-                const size_t o = (((size_t)(b * H + 4 * qy + pp) * W + 4 * qx + q) * Cout) / 4 + c4;
                 f32x4_t v = y[pp] + bs;
-                if (resid != nullptr) v = v + reinterpret_cast<const f32x4_t*>(resid)[o];
-                v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
-                reinterpret_cast<f32x4_t*>(out)[o] = v;
+                if constexpr (!POOL) {
+                    const size_t o = (((size_t)(b * H + 4 * qy + pp) * W + 4 * qx + q) * Cout) / 4 + c4;
+                    if (resid != nullptr) v = v + reinterpret_cast<const f32x4_t*>(resid)[o];
+                    v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
+                    reinterpret_cast<f32x4_t*>(out)[o] = v;
+                } else {
+                    v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
+                    y[pp] = v;
+                }
+            }
+            if constexpr (POOL) {
+                if ((q & 1) == 0) {
+                    colsum[0] = y[0] + y[1];
+                    colsum[1] = y[2] + y[3];
+                } else {
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+                        const f32x4_t v = 0.25f * (colsum[py] + (y[2 * py] + y[2 * py + 1]));
+                        const size_t o = (((size_t)(b * (H >> 1) + 2 * qy + py) * (W >> 1) + 2 * qx + (q >> 1)) * Cout) / 4 + c4;
+                        reinterpret_cast<f32x4_t*>(out)[o] = v;
+                    }
+                }
             }
         }
     }
@@ -579,8 +600,9 @@ static hipError_t wino4_launch_variant(const Wino4Args& a, hipStream_t stream) {
 }
 
 hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, int W, int act, const float* resid,
-                             float* out, hipStream_t stream, int variant, int groups, float* zbuf) {
+                             float* out, hipStream_t stream, int variant, int groups, float* zbuf, int pool) {
     constexpr int BM = 64, BN = 64;
+    if (pool && (groups == 1 || resid != nullptr)) return hipErrorInvalidValue;   // the pooled epilogue lives in the output-transform kernel
     if (L.tile != 4 || L.BN != BN || (L.Cout & 3) || L.Cin % (2 * CONV_BK) || (H & 3) || (W & 3))
         return hipErrorInvalidValue;
     Wino4Args a{};
@@ -622,8 +644,12 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     if (e != hipSuccess || groups == 1) return e;
     const size_t total = (size_t)a.Mq * (L.Cout / 4);
     const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)1 << 20);
-    hipLaunchKernelGGL(wino4_output_transform_kernel, dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid, a.Mq, L.Cout, H,
-                       W, act, out);
+    if (pool)
+        hipLaunchKernelGGL(wino4_output_transform_kernel<true>, dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid, a.Mq,
+                           L.Cout, H, W, act, out);
+    else
+        hipLaunchKernelGGL(wino4_output_transform_kernel<false>, dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid, a.Mq,
+                           L.Cout, H, W, act, out);
     return hipGetLastError();
 }
 

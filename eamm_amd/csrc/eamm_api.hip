@@ -29,6 +29,11 @@ struct eamm_ctx : eamm::CtxBase {
     std::vector<LayerSet> down, hg_enc, hg_dec, res1, res2, up;
     std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
     std::vector<WinoLayer> w4res1, w4res2; // Winograd F(4x4,3x3) packing (bottleneck maps with sides divisible by 4)
+    std::vector<WinoLayer> w4enc;          // F(4x4,3x3) packing of the hourglass encoder convolutions (Cout == 0: level not eligible)
+    int enc_wino = 1;                      // hourglass DownBlock2d levels in F(4x4,3x3) form + pooled output transform (EAMM_ENC_WINO)
+    int enc_wino_min_mflop = 3000;         // ... for levels of at least this many direct-form MFLOP per call (EAMM_ENC_WINO_MIN_MFLOP): smaller ones are
+                                           // launch-bound and one launch beats three (measured 256x256: 1 frame 810 vs 804, 4 frames equal,
+                                           // 8 frames 2896 -> 2960, 12 frames 2849 -> 2968, 16 frames 3529 -> 3659; 512x512 x 8: 911 -> 948 frames/s)
     int bneck_chains = 2;                  // bottleneck as this many chains of frames on as many streams (EAMM_BNECK_CHAINS; 1 = off)
     int pass_chains = 1;                   // the whole per-frame pass as this many chains (EAMM_PASS_CHAINS; 1 = off, the default:
                                            // measured 256x256 -- 16 frames 3381 vs 3370 frames/s, 12 frames 2633 vs 2765, 8 frames 2744 vs 2197)
@@ -197,6 +202,8 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->pass_chains_min_frames = env_int("EAMM_PASS_CHAINS_MIN_FRAMES", c->pass_chains_min_frames);
     c->head_col7_min_tiles = env_int("EAMM_HEAD_COL7_MIN_TILES", c->head_col7_min_tiles);
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
+    c->enc_wino = env_int("EAMM_ENC_WINO", c->enc_wino);
+    c->enc_wino_min_mflop = env_int("EAMM_ENC_WINO_MIN_MFLOP", c->enc_wino_min_mflop);
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
     c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);
     c->dma_cfg_n64 = env_int("EAMM_DMA_CFG_N64", c->dma_cfg_n64);
@@ -310,6 +317,20 @@ int eamm_finalize_weights(eamm_ctx* c) {
         }
         if ((rc = upload(c, &c->pre_s[i], s))) return rc;
         if ((rc = upload(c, &c->pre_t[i], t))) return rc;
+    }
+    // hourglass encoder levels in F(4x4,3x3) form: they borrow the bottleneck's V / Z workspaces (a frame's share must fit)
+    if (c->enc_wino && !c->w4res1.empty()) {
+        c->w4enc.resize(c->nb);
+        const size_t hw_l = (size_t)c->h * c->w, hwf_l = (size_t)c->hf * c->wf;
+        for (int i = 0; i < c->nb; ++i) {
+            const int cr = i == 0 ? cin0 : c->enc_c[i - 1], cp = i == 0 ? c->Cp0 : c->enc_c[i - 1], co = c->enc_c[i];
+            const size_t tiles = (hw_l >> (2 * i)) / 16;
+            if (((c->h >> i) & 3) || ((c->w >> i) & 3) || cp % 64 || (co & 3) || 36 * tiles * cp > 4 * hwf_l * c->Cb ||
+                tiles * co > (hwf_l / 16) * c->Cb)
+                continue;
+            const std::string p = dm + "hourglass.encoder.down_blocks." + std::to_string(i);
+            if ((rc = build_wino4_rect(c, p + ".conv", p + ".norm", cr, cp, &c->w4enc[i]))) return rc;
+        }
     }
     c->up.resize(c->nd);
     for (int i = 0; i < c->nd; ++i) {
@@ -632,6 +653,24 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         io.out = v.e_buf[i];
         io.partial = v.partial;
         io.partial_cap = v.partial_elems;
+        const int tiles = n * (io.Hin / 4) * (io.Win / 4);
+        if (i < (int)c->w4enc.size() && c->w4enc[i].Cout &&
+            288e-6 * tiles * c->w4enc[i].Cin * c->w4enc[i].Cout >= (double)c->enc_wino_min_mflop) {   // 2 * 9 * 16 pixels per tile
+            // F(4x4,3x3): 4x fewer MACs; the transform-point rows are split over workgroups (>= 2: the pooled epilogue is
+            // the output-transform kernel's) -- the largest split that still fits one round of the chip
+            const WinoLayer& L = c->w4enc[i];
+            const int nblk = ((tiles + 63) / 64) * L.ntiles;
+            int cus = 256, g = 2;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            for (int gsel : {6, 3})
+                if (nblk * gsel <= cus) {
+                    g = gsel;
+                    break;
+                }
+            HIP_TRY(c, wino4_transform_launch(io.in0, nullptr, nullptr, n, io.Hin, io.Win, L.Cin, v.wino_v, s));
+            HIP_TRY(c, wino4_gemm_launch(L, v.wino_v, n, io.Hin, io.Win, ACT_RELU, nullptr, io.out, s, c->wino4_variant, g, v.wino_z, 1));
+            continue;
+        }
         HIP_TRY(c, conv_launch(pick(c, c->hg_enc[i], (size_t)n * io.Hin * io.Win), io, s));
     }
     STAGE_MARK(2);
@@ -1115,7 +1154,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         // 2150 + groups (2, 3, 6): F(4x4,3x3) with the transform-point rows split over workgroups + output-transform kernel
         const bool w4 = tile_n >= 2100;
         const int w4_groups = tile_n >= 2150 ? tile_n - 2150 : 1;
-        if (kh != 3 || kw != 3 || up || pool || C1 || splitk > 1 || C0 % 64 || (Cout & 3) ||
+        if (kh != 3 || kw != 3 || up || (pool && (w4_groups == 1 || resid)) || C1 || splitk > 1 || C0 % 64 || (Cout & 3) ||
             (w4 && ((Hin & 3) || (Win & 3))))
             return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported Winograd configuration");
         WinoLayer W;
@@ -1153,7 +1192,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
                 if (w4) {
                     if (tr) e = wino4_transform_launch(in0, nullptr, nullptr, B, Hin, Win, C0, V, s);
                     if (e != hipSuccess || !gm) return e;
-                    return wino4_gemm_launch(W, V, B, Hin, Win, act, resid, out, s, w4_groups > 1 ? 0 : tile_n - 2100, w4_groups, Zb);
+                    return wino4_gemm_launch(W, V, B, Hin, Win, act, resid, out, s, w4_groups > 1 ? 0 : tile_n - 2100, w4_groups, Zb, pool);
                 }
                 if (tr) e = wino_transform_launch(in0, nullptr, nullptr, B, Hin, Win, C0, V, s);
                 if (e != hipSuccess || !gm) return e;

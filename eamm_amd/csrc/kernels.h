@@ -130,9 +130,10 @@ void wino4_pack_host(const float* w_oihw, int Cout, int Cin, int BN, float* dst)
 hipError_t wino4_transform_launch(const float* x, const float* s, const float* t, int B, int H, int W, int C, float* V,
                                   hipStream_t stream);
 // groups in {1,2,3,6}: > 1 splits the six rows of transform points over that many workgroups per tile (few tiles) and
-// finishes with wino4_output_transform_kernel; zbuf: [24][B*H/4*W/4][Cout] floats
+// finishes with wino4_output_transform_kernel; zbuf: [24][B*H/4*W/4][Cout] floats; pool (groups > 1 only): 2x2 average
+// after the activation, out is [B,H/2,W/2,Cout]
 hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, int W, int act, const float* resid,
-                             float* out, hipStream_t stream, int variant = 0, int groups = 1, float* zbuf = nullptr);
+                             float* out, hipStream_t stream, int variant = 0, int groups = 1, float* zbuf = nullptr, int pool = 0);
 
 // ---- motion / warp / image kernels (motion.hip) ---------------------------------------------
 hipError_t kp_prepare_launch(const float* kd_val, const float* kd_jac, const float* ks_val, const float* ks_jac,

@@ -141,6 +141,11 @@ CASES = {
     "wino4_split6":      dict(B=1, H=16, W=16, C0=128, C1=0, Cout=128, ks=3, act=1, tile_n=2156),
     "wino4_split3_res":  dict(B=2, H=8, W=12, C0=64, C1=0, Cout=136, ks=3, resid=True, tile_n=2153),
     "wino4_split2":      dict(B=1, H=64, W=64, C0=256, C1=0, Cout=256, ks=3, resid=True, tile_n=2152),
+    # ... with the DownBlock2d epilogue (ReLU, 2x2 average) in the output-transform kernel: the hourglass encoder levels
+    "wino4_pool_enc0":   dict(B=2, H=64, W=64, C0=64, C1=0, Cout=128, ks=3, act=1, pool=1, tile_n=2152),
+    "wino4_pool_enc1":   dict(B=2, H=32, W=32, C0=128, C1=0, Cout=256, ks=3, act=1, pool=1, tile_n=2153),
+    "wino4_pool_enc3":   dict(B=3, H=8, W=8, C0=512, C1=0, Cout=1024, ks=3, act=1, pool=1, tile_n=2156),
+    "wino4_pool_ragged": dict(B=1, H=12, W=20, C0=64, C1=0, Cout=72, ks=3, act=1, pool=1, tile_n=2156),
     "wino4_interleaved": dict(B=3, H=16, W=20, C0=128, C1=0, Cout=96, ks=3, resid=True, tile_n=2105),
     "7x1_rowsplit":      dict(B=2, H=16, W=16, C0=64, C1=0, Cout=21, ks=7, kw=1),
     "7x7_head":          dict(B=1, H=16, W=16, C0=32, C1=64, Cout=12, ks=7),

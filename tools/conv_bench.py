@@ -25,6 +25,10 @@ LAYERS = [
     ("hg_enc2", 16, 16, 256, 0, 512, 3, 0, 1, 1, 0),
     ("hg_enc3", 8, 8, 512, 0, 1024, 3, 0, 1, 1, 0),
     ("hg_enc4", 4, 4, 1024, 0, 1024, 3, 0, 1, 1, 0),
+    ("hg_enc0_nopool", 64, 64, 64, 0, 128, 3, 0, 1, 0, 0),      # the same convolutions without the pooled epilogue
+    ("hg_enc1_nopool", 32, 32, 128, 0, 256, 3, 0, 1, 0, 0),     # (what the Winograd op path accepts)
+    ("hg_enc2_nopool", 16, 16, 256, 0, 512, 3, 0, 1, 0, 0),
+    ("hg_enc3_nopool", 8, 8, 512, 0, 1024, 3, 0, 1, 0, 0),
     ("hg_dec0", 2, 2, 1024, 0, 1024, 3, 1, 1, 0, 0),
     ("hg_dec1", 4, 4, 1024, 1024, 512, 3, 1, 1, 0, 0),
     ("hg_dec2", 8, 8, 512, 512, 256, 3, 1, 1, 0, 0),
