@@ -56,6 +56,7 @@ struct CtxBase {
     int skinny_max_m = 16384;   // largest per-phase pixel count served by the 32- / 64-row tiles (EAMM_SKINNY_MAX_M; 0 = off):
                                 // 64x128 tiles need no split-K where 256x128 ones do (measured 256x256: 1 frame 753 -> 785, 4 frames 1969 -> 2067,
                                 // 8 frames 2756 -> 2782 frames/s; 16 frames unchanged)
+    int patch_split_max = 4;    // largest split of the channel reduction of the polyphase kernel over workgroups (EAMM_PATCH_SPLIT_MAX; 1 = off)
     int patch_min_blocks = 128; // fewest workgroups for which UpBlock2d layers use the spatial-patch kernel (< 0: never)
 };
 
@@ -382,10 +383,18 @@ const ConvLayer& pick(const CtxBase* c, const LayerSet& S, size_t M) {
 // UpBlock2d launch: the spatial-patch kernel when its 16x16-pixel tiles fill the chip, else the im2col-style kernels
 int launch_up(CtxBase* c, const LayerSet& S, const ConvIO& io, hipStream_t s) {
     if (S.has_patch) {
-        const int blocks = ((io.Hin + 15) / 16) * ((io.Win + 15) / 16) * io.B * ((S.patch.Cout + 31) / 32);   // of the polyphase kernel
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+        int splits = 1;
+        if (S.patch.w_poly) {
+            splits = patch_poly_splits(S.patch, io.B, io.Hin, io.Win, c->patch_split_max, cus);
+            if ((size_t)splits * io.B * 4 * io.Hin * io.Win * S.patch.Cout > io.partial_cap) splits = 1;
+        }
+        const int blocks = ((io.Hin + 15) / 16) * ((io.Win + 15) / 16) * io.B * ((S.patch.Cout + 31) / 32) * splits;   // of the polyphase kernel
         if (blocks >= c->patch_min_blocks && io.Hin >= 16 && io.Win >= 16 && io.act == ACT_RELU && !io.resid && !io.out2 && !io.pool && !io.nchw) {
             if (S.patch.w_poly)
-                HIP_TRY(c, patch_poly_launch(S.patch, io.in0, io.in1, io.B, io.Hin, io.Win, io.act, io.out, s));
+                HIP_TRY(c, patch_poly_launch(S.patch, io.in0, io.in1, io.B, io.Hin, io.Win, io.act, io.out, s, splits, io.partial,
+                                             io.partial_cap));
             else
                 HIP_TRY(c, patch_phase_launch(S.patch, io.in0, io.in1, io.B, io.Hin, io.Win, io.act, io.out, s));
             return EAMM_OK;
@@ -414,6 +423,7 @@ inline void read_tile_knobs(CtxBase* c) {
     c->dma_cfg_n128 = env_int("EAMM_DMA_CFG_N128", c->dma_cfg_n128);
     c->dma_cfg_n64 = env_int("EAMM_DMA_CFG_N64", c->dma_cfg_n64);
     c->patch_min_blocks = env_int("EAMM_PATCH_MIN_BLOCKS", c->patch_min_blocks);
+    c->patch_split_max = env_int("EAMM_PATCH_SPLIT_MAX", c->patch_split_max);
     c->skinny_max_m = env_int("EAMM_SKINNY_MAX_M", c->skinny_max_m);
 }
 

@@ -23,6 +23,7 @@
 // fp32 throughout; only the summation order differs from the reference (measured at the prediction: DESIGN.md 5.2d).
 #include "conv_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace eamm {
@@ -49,6 +50,9 @@ struct PatchPolyArgs {
     const float* bias;     // [>= ntiles*32]
     int Cout, act;
     float* out;
+    int splits;            // > 1: workgroup (.., ks) reduces channel chunks [ks, ks+1) * cchunks / splits and writes raw phase sums
+    float* partial;        // [splits][B,2H,2W,Cout]; patch_poly_reduce_kernel adds the slabs, the bias and the activation
+    size_t slab;           // floats per slab
 };
 
 __global__ __launch_bounds__(ZWAVES * 64) void conv_patch_poly_kernel(const PatchPolyArgs p) {
@@ -71,11 +75,14 @@ __global__ __launch_bounds__(ZWAVES * 64) void conv_patch_poly_kernel(const Patc
     int L = xcd_remap(blockIdx.x, gridDim.x);
     const int ntile = L % p.ntiles;
     L /= p.ntiles;
+    const int ks = L % p.splits;
+    L /= p.splits;
     const int tx0 = (L % p.tiles_x) * ZT;
     L /= p.tiles_x;
     const int ty0 = (L % p.tiles_y) * ZT;
     const int b = L / p.tiles_y;
     const int cchunks = (p.C0 + p.C1) / BK;
+    const int c_begin = ks * cchunks / p.splits, c_end = (ks + 1) * cchunks / p.splits;
 
     // ---- loaders.  Patch piece id = wave + 8 j covers patch pixels 8 id .. 8 id + 7, 128 B each (lane>>3 = pixel,
     // lane&7 = 16-byte slot, XOR-swizzled with the pixel on the global side); the pixel's image index is chunk-invariant.
@@ -175,10 +182,10 @@ __global__ __launch_bounds__(ZWAVES * 64) void conv_patch_poly_kernel(const Patc
     };
 
     auto chunk = [&](int cc) {
-        const int st = cc & 1;
+        const int st = (cc - c_begin) & 1;
         const float* a_stage = As + st * A_STAGE;
         const float* b_stage = Bs + st * B_STAGE;
-        const bool more = cc + 1 < cchunks;
+        const bool more = cc + 1 < c_end;
         fetch(std::integral_constant<int, 0>{}, a_stage, b_stage);
         transform(std::integral_constant<int, 0>{});
         static_for<12>([&](auto qc) {
@@ -202,16 +209,18 @@ __global__ __launch_bounds__(ZWAVES * 64) void conv_patch_poly_kernel(const Patc
     };
 
     // ---- main loop over channel chunks
-    static_for<A_INSTR>([&](auto jc) { dma_patch_piece(jc, 0, 0); });
-    static_for<B_INSTR>([&](auto jc) { dma_weight_piece(jc, 0, 0); });
+    static_for<A_INSTR>([&](auto jc) { dma_patch_piece(jc, c_begin, 0); });
+    static_for<B_INSTR>([&](auto jc) { dma_weight_piece(jc, c_begin, 0); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int cc = 0; cc < cchunks; ++cc) chunk(cc);
+    for (int cc = c_begin; cc < c_end; ++cc) chunk(cc);
 
     // ---- epilogue: form each phase (3 adds per output), stage its 256 x 32 tile through LDS, store 16-byte pieces
     constexpr int LDO = ZBN + 4, C4 = ZBN / 4, NTHR = ZWAVES * 64, PER = ZT * ZT * C4 / NTHR;
     const int OH = 2 * p.H, OW = 2 * p.W;
-    const float bias = p.bias[ntile * ZBN + l31];
+    const bool raw = p.splits > 1;
+    const float bias = raw ? 0.f : p.bias[ntile * ZBN + l31];
+    float* const dst = raw ? p.partial + (size_t)ks * p.slab : p.out;
     static_for<4>([&](auto phc) {
         constexpr int ph = decltype(phc)::value, py = ph >> 1, px = ph & 1;
         if constexpr (ph > 0) __syncthreads();
@@ -231,18 +240,48 @@ __global__ __launch_bounds__(ZWAVES * 64) void conv_patch_poly_kernel(const Patc
             const int n = ntile * ZBN + c4 * 4;
             if (y < p.H && x < p.W && n < p.Cout) {
                 float4 o4 = *reinterpret_cast<const float4*>(smem + row * LDO + c4 * 4);
-                o4.x = apply_act(o4.x, p.act); o4.y = apply_act(o4.y, p.act);
-                o4.z = apply_act(o4.z, p.act); o4.w = apply_act(o4.w, p.act);
+                if (!raw) {
+                    o4.x = apply_act(o4.x, p.act); o4.y = apply_act(o4.y, p.act);
+                    o4.z = apply_act(o4.z, p.act); o4.w = apply_act(o4.w, p.act);
+                }
                 const size_t o = ((size_t)(b * OH + 2 * y + py) * OW + 2 * x + px) * p.Cout + n;
-                *reinterpret_cast<float4*>(p.out + o) = o4;
+                *reinterpret_cast<float4*>(dst + o) = o4;
             }
         }
     });
 }
 
+// out = act(sum of the split-K slabs + bias); 16 bytes per thread and pass, slabs added in a fixed order
+__global__ __launch_bounds__(256) void patch_poly_reduce_kernel(const float* __restrict__ partial, int splits, size_t slab,
+                                                                const float* __restrict__ bias, int Cout, int act,
+                                                                float* __restrict__ out, size_t total4) {
+    const int c4n = Cout >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(partial)[i];
+        for (int sp = 1; sp < splits; ++sp) {
+            const float4 t = reinterpret_cast<const float4*>(partial + (size_t)sp * slab)[i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const float4 bs = reinterpret_cast<const float4*>(bias)[i % c4n];
+        v.x = apply_act(v.x + bs.x, act); v.y = apply_act(v.y + bs.y, act);
+        v.z = apply_act(v.z + bs.z, act); v.w = apply_act(v.w + bs.w, act);
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
+// Split of the channel reduction over workgroups when the 16x16-pixel x 32-cout tiles alone leave CUs idle (the
+// hourglass decoder's last levels): the largest of {4, 2} that keeps one round of the chip and >= 4 chunks per workgroup.
+int patch_poly_splits(const PatchLayer& L, int B, int H, int W, int max_splits, int cus) {
+    const int blocks = ((W + ZT - 1) / ZT) * ((H + ZT - 1) / ZT) * B * ((L.Cout + ZBN - 1) / ZBN);
+    const int cchunks = (L.C0 + L.C1) / CONV_BK;
+    for (int sp : {4, 2})
+        if (sp <= max_splits && blocks * sp <= cus && cchunks % sp == 0 && cchunks / sp >= 4) return sp;
+    return 1;
+}
+
 size_t patch_poly_packed_elems(int Cin_packed, int Cout) {
     return (size_t)((Cout + ZBN - 1) / ZBN) * (Cin_packed / CONV_BK) * 9 * ZBN * CONV_BK;
 }
@@ -275,8 +314,10 @@ void patch_poly_pack_host(const float* w, int Cout, int Cin, const int* cin_map,
 }
 
 hipError_t patch_poly_launch(const PatchLayer& L, const float* in0, const float* in1, int B, int H, int W, int act,
-                              float* out, hipStream_t stream) {
+                              float* out, hipStream_t stream, int splits, float* partial, size_t partial_cap) {
     if ((L.C0 % CONV_BK) || (L.C1 % CONV_BK) || (L.Cout & 3) || L.w_poly == nullptr) return hipErrorInvalidValue;
+    const size_t slab = (size_t)B * 4 * H * W * L.Cout;
+    if (splits < 1 || (splits > 1 && (partial == nullptr || (size_t)splits * slab > partial_cap))) return hipErrorInvalidValue;
     PatchPolyArgs a{};
     a.in0 = in0;
     a.in1 = L.C1 ? in1 : nullptr;
@@ -299,14 +340,23 @@ hipError_t patch_poly_launch(const PatchLayer& L, const float* in0, const float*
     a.Cout = L.Cout;
     a.act = act;
     a.out = out;
+    a.splits = splits;
+    a.partial = partial;
+    a.slab = slab;
     constexpr size_t lds_loop = sizeof(float) * 2 * (ZPAD * CONV_BK + 9 * ZBN * CONV_BK);
     constexpr size_t lds_epi = sizeof(float) * (ZT * ZT) * (ZBN + 4);
     constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static unsigned long long configured = 0;
     if (hipError_t e = ensure_dynamic_lds(conv_patch_poly_kernel, lds, &configured); e != hipSuccess) return e;
-    const int blocks = a.tiles_x * a.tiles_y * B * a.ntiles;
+    const int blocks = a.tiles_x * a.tiles_y * B * a.ntiles * splits;
     hipLaunchKernelGGL(conv_patch_poly_kernel, dim3(blocks), dim3(ZWAVES * 64), lds, stream, a);
+    if (splits > 1) {
+        const size_t total4 = slab / 4;
+        const int rb = (int)std::min<size_t>((total4 + 255) / 256, 4096);
+        hipLaunchKernelGGL(patch_poly_reduce_kernel, dim3(rb), dim3(256), 0, stream, partial, splits, slab, L.bias, L.Cout, act, out,
+                           total4);
+    }
     return hipGetLastError();
 }
 

@@ -409,11 +409,20 @@ int eamm_finalize_weights(eamm_ctx* c) {
             upd1(c->first, f * HW);
             for (int i = 0; i < c->nd; ++i) upd(c->down[i], f * (HW >> (2 * i)));
         }
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+        auto upd_poly = [&](const LayerSet& S, size_t f, int Hin, int Win) {   // split polyphase launches: raw slabs of the output
+            if (!S.has_patch || !S.patch.w_poly || Hin < 16 || Win < 16) return;
+            const int sp = patch_poly_splits(S.patch, (int)f, Hin, Win, c->patch_split_max, cus);
+            if (sp > 1) need = std::max(need, (size_t)sp * f * 4 * Hin * Win * S.patch.Cout);
+        };
         for (size_t f = 1; f <= F; ++f) {
             for (int i = 0; i < c->nb; ++i) {
                 upd(c->hg_enc[i], f * (hw >> (2 * i)));
                 upd(c->hg_dec[i], f * (hw >> (2 * (c->nb - i))));
+                upd_poly(c->hg_dec[i], f, c->h >> (c->nb - i), c->w >> (c->nb - i));
             }
+            for (int i = 0; i < c->nd; ++i) upd_poly(c->up[i], f, c->hf << i, c->wf << i);
             if (c->nb > 0) upd1(c->head, f * hw);
             upd(c->res1[0], f * hwf);
             for (int i = 0; i < c->nd; ++i) upd(c->up[i], f * (hwf << (2 * i)));
@@ -1104,8 +1113,11 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
     }
     if (tile_n == 3000 || tile_n == 3003) {   // spatial-patch kernels for the up-convolution: 3000 collapsed-phase form, 3003 polyphase minimal-filtering form
         const bool pp = tile_n == 3003;
-        if (kh != 3 || kw != 3 || !up || pool || resid || splitk > 1 || (Cout & 3))
+        const int psplit = splitk > 1 ? splitk : 1;   // polyphase form only: the channel reduction over that many workgroups
+        if (kh != 3 || kw != 3 || !up || pool || resid || (Cout & 3) || (psplit > 1 && (!pp || ((C0 + C1) / 32) % psplit)))
             return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported patch-kernel configuration");
+        float* ppart = nullptr;
+        const size_t ppart_elems = psplit > 1 ? (size_t)psplit * B * 4 * Hin * Win * Cout : 0;
         PatchLayer P;
         P.C0 = C0;
         P.C1 = C1;
@@ -1124,9 +1136,10 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         if (!bad(hipMalloc((void**)wslot, packed.size() * sizeof(float)), "hipMalloc") &&
             !bad(hipMalloc((void**)&P.bias, bias.size() * sizeof(float)), "hipMalloc") &&
             !bad(hipMemcpy(*wslot, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
-            !bad(hipMemcpy(P.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")) {
+            !bad(hipMemcpy(P.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
+            (psplit == 1 || !bad(hipMalloc((void**)&ppart, ppart_elems * sizeof(float)), "hipMalloc"))) {
             auto run = [&]() {
-                return pp ? patch_poly_launch(P, in0, in1, B, Hin, Win, act, out, s)
+                return pp ? patch_poly_launch(P, in0, in1, B, Hin, Win, act, out, s, psplit, ppart, ppart_elems)
                           : patch_phase_launch(P, in0, in1, B, Hin, Win, act, out, s);
             };
             if (!bad(run(), "patch launch") && iters > 0 && avg_ms) {
@@ -1147,6 +1160,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         }
         if (P.w) (void)hipFree(P.w);
         if (P.w_poly) (void)hipFree(P.w_poly);
+        if (ppart) (void)hipFree(ppart);
         if (P.bias) (void)hipFree(P.bias);
         return rc;
     }

@@ -93,8 +93,11 @@ struct PatchLayer {
 size_t patch_packed_elems(int Cin_packed, int Cout);
 size_t patch_poly_packed_elems(int Cin_packed, int Cout);
 void patch_poly_pack_host(const float* w_oihw_3x3, int Cout, int Cin, const int* cin_map, int cin_packed, float* dst);
+// splits > 1: the channel reduction split over that many workgroups per tile, raw sums into partial[splits][B,2H,2W,Cout]
+// (partial_cap floats), finished by patch_poly_reduce_kernel; patch_poly_splits picks the split for a launch
 hipError_t patch_poly_launch(const PatchLayer& L, const float* in0, const float* in1, int B, int H, int W, int act,
-                             float* out, hipStream_t stream);
+                             float* out, hipStream_t stream, int splits = 1, float* partial = nullptr, size_t partial_cap = 0);
+int patch_poly_splits(const PatchLayer& L, int B, int H, int W, int max_splits, int cus);
 void patch_pack_host(const float* w_oihw_3x3, int Cout, int Cin, const int* cin_map, int cin_packed, float* dst);
 hipError_t patch_phase_launch(const PatchLayer& L, const float* in0, const float* in1, int B, int H, int W, int act,
                               float* out, hipStream_t stream);

@@ -122,6 +122,10 @@ CASES = {
     "ppoly_up_odd":      dict(B=1, H=9, W=7, C0=32, C1=0, Cout=64, ks=3, up=1, act=0, tile_n=3003),
     "ppoly_up1_like":    dict(B=1, H=64, W=64, C0=128, C1=0, Cout=64, ks=3, up=1, act=1, tile_n=3003),
     "ppoly_up0_like":    dict(B=2, H=32, W=32, C0=256, C1=0, Cout=128, ks=3, up=1, act=0, tile_n=3003),
+    # ... with the channel reduction split over workgroups (the hourglass decoder's last levels)
+    "ppoly_split2_dec4": dict(B=2, H=32, W=32, C0=128, C1=128, Cout=64, ks=3, up=1, act=1, splitk=2, tile_n=3003),
+    "ppoly_split4_dec3": dict(B=3, H=16, W=16, C0=256, C1=256, Cout=128, ks=3, up=1, act=1, splitk=4, tile_n=3003),
+    "ppoly_split2_rag":  dict(B=1, H=18, W=20, C0=64, C1=64, Cout=40, ks=3, up=1, act=0, splitk=2, tile_n=3003),
     # Winograd F(2x2,3x3) path (tile_n = 2000)
     "wino_basic":        dict(B=2, H=16, W=16, C0=64, C1=0, Cout=128, ks=3, act=1, tile_n=2000),
     "wino_tails_resid":  dict(B=1, H=6, W=10, C0=64, C1=0, Cout=136, ks=3, resid=True, tile_n=2000),

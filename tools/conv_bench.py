@@ -12,6 +12,7 @@ from eamm_amd import _lib  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] != "all" else None
+SPLITK = int(os.environ.get("CONV_BENCH_SPLITK", "0"))   # explicit split-K (im2col kernels, polyphase patch kernel)
 TILES = [int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]   # 0 auto, 1001.. dma tiles
 # name, Hin, Win, C0, C1, Cout, ks(,kw), up, act, pool, resid
 LAYERS = [
@@ -70,7 +71,7 @@ def main():
                 continue
             ms = C.c_float()
             rc = L.eamm_op_conv(0, in0.data_ptr(), C0, in1.data_ptr() if C1 else None, C1, B, H, W, up, w.data_ptr(),
-                                b.data_ptr(), Cout, ks, kw, act, pool, res.data_ptr() if resid else None, 0, tile,
+                                b.data_ptr(), Cout, ks, kw, act, pool, res.data_ptr() if resid else None, SPLITK, tile,
                                 out.data_ptr(), 20, C.byref(ms), st)
             _lib.check(rc, None)
             n = 12 if name == "bottleneck" else 1
