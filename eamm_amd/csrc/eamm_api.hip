@@ -677,7 +677,9 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
                     break;
                 }
             HIP_TRY(c, wino4_transform_launch(io.in0, nullptr, nullptr, n, io.Hin, io.Win, L.Cin, v.wino_v, s));
-            HIP_TRY(c, wino4_gemm_launch(L, v.wino_v, n, io.Hin, io.Win, ACT_RELU, nullptr, io.out, s, c->wino4_variant, g, v.wino_z, 1));
+            // pipeline variant 0 (one DMA piece per 4 MFMAs): within noise of the bottleneck's variant at these sizes, and a
+            // different instantiation -- per-kernel averages in traces / PMC passes stay those of the bottleneck launches alone
+            HIP_TRY(c, wino4_gemm_launch(L, v.wino_v, n, io.Hin, io.Win, ACT_RELU, nullptr, io.out, s, 0, g, v.wino_z, 1));
             continue;
         }
         HIP_TRY(c, conv_launch(pick(c, c->hg_enc[i], (size_t)n * io.Hin * io.Win), io, s));
