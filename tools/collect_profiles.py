@@ -23,8 +23,9 @@ for size_tag in ("256_b16", "512_b8"):
         if os.path.exists(os.path.join(d, src)):
             shutil.copy(os.path.join(d, src), os.path.join(P, dst))
     t = os.path.join(d, "pmc_traffic.json")
-    if os.path.exists(t):
-        table.update(json.load(open(t)))
+    if os.path.exists(t):   # each run's table starts from the committed one: take only the records of the run's own size
+        size = size_tag.split("_")[0]
+        table.update({k: v for k, v in json.load(open(t)).items() if f"_{size}x{size}_" in k})
 r = os.path.join(G, f"r02_{tag}")
 for src, dst in (("bench_256_b16.json", "r02_bench_256_b16.json"), ("bench_512_b8.json", "r02_bench_512_b8.json"),
                  ("module_latency.txt", "r02_module_latency.txt"), ("bn_bench.txt", "r02_bn_bench.txt")):
