@@ -55,25 +55,35 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* 
         }
         const float4* img = reinterpret_cast<const float4*>(x) + (size_t)b * H * W * c4n + c4;
         float4 d[4][4];
+        // all 16 loads issued before the first use (clamped addresses, out-of-range pixels zeroed afterwards): a bounds
+        // branch around each load made the compiler wait for every load before issuing the next
+        int yo[4], xo[4];
+        bool oky[4], okx[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int yy = 2 * qy - 1 + i;
+            const int yy = 2 * qy - 1 + i, xx = 2 * qx - 1 + i;
+            oky[i] = (unsigned)yy < (unsigned)H;
+            okx[i] = (unsigned)xx < (unsigned)W;
+            yo[i] = min(max(yy, 0), H - 1) * W;
+            xo[i] = min(max(xx, 0), W - 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = img[(size_t)(yo[i] + xo[j]) * c4n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int xx = 2 * qx - 1 + j;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                    v = img[(size_t)(yy * W + xx) * c4n];
-                    if (s != nullptr) {  // zero padding applies to the ACTIVATED tensor: only in-range pixels
-                        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-                        v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-                        v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-                    }
+                float4 v = d[i][j];
+                if (s != nullptr) {  // zero padding applies to the ACTIVATED tensor: only in-range pixels
+                    v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+                    v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                    v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+                    v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
                 }
-                d[i][j] = v;
+                d[i][j] = (oky[i] && okx[j]) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        }
         // B^T d: rows (d0-d2, d1+d2, d2-d1, d1-d3), then the same along columns
         float4 r[4][4];
 #pragma unroll

@@ -106,20 +106,30 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
         }
         const T* img = reinterpret_cast<const T*>(x) + (size_t)b * H * W * cvn + cv;
         T d[6][6];
+        // all 36 loads are issued before the first use: out-of-range pixels read a clamped (valid) address and are zeroed
+        // afterwards -- a bounds branch around each load made the compiler wait for every load before issuing the next
+        int yo[6], xo[6];
+        bool oky[6], okx[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const int yy = 4 * qy - 1 + i;
+            const int yy = 4 * qy - 1 + i, xx = 4 * qx - 1 + i;
+            oky[i] = (unsigned)yy < (unsigned)H;
+            okx[i] = (unsigned)xx < (unsigned)W;
+            yo[i] = min(max(yy, 0), H - 1) * W;
+            xo[i] = min(max(xx, 0), W - 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) d[i][j] = img[(size_t)(yo[i] + xo[j]) * cvn];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                const int xx = 4 * qx - 1 + j;
-                T v = T(0.f);
-                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                    v = img[(size_t)(yy * W + xx) * cvn];
-                    if (s != nullptr) v = vrelu_affine(v, sc, sh);  // zero padding applies to the ACTIVATED tensor
-                }
-                d[i][j] = v;
+                T v = d[i][j];
+                if (s != nullptr) v = vrelu_affine(v, sc, sh);  // zero padding applies to the ACTIVATED tensor
+                d[i][j] = (oky[i] && okx[j]) ? v : T(0.f);
             }
-        }
 #pragma unroll
         for (int j = 0; j < 6; ++j) bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);   // along y
         T* out = reinterpret_cast<T*>(V) + q * cvn + cv;
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
 
 // y fold of the split form: Y[p][q] = sum_i A^T[p][i] Z[i][q] (+ bias, residual, activation) -> the 4x4 output pixels;
 // POOL: followed by the 2x2 average of DownBlock2d (reference modules/util.py:903-921) -> 2x2 pixels of [B,H/2,W/2,Cout]
-template <bool POOL>
+template <bool POOL, bool RESID>
 __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Z, const float* __restrict__ bias,
                                                                      const float* __restrict__ resid, int Mq, int Cout, int H,
                                                                      int W, int act, float* __restrict__ out) {
@@ -499,12 +509,18 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
             y[1] = d12 + 2.f * d34;
             y[2] = s12 + 4.f * s34;
             y[3] = d12 + 8.f * d34 + zi[5];
+            f32x4_t r4[4];   // residual of this column's four pixels: loaded beside the Z planes, not behind a branch per pixel
+            if constexpr (RESID) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
+                    r4[pp] = reinterpret_cast<const f32x4_t*>(resid)[(((size_t)(b * H + 4 * qy + pp) * W + 4 * qx + q) * Cout) / 4 + c4];
+            }
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
                 f32x4_t v = y[pp] + bs;
                 if constexpr (!POOL) {
                     const size_t o = (((size_t)(b * H + 4 * qy + pp) * W + 4 * qx + q) * Cout) / 4 + c4;
-                    if (resid != nullptr) v = v + reinterpret_cast<const f32x4_t*>(resid)[o];
+                    if constexpr (RESID) v = v + r4[pp];
                     v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
                     reinterpret_cast<f32x4_t*>(out)[o] = v;
                 } else {
@@ -645,11 +661,14 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     const size_t total = (size_t)a.Mq * (L.Cout / 4);
     const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)1 << 20);
     if (pool)
-        hipLaunchKernelGGL(wino4_output_transform_kernel<true>, dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid, a.Mq,
-                           L.Cout, H, W, act, out);
+        hipLaunchKernelGGL((wino4_output_transform_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid,
+                           a.Mq, L.Cout, H, W, act, out);
+    else if (resid != nullptr)
+        hipLaunchKernelGGL((wino4_output_transform_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid,
+                           a.Mq, L.Cout, H, W, act, out);
     else
-        hipLaunchKernelGGL(wino4_output_transform_kernel<false>, dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid, a.Mq,
-                           L.Cout, H, W, act, out);
+        hipLaunchKernelGGL((wino4_output_transform_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid,
+                           a.Mq, L.Cout, H, W, act, out);
     return hipGetLastError();
 }
 

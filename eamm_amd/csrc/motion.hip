@@ -128,22 +128,17 @@ __global__ __launch_bounds__(256) void motion_front_kernel(const float* __restri
         float r_ = 0.f, g_ = 0.f, b_ = 0.f;
         const bool x0ok = (unsigned)b.x0 < (unsigned)w, x1ok = (unsigned)(b.x0 + 1) < (unsigned)w;
         const bool y0ok = (unsigned)b.y0 < (unsigned)h, y1ok = (unsigned)(b.y0 + 1) < (unsigned)h;
-        if (y0ok && x0ok) {
-            const float4 v = src[b.y0 * w + b.x0];
-            r_ = fmaf(v.x, b.wnw, r_); g_ = fmaf(v.y, b.wnw, g_); b_ = fmaf(v.z, b.wnw, b_);
-        }
-        if (y0ok && x1ok) {
-            const float4 v = src[b.y0 * w + b.x0 + 1];
-            r_ = fmaf(v.x, b.wne, r_); g_ = fmaf(v.y, b.wne, g_); b_ = fmaf(v.z, b.wne, b_);
-        }
-        if (y1ok && x0ok) {
-            const float4 v = src[(b.y0 + 1) * w + b.x0];
-            r_ = fmaf(v.x, b.wsw, r_); g_ = fmaf(v.y, b.wsw, g_); b_ = fmaf(v.z, b.wsw, b_);
-        }
-        if (y1ok && x1ok) {
-            const float4 v = src[(b.y0 + 1) * w + b.x0 + 1];
-            r_ = fmaf(v.x, b.wse, r_); g_ = fmaf(v.y, b.wse, g_); b_ = fmaf(v.z, b.wse, b_);
-        }
+        // branch-free taps: out-of-range corners read a clamped address with weight 0 (zeros padding, util.py:69-79) --
+        // a bounds branch around each load made the four loads of a key point, and the key points, wait for one another
+        const int xa = min(max(b.x0, 0), w - 1), xb = min(max(b.x0 + 1, 0), w - 1);
+        const int ya = min(max(b.y0, 0), h - 1) * w, yb = min(max(b.y0 + 1, 0), h - 1) * w;
+        const float4 vnw = src[ya + xa], vne = src[ya + xb], vsw = src[yb + xa], vse = src[yb + xb];
+        const float wnw = (y0ok && x0ok) ? b.wnw : 0.f, wne = (y0ok && x1ok) ? b.wne : 0.f;
+        const float wsw = (y1ok && x0ok) ? b.wsw : 0.f, wse = (y1ok && x1ok) ? b.wse : 0.f;
+        r_ = fmaf(vnw.x, wnw, r_); g_ = fmaf(vnw.y, wnw, g_); b_ = fmaf(vnw.z, wnw, b_);
+        r_ = fmaf(vne.x, wne, r_); g_ = fmaf(vne.y, wne, g_); b_ = fmaf(vne.z, wne, b_);
+        r_ = fmaf(vsw.x, wsw, r_); g_ = fmaf(vsw.y, wsw, g_); b_ = fmaf(vsw.z, wsw, b_);
+        r_ = fmaf(vse.x, wse, r_); g_ = fmaf(vse.y, wse, g_); b_ = fmaf(vse.z, wse, b_);
         dst[k] = make_float4(heat, r_, g_, b_);
         if (sd) {
             sd[(size_t)(k * 3 + 0) * plane] = r_;
