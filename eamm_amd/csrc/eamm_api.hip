@@ -37,7 +37,8 @@ struct eamm_ctx : eamm::CtxBase {
     int enc_wino_min_tiles = 64;           // ... and of at least one full 64-tile GEMM block (EAMM_ENC_WINO_MIN_TILES): the 4x4-map level has 16 tiles at 16
                                            // frames against 151 MB of transformed weights and stays direct
     int bneck_chains = 2;                  // bottleneck as this many chains of frames on as many streams (EAMM_BNECK_CHAINS; 1 = off)
-    int pass_chains = 1;                   // the whole per-frame pass as this many chains (EAMM_PASS_CHAINS; 1 = off, the default:
+    int pass_chains = 0;                   // the whole per-frame pass as this many chains (EAMM_PASS_CHAINS; 1 = off; 0 = the default: two chains
+                                           // when each chain's F(4x4) GEMM still fills the chip -- 512x512 x 8: 989 -> 1012 frames/s; otherwise off:
                                            // measured 256x256 -- 16 frames 3381 vs 3370 frames/s, 12 frames 2633 vs 2765, 8 frames 2744 vs 2197)
     int pass_chains_min_frames = 8;        // ... from this many frames per call (EAMM_PASS_CHAINS_MIN_FRAMES)
     std::vector<hipStream_t> side_streams; // the other chains' streams + fork / join events
@@ -432,7 +433,8 @@ int eamm_finalize_weights(eamm_ctx* c) {
             upd1(c->final_conv, f * HW);
         }
         c->partial_elems = need;   // one slab per whole-pass chain
-        if ((rc = dev_alloc(c, &c->partial, c->partial_elems * (size_t)std::max(1, std::min(env_int("EAMM_PASS_CHAINS", c->pass_chains), 4))))) return rc;
+        const int pc = env_int("EAMM_PASS_CHAINS", c->pass_chains);
+        if ((rc = dev_alloc(c, &c->partial, c->partial_elems * (size_t)(pc == 0 ? 2 : std::max(1, std::min(pc, 4)))))) return rc;
     }
 
     // ---- algorithmic FLOPs (reference layer shapes, real channel counts)
@@ -455,10 +457,11 @@ int eamm_finalize_weights(eamm_ctx* c) {
         c->flops_frame = ff;
     }
     c->bneck_chains = std::max(1, std::min(c->bneck_chains, 16));
-    c->pass_chains = std::max(1, std::min(c->pass_chains, 4));
-    if (std::max(c->bneck_chains, c->pass_chains) > 1) {
+    c->pass_chains = std::max(0, std::min(c->pass_chains, 4));
+    const int max_chains = std::max(c->bneck_chains, c->pass_chains == 0 ? 2 : c->pass_chains);
+    if (max_chains > 1) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        for (int k = 1; k < std::max(c->bneck_chains, c->pass_chains); ++k) {
+        for (int k = 1; k < max_chains; ++k) {
             hipStream_t st = nullptr;
             hipEvent_t ev = nullptr;
             HIP_TRY(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -614,10 +617,16 @@ static FrameView make_view(const eamm_ctx* c, int f0, int n, int ns_call, int sl
 // and their split-K reductions) beside the other chain's MFMA-bound ones.  Needs the F(4x4) bottleneck with whole 64-tile
 // GEMM blocks per chain; EAMM_PASS_CHAINS (0 / 1 = off).
 static int pass_chains(const eamm_ctx* c, int n) {
-    if (c->pass_chains < 2 || (int)c->side_streams.size() + 1 < c->pass_chains) return 1;
-    const int K = c->pass_chains;
+    const bool automatic = c->pass_chains == 0;
+    const int K = automatic ? 2 : c->pass_chains;
+    if (K < 2 || (int)c->side_streams.size() + 1 < K) return 1;
     const int tiles_pf = (c->hf / 4) * (c->wf / 4);
     if (n < c->pass_chains_min_frames || n < K) return 1;
+    if (automatic) {   // only when a chain's bottleneck GEMM is still a full round of one-per-CU blocks
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+        if (((n / K) * tiles_pf / 64) * ((c->Cb + 63) / 64) < cus) return 1;
+    }
     for (int k = 0; k < 2; ++k) {   // both chain sizes (n/K and n/K + 1 when n % K != 0)
         const int nk = n / K + k;
         if (k == 1 && n % K == 0) break;
