@@ -291,7 +291,10 @@ def main():
             blocks = -(-(B // chains) * (hf // 4) * (hf // 4) // 64) * -(-cb // 64)
         else:
             blocks = cus
-        cu_share = min(1.0, blocks / cus)
+        # Whole-pass chains (eamm_pass_chains) are independent launch sequences whose bottleneck launches each fill the chip
+        # on their own and therefore time-share it: a launch's fair share is then 1/K of the chip.
+        shared = eng.pass_chains(B) > 1 and blocks * chains > cus
+        cu_share = 1.0 / chains if shared else min(1.0, blocks / cus)
         peak = FP32_MFMA_PEAK_TFLOPS * cu_share
         ms_tr = prof["ms"]["bneck_transform"] / launches if prof["calls"] else 0.0
         achieved = exec_flop / (ms_conv * 1e-3) / 1e12
@@ -320,8 +323,11 @@ def main():
                          "avg_launch_ms": round(ms_conv, 4), "chains": chains,
                          "executed_gflop_per_launch": round(exec_flop / 1e9, 2),
                          "note": (f"achieved = executed_gflop_per_launch / avg_launch_ms of the main stream's launches ({B // chains} "
-                                  f"frames each, {blocks} one-per-CU blocks); peak = chip_peak x min(1, launch_blocks / cus); the other "
-                                  f"{chains - 1} chain(s) run on their own streams beside it") if chains > 1 else
+                                  f"frames each, {blocks} one-per-CU blocks); " +
+                                  (f"the {chains} whole-pass chains' launches each fill the chip and time-share it: peak = chip_peak / {chains}"
+                                   if shared else
+                                   f"peak = chip_peak x min(1, launch_blocks / cus); the other {chains - 1} chain(s) run on their own "
+                                   f"streams beside it")) if chains > 1 else
                                  "one launch at a time; achieved = executed_gflop_per_launch / avg_launch_ms",
                          "achieved_algorithmic": round(algo, 2),
                          "frac_algorithmic": round(algo / FP32_MFMA_PEAK_TFLOPS, 4),   # whole stage vs the CHIP peak

@@ -1074,6 +1074,10 @@ int eamm_bottleneck_chains(const eamm_ctx* c, int n) {
     const int whole = pass_chains(c, n);   // chains over the whole pass take precedence over chains inside the bottleneck
     return whole > 1 ? whole : bottleneck_chains(c, n);
 }
+int eamm_pass_chains(const eamm_ctx* c, int n) {
+    if (!c || n <= 0) return EAMM_ERR_ARG;
+    return pass_chains(c, n);
+}
 double eamm_encode_flops(const eamm_ctx* c) { return c ? c->flops_encode : 0.0; }
 
 int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int up,

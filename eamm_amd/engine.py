@@ -213,6 +213,10 @@ class Engine:
         """Concurrent launch sequences (streams) the bottleneck of a call of ``frames`` frames is split into."""
         return self._L.eamm_bottleneck_chains(self._ctx, int(frames))
 
+    def pass_chains(self, frames: int) -> int:
+        """Of those, the chains that run the whole per-frame pass as independent launch sequences (1 = none)."""
+        return self._L.eamm_pass_chains(self._ctx, int(frames))
+
     @property
     def encode_flops(self) -> float:
         return self._L.eamm_encode_flops(self._ctx)

@@ -139,6 +139,9 @@ int eamm_bottleneck_form(const eamm_ctx* ctx, int n);
 /* Chains the bottleneck of a call of n frames is split into (1 = one launch sequence on the caller's stream; K > 1 =
  * K groups of whole frames on K streams forked from and joined back into the caller's stream inside the call). */
 int eamm_bottleneck_chains(const eamm_ctx* ctx, int n);
+/* Of those, the chains that cover the WHOLE per-frame pass (independent launch sequences whose bottleneck launches
+ * time-share the chip) rather than the bottleneck alone: 1 = none. */
+int eamm_pass_chains(const eamm_ctx* ctx, int n);
 
 /*
  * ---- key-point detectors -----------------------------------------------
