@@ -38,8 +38,8 @@ struct eamm_ctx : eamm::CtxBase {
                                            // frames against 151 MB of transformed weights and stays direct
     int bneck_chains = 2;                  // bottleneck as this many chains of frames on as many streams (EAMM_BNECK_CHAINS; 1 = off)
     int pass_chains = 0;                   // the whole per-frame pass as this many chains (EAMM_PASS_CHAINS; 1 = off; 0 = the default: two chains
-                                           // when each chain's F(4x4) GEMM still fills the chip -- 512x512 x 8: 989 -> 1012 frames/s; otherwise off:
-                                           // measured 256x256 -- 16 frames 3381 vs 3370 frames/s, 12 frames 2633 vs 2765, 8 frames 2744 vs 2197)
+                                           // when each chain's F(4x4) GEMM keeps enough workgroups (pass_chains_min_blocks); otherwise off)
+    int pass_chains_min_blocks = 80;       // automatic mode: fewest bottleneck-GEMM workgroups per chain (EAMM_PASS_CHAINS_MIN_BLOCKS)
     int pass_chains_min_frames = 8;        // ... from this many frames per call (EAMM_PASS_CHAINS_MIN_FRAMES)
     std::vector<hipStream_t> side_streams; // the other chains' streams + fork / join events
     hipEvent_t ev_fork = nullptr;
@@ -203,6 +203,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->bneck_chains = env_int("EAMM_BNECK_CHAINS", c->bneck_chains);
     c->pass_chains = env_int("EAMM_PASS_CHAINS", c->pass_chains);
     c->pass_chains_min_frames = env_int("EAMM_PASS_CHAINS_MIN_FRAMES", c->pass_chains_min_frames);
+    c->pass_chains_min_blocks = env_int("EAMM_PASS_CHAINS_MIN_BLOCKS", c->pass_chains_min_blocks);
     c->head_col7_min_tiles = env_int("EAMM_HEAD_COL7_MIN_TILES", c->head_col7_min_tiles);
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
     c->enc_wino = env_int("EAMM_ENC_WINO", c->enc_wino);
@@ -622,10 +623,10 @@ static int pass_chains(const eamm_ctx* c, int n) {
     if (K < 2 || (int)c->side_streams.size() + 1 < K) return 1;
     const int tiles_pf = (c->hf / 4) * (c->wf / 4);
     if (n < c->pass_chains_min_frames || n < K) return 1;
-    if (automatic) {   // only when a chain's bottleneck GEMM is still a full round of one-per-CU blocks
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-        if (((n / K) * tiles_pf / 64) * ((c->Cb + 63) / 64) < cus) return 1;
+    if (automatic) {   // only while a chain's bottleneck GEMM keeps >= 80 one-per-CU blocks (measured 256x256, frames/s off -> on:
+        // 8 frames = 64 blocks per chain 2981 -> 2397; 10: 2695 -> 2794; 12: 3018 -> 3105; 16: 3720 -> 3790; 24: 3716 -> 3864;
+        // 32: 3871 -> 3980; 512x512 x 4: 941 -> 952, x 8: 985 -> 1006)
+        if (((n / K) * tiles_pf / 64) * ((c->Cb + 63) / 64) < c->pass_chains_min_blocks) return 1;
     }
     for (int k = 0; k < 2; ++k) {   // both chain sizes (n/K and n/K + 1 when n % K != 0)
         const int nk = n / K + k;

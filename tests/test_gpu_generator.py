@@ -356,15 +356,16 @@ def test_generator_without_motion_network():
 
 
 def test_chained_bottleneck_graph_capture_and_equivalence(monkeypatch):
-    """At 16 frames the bottleneck runs as two chains of 8 frames on two streams forked from / joined into the caller's
-    stream (eamm_bottleneck_chains).  (a) The fork / join is capturable: a HIP graph of the call replays bit-exactly.
-    (b) One chain (EAMM_BNECK_CHAINS=1) and two chains launch the same kernels on the same tiles per frame, only the
-    grouping of frames per launch differs: the frames must agree to rounding."""
+    """At 16 frames the call runs as two chains of 8 frames on two streams forked from / joined into the caller's stream
+    (eamm_bottleneck_chains; since round 2 the chains cover the whole per-frame pass, eamm_pass_chains; with
+    EAMM_PASS_CHAINS=1 only the bottleneck).  (a) The fork / join is capturable: a HIP graph of the call replays
+    bit-exactly.  (b) One chain, bottleneck-only chains and whole-pass chains compute every frame the same way up to the
+    launch plans that depend on the frames per launch (split-K, transform-point groups): the frames must agree to rounding."""
     cfg = hot_path_config()
     gen = generator(hot_path_config)
     src, kp_s, kp_d = synthetic_source(256, seed=1), synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(16, 10, seed=2)
     eng = gen.encode_source(src.to(DEV), max_frames=16)
-    assert eng.bottleneck_chains(16) == 2 and eng.bottleneck_chains(2) == 1
+    assert eng.bottleneck_chains(16) == 2 and eng.pass_chains(16) == 2 and eng.bottleneck_chains(2) == 1 and eng.pass_chains(8) == 1
     kd, ks = cuda(kp_d), cuda(kp_s)
     ref = eng.forward_frames(kd, ks)["prediction"].clone()
     side = torch.cuda.Stream()
@@ -379,10 +380,18 @@ def test_chained_bottleneck_graph_capture_and_equivalence(monkeypatch):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
-    monkeypatch.setenv("EAMM_BNECK_CHAINS", "1")
-    single = OcclusionAwareGenerator(**cfg)
-    single.load_state_dict(synthetic_state_dict(cfg, seed=1234), strict=True)
-    e1 = single.to(DEV).eval().encode_source(src.to(DEV), max_frames=16)
+    def fresh_engine():
+        g2 = OcclusionAwareGenerator(**cfg)
+        g2.load_state_dict(synthetic_state_dict(cfg, seed=1234), strict=True)
+        return g2.to(DEV).eval().encode_source(src.to(DEV), max_frames=16)
+
+    monkeypatch.setenv("EAMM_PASS_CHAINS", "1")          # chains inside the bottleneck only (the round-2 start state)
+    e2 = fresh_engine()
+    assert e2.bottleneck_chains(16) == 2 and e2.pass_chains(16) == 1
+    inner = e2.forward_frames(kd, ks)["prediction"]
+    assert float((inner - ref).abs().max()) <= 2e-5
+    monkeypatch.setenv("EAMM_BNECK_CHAINS", "1")         # ... and none at all
+    e1 = fresh_engine()
     assert e1.bottleneck_chains(16) == 1
     one = e1.forward_frames(kd, ks)["prediction"]
     assert float((one - ref).abs().max()) <= 2e-5
