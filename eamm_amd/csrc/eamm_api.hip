@@ -34,8 +34,8 @@ struct eamm_ctx : eamm::CtxBase {
     int enc_wino_min_mflop = 3000;         // ... for levels of at least this many direct-form MFLOP per call (EAMM_ENC_WINO_MIN_MFLOP): smaller ones are
                                            // launch-bound and one launch beats three (measured 256x256: 1 frame 810 vs 804, 4 frames equal,
                                            // 8 frames 2896 -> 2960, 12 frames 2849 -> 2968, 16 frames 3529 -> 3659; 512x512 x 8: 911 -> 948 frames/s)
-    int enc_wino_min_tiles = 64;           // ... and of at least one full 64-tile GEMM block (EAMM_ENC_WINO_MIN_TILES): the 4x4-map level has 16 tiles at 16
-                                           // frames against 151 MB of transformed weights and stays direct
+    int enc_wino_min_tiles = 32;           // ... and of at least this many 4x4 tiles (EAMM_ENC_WINO_MIN_TILES; x4 for levels with > 100 MB of transformed
+                                           // weights): the 4x4-map level has 16 tiles at 16 frames against 151 MB and stays direct
     int bneck_chains = 2;                  // bottleneck as this many chains of frames on as many streams (EAMM_BNECK_CHAINS; 1 = off)
     int pass_chains = 0;                   // the whole per-frame pass as this many chains (EAMM_PASS_CHAINS; 1 = off; 0 = the default: two chains
                                            // when each chain's F(4x4) GEMM keeps enough workgroups (pass_chains_min_blocks); otherwise off)
@@ -331,7 +331,8 @@ int eamm_finalize_weights(eamm_ctx* c) {
             const int cr = i == 0 ? cin0 : c->enc_c[i - 1], cp = i == 0 ? c->Cp0 : c->enc_c[i - 1], co = c->enc_c[i];
             const size_t tiles = (hw_l >> (2 * i)) / 16;
             if (((c->h >> i) & 3) || ((c->w >> i) & 3) || cp % 64 || (co & 3) || 36 * tiles * cp > 4 * hwf_l * c->Cb ||
-                tiles * co > (hwf_l / 16) * c->Cb || (size_t)g.max_frames * tiles < (size_t)c->enc_wino_min_tiles)
+                tiles * co > (hwf_l / 16) * c->Cb ||
+                (size_t)g.max_frames * tiles < (size_t)c->enc_wino_min_tiles * (144.0 * cp * co > 100e6 ? 4 : 1))
                 continue;   // (the last: never used at any call size -- do not pack 36 / 9 x the weights for nothing)
             const std::string p = dm + "hourglass.encoder.down_blocks." + std::to_string(i);
             if ((rc = build_wino4_rect(c, p + ".conv", p + ".norm", cr, cp, &c->w4enc[i]))) return rc;
@@ -676,7 +677,9 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         io.partial = v.partial;
         io.partial_cap = v.partial_elems;
         const int tiles = n * (io.Hin / 4) * (io.Win / 4);
-        if (i < (int)c->w4enc.size() && c->w4enc[i].Cout && tiles >= c->enc_wino_min_tiles &&
+        // (levels whose transformed weights exceed ~100 MB -- the 4x4-map level: 151 MB -- need four times the tiles to pay)
+        const bool heavy = i < (int)c->w4enc.size() && 144.0 * c->w4enc[i].Cin * c->w4enc[i].Cout > 100e6;
+        if (i < (int)c->w4enc.size() && c->w4enc[i].Cout && tiles >= c->enc_wino_min_tiles * (heavy ? 4 : 1) &&
             288e-6 * tiles * c->w4enc[i].Cin * c->w4enc[i].Cout >= (double)c->enc_wino_min_mflop) {   // 2 * 9 * 16 pixels per tile
             // F(4x4,3x3): 4x fewer MACs; the transform-point rows are split over workgroups (>= 2: the pooled epilogue is
             // the output-transform kernel's) -- the largest split that still fits one round of the chip
