@@ -20,6 +20,9 @@
 //   * all nine points' weights of a 32-channel chunk are 36 KiB: one barrier per chunk (144 MFMAs per wave);
 //   * a lane's tile pixel is rotated by two columns on odd rows so that the four 16-lane groups a ds_read_b128 is served
 //     in ({0-3,12-15,20-27}, ...) touch sixteen different (pixel & 15) keys of the swizzled patch image: conflict-free.
+//   * few tiles (the hourglass decoder's last levels): the channel chunks are split over 2 or 4 workgroups per tile
+//     (patch_poly_splits), raw phase sums go to a slab per split and patch_poly_reduce_kernel adds them in a fixed order
+//     with bias and activation.
 // fp32 throughout; only the summation order differs from the reference (measured at the prediction: DESIGN.md 5.2d).
 #include "conv_common.h"
 
