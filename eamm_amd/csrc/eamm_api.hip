@@ -26,6 +26,8 @@ struct eamm_ctx : eamm::CtxBase {
 
     // layers
     ConvLayer first, final_conv, head;
+    float *first7_w = nullptr, *first7_bias = nullptr;   // the first block on its dedicated 3-channel kernel (conv_first.hip), or null
+    int first7 = 1;                                       // EAMM_FIRST7: 0 = the generic 7x7 kernel on the 32-channel-padded source
     std::vector<LayerSet> down, hg_enc, hg_dec, res1, res2, up;
     std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
     std::vector<WinoLayer> w4res1, w4res2; // Winograd F(4x4,3x3) packing (bottleneck maps with sides divisible by 4)
@@ -207,6 +209,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->head_col7_min_tiles = env_int("EAMM_HEAD_COL7_MIN_TILES", c->head_col7_min_tiles);
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
     c->enc_wino = env_int("EAMM_ENC_WINO", c->enc_wino);
+    c->first7 = env_int("EAMM_FIRST7", c->first7);
     c->enc_wino_min_mflop = env_int("EAMM_ENC_WINO_MIN_MFLOP", c->enc_wino_min_mflop);
     c->enc_wino_min_tiles = env_int("EAMM_ENC_WINO_MIN_TILES", c->enc_wino_min_tiles);
     c->dma_cfg_n256 = env_int("EAMM_DMA_CFG_N256", c->dma_cfg_n256);
@@ -281,6 +284,23 @@ int eamm_finalize_weights(eamm_ctx* c) {
     }
     // generator encoder
     if ((rc = build_layer(c, {{"first.conv", "first.norm"}}, 7, 3, c->Csrc, 0, 0, &c->first))) return rc;
+    if (c->first7 && first7_supported(c->down_c[0])) {   // K = 147 (196 with the zero rows) instead of 49 x 32
+        const HostTensor *wt = find(c, "first.conv.weight"), *bt = find(c, "first.conv.bias"), *gm = find(c, "first.norm.weight"),
+                         *be = find(c, "first.norm.bias"), *mu = find(c, "first.norm.running_mean"), *vr = find(c, "first.norm.running_var");
+        const int co = c->down_c[0];
+        if (wt && bt && gm && be && mu && vr && wt->shape.size() == 4 && wt->shape[0] == co && wt->shape[1] == 3 &&
+            wt->shape[2] == 7 && wt->shape[3] == 7) {
+            std::vector<float> wf(wt->data), bf(co), packed((size_t)196 * co);
+            for (int o = 0; o < co; ++o) {
+                const double sc = (double)gm->data[o] / std::sqrt((double)vr->data[o] + 1e-5);
+                bf[o] = (float)(((double)bt->data[o] - (double)mu->data[o]) * sc + (double)be->data[o]);
+                for (int i = 0; i < 147; ++i) wf[(size_t)o * 147 + i] = (float)((double)wt->data[(size_t)o * 147 + i] * sc);
+            }
+            first7_pack_host(wf.data(), co, packed.data());
+            if ((rc = upload(c, &c->first7_w, packed))) return rc;
+            if ((rc = upload(c, &c->first7_bias, bf))) return rc;
+        }
+    }
     c->down.resize(c->nd);
     for (int i = 0; i < c->nd; ++i) {
         const std::string p = "down_blocks." + std::to_string(i);
@@ -498,7 +518,10 @@ int eamm_encode_source(eamm_ctx* c, const float* source, int ns, void* stream_) 
     io.out = c->enc_tmp[0];
     io.partial = c->partial;
         io.partial_cap = c->partial_elems;
-    HIP_TRY(c, conv_launch(c->first, io, s));                     // SameBlock2d 7x7   generator.py:61
+    if (c->first7_w)                                              // SameBlock2d 7x7   generator.py:61
+        HIP_TRY(c, first7_launch(source, c->first7_w, c->first7_bias, ns, c->H, c->W, c->down_c[0], c->enc_tmp[0], s));
+    else
+        HIP_TRY(c, conv_launch(c->first, io, s));
     for (int i = 0; i < c->nd; ++i) {                             // DownBlock2d       generator.py:62-63
         ConvIO d{};
         d.in0 = c->enc_tmp[i];

@@ -138,6 +138,12 @@ hipError_t wino4_transform_launch(const float* x, const float* s, const float* t
 hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, int W, int act, const float* resid,
                              float* out, hipStream_t stream, int variant = 0, int groups = 1, float* zbuf = nullptr, int pool = 0);
 
+// ---- the generator's first block: 7x7 conv 3 -> Cout (+ folded BatchNorm, ReLU) from the NCHW source (conv_first.hip)
+bool first7_supported(int Cout);
+void first7_pack_host(const float* w_oihw_7x7_folded, int Cout, float* dst /*[196][Cout]*/);
+hipError_t first7_launch(const float* src /*[ns,3,H,W]*/, const float* w_packed, const float* bias, int ns, int H, int W,
+                         int Cout, float* out /*[ns,H,W,Cout]*/, hipStream_t stream);
+
 // ---- motion / warp / image kernels (motion.hip) ---------------------------------------------
 hipError_t kp_prepare_launch(const float* kd_val, const float* kd_jac, const float* ks_val, const float* ks_jac,
                              int n, int ns, int K, float* kp_rec, int* bad_flag, hipStream_t s);
