@@ -31,6 +31,7 @@ struct eamm_ctx : eamm::CtxBase {
     std::vector<LayerSet> down, hg_enc, hg_dec, res1, res2, up;
     std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
     std::vector<WinoLayer> w4res1, w4res2; // Winograd F(4x4,3x3) packing (bottleneck maps with sides divisible by 4)
+    std::vector<WinoLayer> w4down;         // ... and of the generator encoder's DownBlock2d levels (source encoding, once per clip / per module call without cache)
     std::vector<WinoLayer> w4enc;          // F(4x4,3x3) packing of the hourglass encoder convolutions (Cout == 0: level not eligible)
     int enc_wino = 1;                      // hourglass DownBlock2d levels in F(4x4,3x3) form + pooled output transform (EAMM_ENC_WINO)
     int enc_wino_min_mflop = 3000;         // ... for levels of at least this many direct-form MFLOP per call (EAMM_ENC_WINO_MIN_MFLOP): smaller ones are
@@ -358,6 +359,15 @@ int eamm_finalize_weights(eamm_ctx* c) {
             if ((rc = build_wino4_rect(c, p + ".conv", p + ".norm", cr, cp, &c->w4enc[i]))) return rc;
         }
     }
+    if (c->enc_wino && !c->w4res1.empty()) {   // the source encoder's down blocks likewise (workspaces sized for them below)
+        c->w4down.resize(c->nd);
+        for (int i = 0; i < c->nd; ++i) {
+            const int ci = c->down_c[i], co = c->down_c[i + 1];
+            if (((c->H >> i) & 3) || ((c->W >> i) & 3) || ci % 64 || (co & 3)) continue;
+            const std::string p = "down_blocks." + std::to_string(i);
+            if ((rc = build_wino4_rect(c, p + ".conv", p + ".norm", ci, ci, &c->w4down[i]))) return rc;
+        }
+    }
     c->up.resize(c->nd);
     for (int i = 0; i < c->nd; ++i) {
         const std::string p = "up_blocks." + std::to_string(i);
@@ -412,8 +422,15 @@ int eamm_finalize_weights(eamm_ctx* c) {
     if ((rc = dev_alloc(c, &c->act, F * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->tmp, F * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->final_part, F * HW * 32))) return rc;
-    if (!c->wres1.empty() && (rc = dev_alloc(c, &c->wino_v, 4 * F * hwf * c->Cb))) return rc;
-    if (!c->w4res1.empty() && (rc = dev_alloc(c, &c->wino_z, 24 * ((F * hwf + 15) / 16) * c->Cb))) return rc;
+    size_t v_elems = 4 * F * hwf * c->Cb, z_elems = 24 * ((F * hwf + 15) / 16) * c->Cb;
+    for (size_t i = 0; i < c->w4down.size(); ++i)   // the encoder's down blocks in F(4x4) form borrow the same workspaces
+        if (c->w4down[i].Cout) {
+            const size_t tiles = S * (HW >> (2 * i)) / 16;
+            v_elems = std::max(v_elems, 36 * tiles * c->w4down[i].Cin);
+            z_elems = std::max(z_elems, 24 * tiles * c->w4down[i].Cout);
+        }
+    if (!c->wres1.empty() && (rc = dev_alloc(c, &c->wino_v, v_elems))) return rc;
+    if (!c->w4res1.empty() && (rc = dev_alloc(c, &c->wino_z, z_elems))) return rc;
     c->up_buf.resize(c->nd);
     for (int i = 0; i < c->nd; ++i)
         if ((rc = dev_alloc(c, &c->up_buf[i], F * (hwf << (2 * (i + 1))) * c->up_c[i]))) return rc;
@@ -533,6 +550,22 @@ int eamm_encode_source(eamm_ctx* c, const float* source, int ns, void* stream_) 
         d.out = (i == c->nd - 1) ? c->feat : c->enc_tmp[i + 1];
         d.partial = c->partial;
         d.partial_cap = c->partial_elems;
+        const int tiles = ns * (d.Hin / 4) * (d.Win / 4);
+        if (i < (int)c->w4down.size() && c->w4down[i].Cout && c->wino_v && c->wino_z && tiles >= c->enc_wino_min_tiles &&
+            288e-6 * tiles * c->w4down[i].Cin * c->w4down[i].Cout >= (double)c->enc_wino_min_mflop) {
+            const WinoLayer& L = c->w4down[i];   // as the hourglass encoder levels (forward_view)
+            const int nblk = ((tiles + 63) / 64) * L.ntiles;
+            int cus = 256, g = 2;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            for (int gsel : {6, 3})
+                if (nblk * gsel <= cus) {
+                    g = gsel;
+                    break;
+                }
+            HIP_TRY(c, wino4_transform_launch(d.in0, nullptr, nullptr, ns, d.Hin, d.Win, L.Cin, c->wino_v, s));
+            HIP_TRY(c, wino4_gemm_launch(L, c->wino_v, ns, d.Hin, d.Win, ACT_RELU, nullptr, d.out, s, 0, g, c->wino_z, 1));
+            continue;
+        }
         HIP_TRY(c, conv_launch(pick(c, c->down[i], (size_t)ns * d.Hin * d.Win), d, s));
     }
     c->ns_cached = ns;
