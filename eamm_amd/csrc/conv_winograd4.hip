@@ -600,9 +600,9 @@ hipError_t wino4_transform_launch(const float* x, const float* s, const float* t
     return hipGetLastError();
 }
 
-template <int SUB, int NST, int PE, int DBG = 0>
+template <int SUB, int NST, int PE, int DBG = 0, int WM = 4>
 static hipError_t wino4_launch_variant(const Wino4Args& a, hipStream_t stream) {
-    constexpr int NT = 2, WM = 4, WN = 2;
+    constexpr int NT = 2, WN = 2;
     constexpr int BM = WM * 16, BN = WN * NT * 16;
     constexpr size_t lds_loop = sizeof(float) * NST * SUB * (BM + BN) * CONV_BK;
     constexpr size_t lds_epi = sizeof(float) * 4 * BM * (BN + 4);
@@ -632,6 +632,10 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     a.W = W;
     a.mtiles = (a.Mq + BM - 1) / BM;
     a.ntiles = L.ntiles;
+    // very few tiles (one 256x256 frame: 4 x 4 x 6 = 96 workgroups): 32-tile blocks of four waves double the grid
+    static const int narrow_max = [] { const char* e = getenv("EAMM_WINO4_NARROW_MAX_BLOCKS"); return e ? atoi(e) : 128; }();
+    const bool narrow = groups == 6 && a.mtiles * a.ntiles * groups <= narrow_max && L.Cin % (4 * CONV_BK) == 0;
+    if (narrow) a.mtiles = (a.Mq + 31) / 32;
     a.act = act;
     a.resid = resid;
     a.out = out;
@@ -645,7 +649,9 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     a.u_bytes = (unsigned)ub;
     const bool sub4 = L.Cin % (4 * CONV_BK) == 0;
     hipError_t e = hipErrorInvalidValue;
+    if (narrow) variant = 30;
     switch (variant) {   // (chunks per barrier, ring depth, MFMAs per DMA piece)
+        case 30: e = wino4_launch_variant<4, 2, 4, 0, 2>(a, stream); break;
         case 0: e = sub4 ? wino4_launch_variant<4, 2, 4>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream); break;
         case 1: e = wino4_launch_variant<2, 2, 4>(a, stream); break;
         case 2: e = wino4_launch_variant<2, 3, 4>(a, stream); break;
