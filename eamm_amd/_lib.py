@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeamm_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EAMM_OK = 0
 ERR_ARG, ERR_STATE, ERR_KEY, ERR_HIP, ERR_NUMERIC = -1, -2, -3, -4, -5
@@ -100,6 +100,8 @@ SIGNATURES = {
                                     C.POINTER(C.c_int64), C.c_int]),
     "eamm_op_conv": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                               C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "eamm_op_warp": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
 }
 

@@ -297,8 +297,9 @@ hipError_t conv_col7s_launch(const float* in0, int C0, const float* in1, int C1,
     a.PS = pixel_stride;
     constexpr size_t lds = sizeof(float) * (2 * CPIX * CONV_BK + 2 * 3 * 32 * CONV_BK);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static unsigned long long configured = 0;
+    static lds_once_mask configured{0};
     if (hipError_t e = ensure_dynamic_lds(conv_col7s_kernel<3>, lds, &configured); e != hipSuccess) return e;
+    note_mfma_flops(2.0 * a.tiles_x * a.tiles_y * B * (CT * CT) * 7.0 * (ntile32 * 32) * (C0 + C1));
     hipLaunchKernelGGL(conv_col7s_kernel<3>, dim3(a.tiles_x * a.tiles_y * B), dim3(CWAVES * 64), lds, stream, a);
     return hipGetLastError();
 }
@@ -323,12 +324,13 @@ hipError_t conv_col7_launch(const float* in, int C, int B, int H, int W, const f
     a.out = out;
     const size_t lds = wb + sizeof(float) * 2 * CPIX * CONV_BK;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static unsigned long long configured = 0;
+    static lds_once_mask configured{0};
     if (hipError_t e = ensure_dynamic_lds(conv_col7_kernel, 160 * 1024, &configured); e != hipSuccess) return e;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int blocks = std::min(a.tiles, cus);
+    note_mfma_flops(2.0 * a.tiles * (CT * CT) * 7.0 * 32 * C);
     hipLaunchKernelGGL(conv_col7_kernel, dim3(blocks), dim3(CWAVES * 64), lds, stream, a);
     return hipGetLastError();
 }

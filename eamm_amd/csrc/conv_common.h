@@ -2,21 +2,24 @@
 #pragma once
 #include "kernels.h"
 
+#include <atomic>
 #include <type_traits>
 
 namespace eamm {
 
 // Opt a kernel into > 64 KiB of dynamic LDS once per (kernel instantiation, device): the attribute belongs to the
 // device's copy of the function, and one process may drive several GPUs (one handle per device).
+// The mask is shared by every host thread that launches the kernel (one thread per device): a real atomic.
+typedef std::atomic<unsigned long long> lds_once_mask;
 template <typename K>
-inline hipError_t ensure_dynamic_lds(K kern, size_t bytes, unsigned long long* done_mask) {
+inline hipError_t ensure_dynamic_lds(K kern, size_t bytes, lds_once_mask* done_mask) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
-    if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    if (done_mask->load(std::memory_order_acquire) & bit) return hipSuccess;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+    if (e == hipSuccess) done_mask->fetch_or(bit, std::memory_order_release);
     return e;
 }
 

@@ -119,12 +119,12 @@ hipError_t first7_launch(const float* src, const float* w_packed, const float* b
     a.out = out;
     const size_t lds = sizeof(float) * (4 * FPLANE + (size_t)FK * Cout);
     const int blocks = a.tiles_x * a.tiles_y * ns;
-    auto go = [&](auto kern, unsigned long long* configured) -> hipError_t {
+    auto go = [&](auto kern, lds_once_mask* configured) -> hipError_t {
         if (hipError_t e = ensure_dynamic_lds(kern, lds, configured); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(FWAVES * 64), lds, stream, a);
         return hipGetLastError();
     };
-    static unsigned long long cfg[4] = {0, 0, 0, 0};
+    static lds_once_mask cfg[4];
     switch (Cout / 32) {
         case 1: return go(conv_first7_kernel<1>, &cfg[0]);
         case 2: return go(conv_first7_kernel<2>, &cfg[1]);

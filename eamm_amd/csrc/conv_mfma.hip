@@ -337,7 +337,7 @@ static hipError_t launch_cfg(const ConvArgs& a, int blocks, hipStream_t stream) 
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * CONV_LDK;
     auto kern = conv_mfma_kernel<KH, KW, MT, NT, WM, WN, PHASE>;
-    static unsigned long long configured = 0;  // per-device bit mask
+    static lds_once_mask configured{0};  // per-device bit mask
     if (hipError_t e = ensure_dynamic_lds(kern, lds, &configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
     return hipGetLastError();
@@ -349,6 +349,16 @@ static hipError_t launch_tile(int BN, const ConvArgs& a, int blocks, hipStream_t
     if (BN == 64) return launch_cfg<KH, KW, 2, 1, 2, 2, PHASE>(a, blocks, stream);
     if (BN == 32) return launch_cfg<KH, KW, 1, 1, 4, 1, PHASE>(a, blocks, stream);
     return hipErrorInvalidValue;
+}
+
+namespace {
+thread_local double g_mfma_flops = 0.0;
+}
+void note_mfma_flops(double flops) { g_mfma_flops += flops; }
+double take_mfma_flops() {
+    const double v = g_mfma_flops;
+    g_mfma_flops = 0.0;
+    return v;
 }
 
 hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream, int force_splits) {
@@ -396,6 +406,7 @@ hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream,
     if (pl.splits > 1 && io.partial == nullptr) return hipErrorInvalidValue;
     if (L.phase && io.pool) return hipErrorInvalidValue;
     const int blocks = pl.mtiles * pl.ntiles * a.nphase * pl.splits;
+    note_mfma_flops(2.0 * pl.mtiles * L.BM * (double)pl.ntiles * L.BN * (double)L.nchunks * CONV_BK * a.nphase);
     hipError_t e = hipErrorInvalidValue;
     if (L.dma_cfg > 0) e = conv_dma_launch_kernel(L, a, blocks, stream);
     else if (L.phase) e = launch_tile<2, 2, true>(L.BN, a, blocks, stream);

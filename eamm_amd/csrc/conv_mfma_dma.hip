@@ -204,7 +204,7 @@ static hipError_t launch_dma_cfg(const ConvArgs& a, int blocks, hipStream_t stre
     constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv_mfma_dma_kernel<KH, KW, MT, NT, WM, WN, PHASE>;
-    static unsigned long long configured = 0;  // per-device bit mask
+    static lds_once_mask configured{0};  // per-device bit mask
     if (hipError_t e = ensure_dynamic_lds(kern, lds, &configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WM * WN * 64), lds, stream, a);
     return hipGetLastError();

@@ -287,9 +287,10 @@ hipError_t patch_phase_launch(const PatchLayer& L, const float* in0, const float
     constexpr size_t lds_epi = sizeof(float) * (PT * PT) * (PBN + 4);
     constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static unsigned long long configured = 0;
+    static lds_once_mask configured{0};
     if (hipError_t e = ensure_dynamic_lds(conv_patch_phase_kernel, lds, &configured); e != hipSuccess) return e;
     const int blocks = a.tiles_x * a.tiles_y * B * a.ntiles;
+    note_mfma_flops(2.0 * a.tiles_x * a.tiles_y * B * (PT * PT) * 16.0 * (a.ntiles * PBN) * (L.C0 + L.C1));
     hipLaunchKernelGGL(conv_patch_phase_kernel, dim3(blocks), dim3(PWAVES * 64), lds, stream, a);
     return hipGetLastError();
 }

@@ -350,9 +350,10 @@ hipError_t patch_poly_launch(const PatchLayer& L, const float* in0, const float*
     constexpr size_t lds_epi = sizeof(float) * (ZT * ZT) * (ZBN + 4);
     constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static unsigned long long configured = 0;
+    static lds_once_mask configured{0};
     if (hipError_t e = ensure_dynamic_lds(conv_patch_poly_kernel, lds, &configured); e != hipSuccess) return e;
     const int blocks = a.tiles_x * a.tiles_y * B * a.ntiles * splits;
+    note_mfma_flops(2.0 * a.tiles_x * a.tiles_y * B * (ZT * ZT) * 9.0 * (a.ntiles * ZBN) * (L.C0 + L.C1));
     hipLaunchKernelGGL(conv_patch_poly_kernel, dim3(blocks), dim3(ZWAVES * 64), lds, stream, a);
     if (splits > 1) {
         const size_t total4 = slab / 4;

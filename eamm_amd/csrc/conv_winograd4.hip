@@ -609,8 +609,9 @@ static hipError_t wino4_launch_variant(const Wino4Args& a, hipStream_t stream) {
     constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = wino4_gemm_kernel<NT, WM, WN, SUB, NST, PE, DBG>;
-    static unsigned long long configured = 0;  // per-device bit mask
+    static lds_once_mask configured{0};  // per-device bit mask
     if (hipError_t e = ensure_dynamic_lds(kern, lds, &configured); e != hipSuccess) return e;
+    note_mfma_flops(2.0 * 36.0 * a.mtiles * BM * (double)a.ntiles * BN * a.C);
     hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles * a.groups), dim3(WM * WN * 64), lds, stream, a);
     return hipGetLastError();
 }

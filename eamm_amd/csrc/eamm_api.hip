@@ -84,12 +84,20 @@ struct eamm_ctx : eamm::CtxBase {
     double flops_frame = 0, flops_encode = 0;
 
     // optional stage timing with HIP events on the caller's stream (bench.py roofline leg)
-    static constexpr int NSTAGE = 10;      // front, hg_enc, hg_dec, head, warp, bneck_transform, bneck_conv, up, final + bneck_gemm_kernel
+    static constexpr int NSTAGE = 14;      // front, hg_enc, hg_dec, head, warp, bneck_transform, bneck_conv, up, final + bneck_gemm_kernel
+                                           // + bneck_union_ms (wall time during which ANY chain is in its bottleneck stage), bneck_windows_ms (sum of
+                                           // the chains' bottleneck windows), exec_gflop / bneck_exec_gflop (executed MFMA GFLOP of the recorded
+                                           // calls, all chains: whole pass / bottleneck GEMMs)
+    static constexpr int MAXCHAIN = 4;     // chains whose bottleneck window is recorded per call
     static constexpr int NMARK = 8;        // stage boundaries recorded per call (bottleneck is split from sub-events)
     static constexpr int NSUB = 64;        // per-launch events inside the bottleneck (4 per res-block + 1)
     static constexpr int PROF_CALLS = 256; // event sets kept before the host must read them
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;   // PROF_CALLS * (NMARK+1 + NSUB)
+    std::vector<hipEvent_t> prof_chain_ev; // PROF_CALLS * MAXCHAIN * 2: start / end of each whole-pass chain's bottleneck stage
+    std::vector<int> prof_nchain;          // chains recorded by each call
+    std::vector<double> prof_flops, prof_flops_bneck;   // executed MFMA flops of each recorded call
+    double call_flops = 0, call_flops_bneck = 0;         // ... of the call being enqueued
     std::vector<int> prof_sub;             // sub-events used by each recorded call (0: direct form)
     std::vector<int> prof_marks;           // stage marks each recorded call completed (NMARK + 1 unless it failed midway)
     int prof_used = 0;
@@ -129,6 +137,12 @@ void expected_keys(const eamm_ctx* c, std::vector<std::string>* keys) {
 }
 
 double conv_flops(int ks, int cin, int cout, double pixels) { return 2.0 * ks * ks * (double)cin * cout * pixels; }
+
+// The F(4x4) kernels address V ([36][tiles][Cin]) and Z ([24][tiles][Cout]) through 32-bit buffer descriptors
+// (wino4_gemm_launch refuses from 0xFFFFF000 bytes): a call with more tiles than this takes the direct kernels.
+bool wino4_fits(size_t tiles, int cin, int cout) {
+    return 36.0 * tiles * cin * 4.0 < 4294963200.0 && 24.0 * tiles * cout * 4.0 < 4294963200.0;
+}
 
 }  // namespace
 
@@ -205,6 +219,10 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->col7 = env_int("EAMM_COL7", c->col7);
     c->bneck_chains = env_int("EAMM_BNECK_CHAINS", c->bneck_chains);
     c->pass_chains = env_int("EAMM_PASS_CHAINS", c->pass_chains);
+    // clamped ONCE, here: negative = off (as the other knobs), at most four chains; the split-K slab count and the runtime
+    // chain count both derive from this value
+    c->pass_chains = c->pass_chains < 0 ? 1 : std::min(c->pass_chains, 4);
+    c->bneck_chains = std::max(1, std::min(c->bneck_chains, 16));
     c->pass_chains_min_frames = env_int("EAMM_PASS_CHAINS_MIN_FRAMES", c->pass_chains_min_frames);
     c->pass_chains_min_blocks = env_int("EAMM_PASS_CHAINS_MIN_BLOCKS", c->pass_chains_min_blocks);
     c->head_col7_min_tiles = env_int("EAMM_HEAD_COL7_MIN_TILES", c->head_col7_min_tiles);
@@ -225,6 +243,7 @@ void eamm_destroy(eamm_ctx* c) {
     DeviceGuard guard(c->device);
     free_owned(c);
     for (auto& e : c->prof_events) (void)hipEventDestroy(e);
+    for (auto& e : c->prof_chain_ev) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (auto& e : c->ev_join) (void)hipEventDestroy(e);
     for (auto& st : c->side_streams) (void)hipStreamDestroy(st);
@@ -424,8 +443,10 @@ int eamm_finalize_weights(eamm_ctx* c) {
     if ((rc = dev_alloc(c, &c->final_part, F * HW * 32))) return rc;
     size_t v_elems = 4 * F * hwf * c->Cb, z_elems = 24 * ((F * hwf + 15) / 16) * c->Cb;
     for (size_t i = 0; i < c->w4down.size(); ++i)   // the encoder's down blocks in F(4x4) form borrow the same workspaces
-        if (c->w4down[i].Cout) {
-            const size_t tiles = S * (HW >> (2 * i)) / 16;
+        if (c->w4down[i].Cout) {   // ... for as many sources per call as the 32-bit descriptors allow (more take the direct kernels)
+            size_t ns_fit = S;
+            while (ns_fit > 0 && !wino4_fits(ns_fit * (HW >> (2 * i)) / 16, c->w4down[i].Cin, c->w4down[i].Cout)) --ns_fit;
+            const size_t tiles = ns_fit * (HW >> (2 * i)) / 16;
             v_elems = std::max(v_elems, 36 * tiles * c->w4down[i].Cin);
             z_elems = std::max(z_elems, 24 * tiles * c->w4down[i].Cout);
         }
@@ -472,8 +493,8 @@ int eamm_finalize_weights(eamm_ctx* c) {
             upd1(c->final_conv, f * HW);
         }
         c->partial_elems = need;   // one slab per whole-pass chain
-        const int pc = env_int("EAMM_PASS_CHAINS", c->pass_chains);
-        if ((rc = dev_alloc(c, &c->partial, c->partial_elems * (size_t)(pc == 0 ? 2 : std::max(1, std::min(pc, 4)))))) return rc;
+        const int slabs = c->pass_chains == 0 ? 2 : c->pass_chains;   // (clamped to 0..4 in eamm_create; 0 = automatic = two chains)
+        if ((rc = dev_alloc(c, &c->partial, c->partial_elems * (size_t)slabs))) return rc;
     }
 
     // ---- algorithmic FLOPs (reference layer shapes, real channel counts)
@@ -495,8 +516,6 @@ int eamm_finalize_weights(eamm_ctx* c) {
         if (c->nb > 0) ff += 9.0 * hwf * c->Cb;  // bilinear feature warp + occlusion multiply
         c->flops_frame = ff;
     }
-    c->bneck_chains = std::max(1, std::min(c->bneck_chains, 16));
-    c->pass_chains = std::max(0, std::min(c->pass_chains, 4));
     const int max_chains = std::max(c->bneck_chains, c->pass_chains == 0 ? 2 : c->pass_chains);
     if (max_chains > 1) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -552,6 +571,7 @@ int eamm_encode_source(eamm_ctx* c, const float* source, int ns, void* stream_) 
         d.partial_cap = c->partial_elems;
         const int tiles = ns * (d.Hin / 4) * (d.Win / 4);
         if (i < (int)c->w4down.size() && c->w4down[i].Cout && c->wino_v && c->wino_z && tiles >= c->enc_wino_min_tiles &&
+            wino4_fits((size_t)tiles, c->w4down[i].Cin, c->w4down[i].Cout) &&
             288e-6 * tiles * c->w4down[i].Cin * c->w4down[i].Cout >= (double)c->enc_wino_min_mflop) {
             const WinoLayer& L = c->w4down[i];   // as the hourglass encoder levels (forward_view)
             const int nblk = ((tiles + 63) / 64) * L.ntiles;
@@ -694,7 +714,7 @@ static int pass_chains(const eamm_ctx* c, int n) {
 }
 
 // One launch sequence over the frames of `v` on stream s.  `chained`: another sequence runs beside this one.
-static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent_t* ev, bool chained) {
+static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent_t* ev, bool chained, hipEvent_t* cev = nullptr) {
     const int n = v.n, ns = v.ns;
     const int h = c->h, w = c->w, hf = c->hf, wf = c->wf, K = c->K;
     const bool occ = c->cfg.estimate_occlusion_map != 0;
@@ -817,6 +837,8 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
     }
     // bottleneck                                                               generator.py:89
     float *x = v.xa, *xn = v.xb;
+    if (cev) HIP_TRY(c, hipEventRecord(cev[0], s));
+    c->call_flops += take_mfma_flops();
     hipEvent_t* sub = (ev && wino && 4 * nr + 1 <= eamm_ctx::NSUB) ? ev + eamm_ctx::NMARK + 1 : nullptr;
     int nsub = 0;
 #define SUB_MARK()                                               \
@@ -914,6 +936,12 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         std::swap(x, xn);
     }
     STAGE_MARK(6);
+    if (cev) HIP_TRY(c, hipEventRecord(cev[1], s));
+    {
+        const double fb = take_mfma_flops();
+        c->call_flops += fb;
+        c->call_flops_bneck += fb;
+    }
     // up blocks                                                                generator.py:90-91
     const float* cur = x;
     for (int i = 0; i < c->nd; ++i) {
@@ -950,6 +978,7 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         HIP_TRY(c, final_shift_sum_launch(v.final_part, c->final_bias, n, c->H, c->W, v.out.prediction, s));
     }
     if (v.out.frames_u8) HIP_TRY(c, to_u8_launch(v.out.prediction, n, c->H, c->W, v.out.frames_u8, s));
+    c->call_flops += take_mfma_flops();
 #undef STAGE_MARK
     return EAMM_OK;   // (the caller records the last stage mark, after joining the chains)
 }
@@ -974,16 +1003,23 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
 
     hipEvent_t* ev = nullptr;  // stage boundaries (of the main stream's sequence), recorded only while profiling
+    hipEvent_t* cev = nullptr; // bottleneck window of every whole-pass chain
+    const int chains = pass_chains(c, n);
     if (c->profiling && c->prof_used < eamm_ctx::PROF_CALLS) {
         ev = c->prof_events.data() + (size_t)c->prof_used * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB);
+        cev = c->prof_chain_ev.data() + (size_t)c->prof_used * eamm_ctx::MAXCHAIN * 2;
         c->prof_n.push_back(n);
         c->prof_sub.push_back(0);
         c->prof_marks.push_back(0);
+        c->prof_nchain.push_back(std::min(chains, (int)eamm_ctx::MAXCHAIN));
+        c->prof_flops.push_back(0.0);
+        c->prof_flops_bneck.push_back(0.0);
         ++c->prof_used;
     }
-    const int chains = pass_chains(c, n);
+    (void)take_mfma_flops();
+    c->call_flops = c->call_flops_bneck = 0.0;
     if (chains == 1) {
-        if (int rc = forward_view(c, make_view(c, 0, n, ns, 0, kd_val, kd_jac, ks_val, ks_jac, o), s, ev, false)) return rc;
+        if (int rc = forward_view(c, make_view(c, 0, n, ns, 0, kd_val, kd_jac, ks_val, ks_jac, o), s, ev, false, cev)) return rc;
     } else {
         const int nbase = n / chains, nrem = n % chains;   // the first nrem chains take one more frame
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
@@ -991,7 +1027,9 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         for (int k = 0; k < chains; ++k) {
             const int nk = nbase + (k < nrem ? 1 : 0), f0 = k * nbase + std::min(k, nrem);
             const FrameView v = make_view(c, f0, nk, ns, k, kd_val, kd_jac, ks_val, ks_jac, o);
-            if (int rc = forward_view(c, v, k ? c->side_streams[k - 1] : s, k ? nullptr : ev, true)) return rc;
+            if (int rc = forward_view(c, v, k ? c->side_streams[k - 1] : s, k ? nullptr : ev, true,
+                                      (cev && k < eamm_ctx::MAXCHAIN) ? cev + 2 * k : nullptr))
+                return rc;
         }
         for (int k = 1; k < chains; ++k) {
             HIP_TRY(c, hipEventRecord(c->ev_join[k - 1], c->side_streams[k - 1]));
@@ -1001,6 +1039,8 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     if (ev) {   // the last stage ends where the call ends (after the join)
         HIP_TRY(c, hipEventRecord(ev[eamm_ctx::NMARK], s));
         c->prof_marks.back() = eamm_ctx::NMARK + 1;
+        c->prof_flops.back() = c->call_flops;
+        c->prof_flops_bneck.back() = c->call_flops_bneck;
     }
     return EAMM_OK;
 }
@@ -1012,6 +1052,8 @@ int eamm_profile_enable(eamm_ctx* c, int on) {
     if (on && c->prof_events.empty()) {
         c->prof_events.resize((size_t)eamm_ctx::PROF_CALLS * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB));
         for (auto& e : c->prof_events) HIP_TRY(c, hipEventCreate(&e));
+        c->prof_chain_ev.resize((size_t)eamm_ctx::PROF_CALLS * eamm_ctx::MAXCHAIN * 2);
+        for (auto& e : c->prof_chain_ev) HIP_TRY(c, hipEventCreate(&e));
     }
     c->profiling = on != 0;
     return EAMM_OK;
@@ -1051,6 +1093,36 @@ int eamm_profile_read(eamm_ctx* c, double* stage_ms, int nstage, int64_t* calls,
                 ms_set[9] += ms;
             }
         }
+        if (ok) {   // bottleneck windows of the whole-pass chains, on the clock of this call's first event
+            hipEvent_t* cv = c->prof_chain_ev.data() + (size_t)k * eamm_ctx::MAXCHAIN * 2;
+            const int nc = c->prof_nchain[k];
+            float t0[eamm_ctx::MAXCHAIN], t1[eamm_ctx::MAXCHAIN];
+            for (int j = 0; ok && j < nc; ++j)
+                ok = hipEventSynchronize(cv[2 * j + 1]) == hipSuccess && hipEventElapsedTime(&t0[j], ev[0], cv[2 * j]) == hipSuccess &&
+                     hipEventElapsedTime(&t1[j], ev[0], cv[2 * j + 1]) == hipSuccess;
+            if (ok) {
+                int order[eamm_ctx::MAXCHAIN];
+                for (int j = 0; j < nc; ++j) order[j] = j;
+                std::sort(order, order + nc, [&](int a, int b) { return t0[a] < t0[b]; });
+                double uni = 0, sum = 0, cur0 = 0, cur1 = -1;
+                for (int q = 0; q < nc; ++q) {
+                    const int j = order[q];
+                    sum += t1[j] - t0[j];
+                    if (cur1 < cur0 || t0[j] > cur1) {   // a new disjoint interval
+                        if (cur1 >= cur0) uni += cur1 - cur0;
+                        cur0 = t0[j];
+                        cur1 = t1[j];
+                    } else {
+                        cur1 = std::max<double>(cur1, t1[j]);
+                    }
+                }
+                if (cur1 >= cur0) uni += cur1 - cur0;
+                ms_set[10] = uni;
+                ms_set[11] = sum;
+                ms_set[12] = c->prof_flops[k] * 1e-9;
+                ms_set[13] = c->prof_flops_bneck[k] * 1e-9;
+            }
+        }
         if (!ok) {
             (void)hipGetLastError();
             ++dropped;
@@ -1065,6 +1137,9 @@ int eamm_profile_read(eamm_ctx* c, double* stage_ms, int nstage, int64_t* calls,
     c->prof_n.clear();
     c->prof_sub.clear();
     c->prof_marks.clear();
+    c->prof_nchain.clear();
+    c->prof_flops.clear();
+    c->prof_flops_bneck.clear();
     for (int i = 0; i < nstage; ++i) stage_ms[i] = c->prof_ms[i];
     if (calls) *calls = c->prof_calls;
     if (frames) *frames = c->prof_frames;
@@ -1388,6 +1463,34 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
     }
     cleanup();
 #undef OP_TRY
+    return EAMM_OK;
+}
+
+int eamm_op_warp(int device, const float* feat, const float* deformation, const float* occlusion, int n, int ns, int hf,
+                 int wf, int C, int h, int w, float* out, int iters, float* avg_ms, void* stream_) {
+    if (!feat || !deformation || !out || n < 1 || (ns != 1 && ns != n) || hf < 1 || wf < 1 || h < 1 || w < 1 || C < 8 || (C & 7))
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_warp: bad argument");
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    auto run = [&]() { return warp_features_launch(feat, deformation, occlusion, n, ns, hf, wf, C, h, w, out, nullptr, nullptr, nullptr, s); };
+    hipError_t e = run();
+    if (e == hipSuccess && iters > 0 && avg_ms) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters && e == hipSuccess; ++i) e = run();
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *avg_ms = ms / iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "eamm_op_warp failed: %s", hipGetErrorString(e));
     return EAMM_OK;
 }
 

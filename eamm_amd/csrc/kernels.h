@@ -12,6 +12,12 @@ constexpr int KP_STRIDE = 8;          // per (frame, keypoint) record: kd.xy, ks
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
 
+// Executed-MFMA accounting for bench.py's roofline: every launcher of a matrix-core kernel adds the multiply-adds its grid
+// really issues (padded tile dimensions, Winograd / polyphase point counts -- not the reference convolution's) x 2 to a
+// per-host-thread counter; eamm_forward_frames folds it into the profile totals while profiling is on.
+void note_mfma_flops(double flops);
+double take_mfma_flops();   // returns the counter and resets it
+
 // One convolution launch. Activations are NHWC fp32; the GEMM view is
 //   M = B*H*W pixels (2x2-quad order), N = Cout, K = taps * (C0 + C1).
 struct ConvArgs {

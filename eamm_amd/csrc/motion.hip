@@ -128,13 +128,16 @@ __global__ __launch_bounds__(256) void motion_front_kernel(const float* __restri
         float r_ = 0.f, g_ = 0.f, b_ = 0.f;
         const bool x0ok = (unsigned)b.x0 < (unsigned)w, x1ok = (unsigned)(b.x0 + 1) < (unsigned)w;
         const bool y0ok = (unsigned)b.y0 < (unsigned)h, y1ok = (unsigned)(b.y0 + 1) < (unsigned)h;
-        // branch-free taps: out-of-range corners read a clamped address with weight 0 (zeros padding, util.py:69-79) --
+        // branch-free taps: out-of-range corners read a clamped address and the loaded VALUE is replaced by zero (zeros
+        // padding, util.py:69-79; zeroing the weight instead would turn a non-finite border pixel into 0 * Inf = NaN) --
         // a bounds branch around each load made the four loads of a key point, and the key points, wait for one another
         const int xa = min(max(b.x0, 0), w - 1), xb = min(max(b.x0 + 1, 0), w - 1);
         const int ya = min(max(b.y0, 0), h - 1) * w, yb = min(max(b.y0 + 1, 0), h - 1) * w;
-        const float4 vnw = src[ya + xa], vne = src[ya + xb], vsw = src[yb + xa], vse = src[yb + xb];
-        const float wnw = (y0ok && x0ok) ? b.wnw : 0.f, wne = (y0ok && x1ok) ? b.wne : 0.f;
-        const float wsw = (y1ok && x0ok) ? b.wsw : 0.f, wse = (y1ok && x1ok) ? b.wse : 0.f;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 lnw = src[ya + xa], lne = src[ya + xb], lsw = src[yb + xa], lse = src[yb + xb];
+        const float4 vnw = (y0ok && x0ok) ? lnw : z4, vne = (y0ok && x1ok) ? lne : z4;
+        const float4 vsw = (y1ok && x0ok) ? lsw : z4, vse = (y1ok && x1ok) ? lse : z4;
+        const float wnw = b.wnw, wne = b.wne, wsw = b.wsw, wse = b.wse;
         r_ = fmaf(vnw.x, wnw, r_); g_ = fmaf(vnw.y, wnw, g_); b_ = fmaf(vnw.z, wnw, b_);
         r_ = fmaf(vne.x, wne, r_); g_ = fmaf(vne.y, wne, g_); b_ = fmaf(vne.z, wne, b_);
         r_ = fmaf(vsw.x, wsw, r_); g_ = fmaf(vsw.y, wsw, g_); b_ = fmaf(vsw.z, wsw, b_);
@@ -323,9 +326,10 @@ __global__ __launch_bounds__(256) void warp_features_kernel(const float* __restr
         const float4* src = reinterpret_cast<const float4*>(feat + (size_t)((ns == 1) ? 0 : f) * hf * wf * C) + c4;
         const bool x0ok = (unsigned)b.x0 < (unsigned)wf, x1ok = (unsigned)(b.x0 + 1) < (unsigned)wf;
         const bool y0ok = (unsigned)b.y0 < (unsigned)hf, y1ok = (unsigned)(b.y0 + 1) < (unsigned)hf;
-        const float wgt[4] = {(y0ok && x0ok) ? b.wnw : 0.f, (y0ok && x1ok) ? b.wne : 0.f, (y1ok && x0ok) ? b.wsw : 0.f,
-                              (y1ok && x1ok) ? b.wse : 0.f};
-        // clamp the corner coordinates so every load is in range; out-of-range corners carry weight 0
+        const float wgt[4] = {b.wnw, b.wne, b.wsw, b.wse};
+        const bool cok[4] = {y0ok && x0ok, y0ok && x1ok, y1ok && x0ok, y1ok && x1ok};
+        // clamp the corner coordinates so every load is in range; the VALUE of an out-of-range corner is replaced by zero
+        // (grid_sample's zeros padding; a zero weight would let a non-finite border value through as 0 * Inf = NaN)
         const int xa = min(max(b.x0, 0), wf - 1), xb = min(max(b.x0 + 1, 0), wf - 1);
         const int ya = min(max(b.y0, 0), hf - 1), yb = min(max(b.y0 + 1, 0), hf - 1);
         const size_t off[4] = {(size_t)(ya * wf + xa) * c4n, (size_t)(ya * wf + xb) * c4n, (size_t)(yb * wf + xa) * c4n,
@@ -335,6 +339,11 @@ __global__ __launch_bounds__(256) void warp_features_kernel(const float* __restr
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[g][k] = src[off[k] + g * half_n];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!cok[k]) v[g][k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -188,7 +188,8 @@ class Engine:
         self.cache_generation += 1
 
     # -- stage timing (HIP events inside the library, on the stream the kernels run on) -----------------
-    STAGES = ("front", "hg_enc", "hg_dec", "head", "warp", "bneck_transform", "bneck_conv", "up", "final", "bneck_gemm_kernel")
+    STAGES = ("front", "hg_enc", "hg_dec", "head", "warp", "bneck_transform", "bneck_conv", "up", "final", "bneck_gemm_kernel",
+              "bneck_union", "bneck_windows", "exec_gflop", "bneck_exec_gflop")   # the last four: chip-level accounting (eamm_hip.h)
 
     def profile(self, on: bool = True):
         _lib.check(self._L.eamm_profile_enable(self._ctx, int(on)), self._ctx)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EAMM_ABI_VERSION 2
+#define EAMM_ABI_VERSION 3
 
 typedef enum eamm_status {
     EAMM_OK = 0,
@@ -249,8 +249,12 @@ const char* eamm_bn_last_error(void);
  * stream's transforms), 7 up blocks, 8 final 7x7 + sigmoid (+ uint8 packing) -- stages 0..8 add up to the call --
  * and 9 the bottleneck GEMM kernels' own durations on the main stream (2 x num_bottleneck_blocks launches per call;
  * with K chains each of those launches covers 1/K of the frames and runs beside the other chains' launches).
+ * Chip-level accounting (all chains, not only the main stream): 10 the wall time during which ANY whole-pass chain is
+ * inside its bottleneck stage (union of the chains' windows, events on every chain's stream), 11 the sum of those
+ * windows, 12 executed matrix-core GFLOP of the recorded calls (what the grids really issue: padded tiles, Winograd /
+ * polyphase point counts), 13 the bottleneck GEMMs' share of 12.  (12 and 13 are GFLOP, not milliseconds.)
  */
-#define EAMM_NSTAGE 10
+#define EAMM_NSTAGE 14
 int eamm_profile_enable(eamm_ctx* ctx, int on);
 int eamm_profile_read(eamm_ctx* ctx, double* stage_ms, int nstage, int64_t* calls, int64_t* frames, int reset);
 
@@ -271,6 +275,14 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
                  const float* weight_host, const float* bias_host, int Cout, int kh, int kw,
                  int act, int pool, const float* resid, int splitk, int tile_n, float* out, int iters,
                  float* avg_ms, void* stream);
+
+/* The HBM-bound kernel of the path on its own: out = grid_sample(feat, deformation, bilinear, zeros, align_corners=False)
+ * * occlusion (reference modules/generator.py:50-57, 79-84).  feat: NHWC [ns,hf,wf,C] (ns = 1 broadcasts one source to
+ * all frames, else ns = n), deformation [n,h,w,2], occlusion [n,h,w] or NULL, out NHWC [n,hf,wf,C]; when (h,w) != (hf,wf)
+ * flow and occlusion are resized bilinearly first (generator.py:52-56, 82-83).  iters > 0 times `iters` back-to-back
+ * launches with HIP events on `stream` (bench.py's isolated roofline_warp figure). */
+int eamm_op_warp(int device, const float* feat, const float* deformation, const float* occlusion, int n, int ns, int hf,
+                 int wf, int C, int h, int w, float* out, int iters, float* avg_ms, void* stream);
 
 #ifdef __cplusplus
 }

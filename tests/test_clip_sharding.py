@@ -105,3 +105,22 @@ def test_two_rank_clip_equals_single_process(tmp_path):
     u8 = np.load(tmp_path / "gathered.npy")
     want = np.clip(np.rint(ref.numpy() * 255), 0, 255).astype(np.uint8).transpose(0, 2, 3, 1)
     assert np.abs(u8.astype(int) - want.astype(int)).max() <= 1
+
+
+def test_bare_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE in the environment (the command shape the driver uses)
+    must become the launcher: two ranks of bench.py under torch.distributed.run that find each other on 127.0.0.1.
+    EAMM_BENCH_RENDEZVOUS_ONLY=1 stops each rank after the rendezvous, before any GPU work (this container has none)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["EAMM_BENCH_RENDEZVOUS_ONLY"] = "1"
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=root,
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d == {"rendezvous": True, "world": 2, "gpus_arg": 2, "rank_sum": 1.0}

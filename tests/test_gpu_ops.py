@@ -192,3 +192,55 @@ def test_conv_linearity_property():
     torch.cuda.synchronize()
     assert torch.equal(outs[0] * 4.0, outs[1])
     assert float(outs[0].abs().max()) > 0.5
+
+
+# ---- the HBM-bound kernel of the path on its own: feature warp x occlusion (reference generator.py:50-57, 79-84) -------
+def _warp_case(n, ns, hf, wf, C, h, w, occ=True, seed=0, poison=False):
+    g = torch.Generator().manual_seed(seed)
+    feat = torch.randn(ns, C, hf, wf, generator=g)
+    if poison:   # a non-finite BORDER value must not leak into samples whose out-of-range corner is zero padding
+        feat[:, :, 0, 0] = float("inf")
+    ident = torch.stack(torch.meshgrid(torch.linspace(-1, 1, h), torch.linspace(-1, 1, w), indexing="ij")[::-1], -1)
+    defo = ident[None] + 0.3 * torch.randn(n, h, w, 2, generator=g)          # some samples fall outside the map
+    if poison:
+        defo[:, 0, 0] = torch.tensor([-1.0 - 1.5 / wf, -1.0 - 1.5 / hf])    # top-left sample: every corner out of range -> exactly 0
+    om = torch.rand(n, 1, h, w, generator=g) if occ else None
+    src = feat if ns == n else feat.expand(n, -1, -1, -1)
+    d, o = defo, om
+    if (h, w) != (hf, wf):    # generator.py:52-56, 82-83
+        d = F.interpolate(defo.permute(0, 3, 1, 2), size=(hf, wf), mode="bilinear").permute(0, 2, 3, 1)
+        o = F.interpolate(om, size=(hf, wf), mode="bilinear") if occ else None
+    want = F.grid_sample(src, d, mode="bilinear", padding_mode="zeros", align_corners=False)
+    if occ:
+        want = want * o
+    dev = torch.device("cuda:0")
+    f_d, d_d = nhwc(feat).to(dev), defo.contiguous().to(dev)
+    o_d = om[:, 0].contiguous().to(dev) if occ else None
+    out = torch.full((n, hf, wf, C), float("nan"), device=dev)
+    rc = _lib.lib().eamm_op_warp(0, f_d.data_ptr(), d_d.data_ptr(), o_d.data_ptr() if occ else None, n, ns, hf, wf, C, h, w,
+                                 out.data_ptr(), 0, None, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, None)
+    return out.cpu().permute(0, 3, 1, 2), want
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("one_source", dict(n=3, ns=1, hf=16, wf=16, C=64, h=16, w=16)),
+    ("per_frame_source", dict(n=2, ns=2, hf=12, wf=20, C=32, h=12, w=20, seed=1)),
+    ("no_occlusion", dict(n=2, ns=1, hf=16, wf=16, C=256, h=16, w=16, occ=False, seed=2)),
+    ("resized_flow", dict(n=2, ns=1, hf=32, wf=32, C=64, h=16, w=16, seed=3)),
+])
+def test_warp_features_matches_grid_sample(name, kw):
+    got, want = _warp_case(**kw)
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    print(f"warp {name}: max|hip - grid_sample| = {err:.2e}")
+    assert err <= 2e-5 * max(1.0, float(want.abs().max())), (name, err)
+
+
+def test_warp_zero_padding_is_exact_beside_a_non_finite_border_pixel():
+    """a clamped out-of-range corner with weight 0 would give 0 * inf = NaN; grid_sample's zeros padding gives 0."""
+    got, want = _warp_case(n=1, ns=1, hf=8, wf=8, C=32, h=8, w=8, occ=False, seed=5, poison=True)
+    assert float(got[0, :, 0, 0].abs().max()) == 0.0 and float(want[0, :, 0, 0].abs().max()) == 0.0
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(got), fin)
+    assert float((got[fin] - want[fin]).abs().max()) <= 2e-5 * max(1.0, float(want[fin].abs().max()))
