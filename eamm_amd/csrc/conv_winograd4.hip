@@ -319,6 +319,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
         }
     };
 
+    // (round 3: computing the column of A^T with scalar selects on j instead of these four s_loads measured SLOWER, 3826 -> 3785
+    // frames/s: hipcc issues the loads ahead of the interval's last MFMAs, the select chain sits in the gap)
     auto fold_x = [&](int j) {   // Z[q] += A^T[q][j] * M_ij
         const float c0 = WINO4_AT[0][j], c1 = WINO4_AT[1][j], c2 = WINO4_AT[2][j], c3 = WINO4_AT[3][j];
         static_for<NT>([&](auto jc) {
