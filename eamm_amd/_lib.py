@@ -91,7 +91,13 @@ SIGNATURES = {
     "eamm_bn_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "eamm_bn_local_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eamm_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eamm_bn_backward_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "eamm_bn_backward_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eamm_bn_backward_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p]),
     "eamm_bn_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                 C.c_void_p]),
     "eamm_bn_last_error": (C.c_char_p, []),

@@ -1,6 +1,6 @@
-// Training-mode BatchNorm2d forward on NCHW fp32 tensors -- SURVEY.md section 8f row N4, first slice (forward and
-// running statistics; no backward).  Reference: sync_batchnorm/batchnorm.py:46-125 (`_SynchronizedBatchNorm.forward`:
-// per-channel sum and sum of squares -> reduce over the replicas -> mean / inverse standard deviation + running
+// Training-mode BatchNorm2d on NCHW fp32 tensors -- SURVEY.md section 8f row N4: forward with running statistics (first
+// slice, round 2) and backward (round 3: bn_bwd_* below, the standard synchronised-BatchNorm gradient).
+// Reference: sync_batchnorm/batchnorm.py:46-125 (`_SynchronizedBatchNorm.forward`: per-channel sum and sum of squares -> reduce over the replicas -> mean / inverse standard deviation + running
 // statistics on the master (`_compute_mean_std`) -> (x - mean) * (inv_std * weight) + bias).
 //
 // Four HBM-bound kernels; the all-reduce of the 2C (+2) per-channel sums sits between the second and the third and is
@@ -101,13 +101,15 @@ __global__ void bn_combine_kernel(const double* __restrict__ partial, int C, int
 // mode 2: evaluation: running statistics, nothing updated
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float eps, float momentum, int mode,
                                    const float* __restrict__ weight, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ mean_out, float* __restrict__ scale_out) {
+                                   float* __restrict__ running_var, float* __restrict__ mean_out, float* __restrict__ scale_out,
+                                   float* __restrict__ inv_std_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float w = weight != nullptr ? weight[c] : 1.f;
     if (mode == 2) {
         mean_out[c] = running_mean[c];
         scale_out[c] = w / sqrtf(running_var[c] + eps);
+        if (inv_std_out) inv_std_out[c] = 1.f / sqrtf(running_var[c] + eps);
         return;
     }
     const float size = sums[2 * C] + 4096.f * sums[2 * C + 1];
@@ -131,6 +133,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float 
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbias_var;
     mean_out[c] = mean;
     scale_out[c] = inv_std * w;
+    if (inv_std_out) inv_std_out[c] = inv_std;
 }
 
 // y = (x - mean[c]) * scale[c] + bias[c]     (batchnorm.py:74-79); grid (N*C planes, slices)
@@ -150,6 +153,109 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float* __res
             reinterpret_cast<float4*>(dst)[i] = v;
         } else {
             dst[i] = fmaf(src[i] - m, s, b);
+        }
+    }
+}
+
+// ---- backward (round 3) ------------------------------------------------------------------------------------
+// With xhat = (x - mean) * inv_std and y = xhat * weight + bias over the N_total elements per channel of ALL replicas
+// (reference: autograd through sync_batchnorm/batchnorm.py:61-79, 110-125, whose ReduceAddCoalesced / Broadcast carry the
+// gradient across the replicas):
+//   dbias = sum dy,  dweight = sum dy * xhat                      (this replica's shard; the replicas' sums are the caller's)
+//   dx = weight * inv_std * (dy - S1 / N_total - xhat * S2 / N_total),  S1 = sum_all dy,  S2 = sum_all dy * xhat
+// -- the same expression for both forms of inv_std ((var + eps)^-1/2 and clamp(var, eps)^-1/2: d inv_std / d var =
+// -inv_std^3 / 2 in both), except that a CLAMPED channel (replicas' form, var <= eps) has no gradient through the variance.
+// bn_bwd_partial_kernel: (sum dy, sum dy * (x - mean)) per (channel, slice), double accumulators -- the forward's layout, so
+// bn_combine_kernel packs them the same way (2C floats + count for the all-reduce, 2C doubles behind).
+template <int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     const float* __restrict__ mean, int N, int C, int HW, int S,
+                                                                     int R, double* __restrict__ partial) {
+    const int c = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
+    const int per = (HW / VEC + R - 1) / R;
+    const int lo = r * per, hi = min(HW / VEC, lo + per);
+    const float m = mean[c];
+    double sa = 0.0, sb = 0.0;
+    for (int n = s; n < N; n += S) {
+        const size_t base = ((size_t)n * C + c) * HW;
+        for (int i = lo + threadIdx.x; i < hi; i += BN_THREADS) {
+            if constexpr (VEC == 4) {
+                const float4 v = reinterpret_cast<const float4*>(x + base)[i];
+                const float4 g = reinterpret_cast<const float4*>(dy + base)[i];
+                sa += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
+                sb += ((double)g.x * (v.x - m) + (double)g.y * (v.y - m)) + ((double)g.z * (v.z - m) + (double)g.w * (v.w - m));
+            } else {
+                const float g = dy[base + i];
+                sa += (double)g;
+                sb += (double)g * (x[base + i] - m);
+            }
+        }
+    }
+    __shared__ double red[2][BN_THREADS / 64];
+    sa = wave_sum(sa);
+    sb = wave_sum(sb);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sa;
+        red[1][threadIdx.x >> 6] = sb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < BN_THREADS / 64; ++w) {
+            a += red[0][w];
+            b += red[1][w];
+        }
+        double* dst = partial + ((size_t)c * (S * R) + (s * R + r)) * 2;
+        dst[0] = a;
+        dst[1] = b;
+    }
+}
+
+// local: this replica's packed sums (dweight / dbias); reduced: the same buffer after the caller's all-reduce of its first
+// 2C + 2 floats (may be the same pointer on one replica).  coef[c], coef[C + c], coef[2C + c] = S1 / N, S2 * inv_std^2 / N,
+// weight * inv_std for bn_bwd_apply_kernel.  mode as in bn_finalize_kernel (2 = evaluation: statistics are constants).
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ local, const float* __restrict__ reduced, int C,
+                                       const float* __restrict__ inv_std, const float* __restrict__ weight, float eps, int mode,
+                                       float* __restrict__ dweight, float* __restrict__ dbias, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double* lex = reinterpret_cast<const double*>(local + 2 * C + 2);
+    const double is = (double)inv_std[c];
+    if (dbias) dbias[c] = (float)lex[c];
+    if (dweight) dweight[c] = (float)(lex[C + c] * is);
+    const float w = weight != nullptr ? weight[c] : 1.f;
+    double a = 0.0, b = 0.0;
+    if (mode != 2) {
+        const double size = (double)reduced[2 * C] + 4096.0 * (double)reduced[2 * C + 1];
+        // one replica: the double totals (nothing was exchanged); several: the all-reduced floats, as the forward does
+        const double* rex = reinterpret_cast<const double*>(reduced + 2 * C + 2);
+        const double s1 = mode == 1 ? rex[c] : (double)reduced[c], s2 = mode == 1 ? rex[C + c] : (double)reduced[C + c];
+        const bool clamped = mode == 0 && inv_std[c] >= powf(eps, -0.5f);   // clamp(var, eps): no gradient through the variance
+        a = s1 / size;
+        b = clamped ? 0.0 : s2 * is * is / size;
+    }
+    coef[c] = (float)a;
+    coef[C + c] = (float)b;
+    coef[2 * C + c] = (float)(is * (double)w);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   const float* __restrict__ mean, const float* __restrict__ coef,
+                                                                   int C, int HW, float* __restrict__ dx) {
+    const int plane = blockIdx.x, c = plane % C;
+    const float m = mean[c], a = coef[c], b = coef[C + c], sc = coef[2 * C + c];
+    const size_t base = (size_t)plane * HW;
+    for (int i = blockIdx.y * BN_THREADS + threadIdx.x; i < HW / VEC; i += gridDim.y * BN_THREADS) {
+        if constexpr (VEC == 4) {
+            const float4 v = reinterpret_cast<const float4*>(x + base)[i];
+            float4 g = reinterpret_cast<const float4*>(dy + base)[i];
+            g.x = sc * (g.x - a - (v.x - m) * b); g.y = sc * (g.y - a - (v.y - m) * b);
+            g.z = sc * (g.z - a - (v.z - m) * b); g.w = sc * (g.w - a - (v.w - m) * b);
+            reinterpret_cast<float4*>(dx + base)[i] = g;
+        } else {
+            dx[base + i] = sc * (dy[base + i] - a - (x[base + i] - m) * b);
         }
     }
 }
@@ -183,9 +289,9 @@ hipError_t bn_local_sums_launch(const float* x, int N, int C, int HW, float* sum
 }
 
 hipError_t bn_finalize_launch(const float* sums, int C, float eps, float momentum, int mode, const float* weight,
-                              float* running_mean, float* running_var, float* mean, float* scale, hipStream_t s) {
+                              float* running_mean, float* running_var, float* mean, float* scale, float* inv_std, hipStream_t s) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, eps, momentum, mode, weight,
-                       running_mean, running_var, mean, scale);
+                       running_mean, running_var, mean, scale, inv_std);
     return hipGetLastError();
 }
 
@@ -198,6 +304,40 @@ hipError_t bn_apply_launch(const float* x, const float* mean, const float* scale
         hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(N * C, slices), dim3(BN_THREADS), 0, s, x, mean, scale, bias, C, HW, y);
     else
         hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(N * C, slices), dim3(BN_THREADS), 0, s, x, mean, scale, bias, C, HW, y);
+    return hipGetLastError();
+}
+
+hipError_t bn_bwd_sums_launch(const float* x, const float* dy, const float* mean, int N, int C, int HW, float* sums, float* workspace,
+                              hipStream_t s) {
+    int S, R;
+    bn_plan(N, C, HW, &S, &R);
+    const bool vec = (HW % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0);
+    double* part = reinterpret_cast<double*>(workspace);
+    if (vec)
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<4>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, dy, mean, N, C, HW, S, R, part);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<1>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, dy, mean, N, C, HW, S, R, part);
+    hipLaunchKernelGGL(bn_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, C, S * R, (long long)N * HW, sums);
+    return hipGetLastError();
+}
+
+hipError_t bn_bwd_finalize_launch(const float* local, const float* reduced, int C, const float* inv_std, const float* weight, float eps,
+                                  int mode, float* dweight, float* dbias, float* coef, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, local, reduced, C, inv_std, weight, eps, mode,
+                       dweight, dbias, coef);
+    return hipGetLastError();
+}
+
+hipError_t bn_bwd_apply_launch(const float* x, const float* dy, const float* mean, const float* coef, int N, int C, int HW, float* dx,
+                               hipStream_t s) {
+    const bool vec = (HW % 4 == 0) &&
+                     (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+    const int per = vec ? HW / 4 : HW;
+    const int slices = std::max(1, std::min(64, (per + 4 * BN_THREADS - 1) / (4 * BN_THREADS)));
+    if (vec)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(N * C, slices), dim3(BN_THREADS), 0, s, x, dy, mean, coef, C, HW, dx);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(N * C, slices), dim3(BN_THREADS), 0, s, x, dy, mean, coef, C, HW, dx);
     return hipGetLastError();
 }
 

@@ -1,4 +1,4 @@
-// C ABI of the training-mode BatchNorm forward (include/eamm_hip.h, "N4, first slice"; kernels in batchnorm.hip).
+// C ABI of the training-mode BatchNorm forward and backward (include/eamm_hip.h, row N4; kernels in batchnorm.hip).
 // Stateless: the caller owns every buffer and selects the device; errors are reported per thread.
 #include "../../include/eamm_hip.h"
 #include "kernels.h"
@@ -44,11 +44,11 @@ int eamm_bn_local_sums(const float* x, int N, int C, int HW, float* sums, float*
 }
 
 int eamm_bn_finalize(const float* sums, int C, float eps, float momentum, int mode, const float* weight, float* running_mean,
-                     float* running_var, float* mean, float* scale, void* stream) {
+                     float* running_var, float* mean, float* scale, float* inv_std, void* stream) {
     if (!running_mean || !running_var || !mean || !scale || (mode != EAMM_BN_EVAL && !sums))
         return bn_fail(EAMM_ERR_ARG, "null argument");
     if (C < 1 || mode < 0 || mode > 2) return bn_fail(EAMM_ERR_ARG, "bad channel count or mode");
-    return bn_check(bn_finalize_launch(sums, C, eps, momentum, mode, weight, running_mean, running_var, mean, scale,
+    return bn_check(bn_finalize_launch(sums, C, eps, momentum, mode, weight, running_mean, running_var, mean, scale, inv_std,
                                        reinterpret_cast<hipStream_t>(stream)), "bn_finalize");
 }
 
@@ -57,6 +57,29 @@ int eamm_bn_apply(const float* x, const float* mean, const float* scale, const f
     if (!x || !mean || !scale || !y) return bn_fail(EAMM_ERR_ARG, "null argument");
     if (N < 1 || C < 1 || HW < 1) return bn_fail(EAMM_ERR_ARG, "empty tensor [%d,%d,%d]", N, C, HW);
     return bn_check(bn_apply_launch(x, mean, scale, bias, N, C, HW, y, reinterpret_cast<hipStream_t>(stream)), "bn_apply");
+}
+
+int eamm_bn_backward_sums(const float* x, const float* dy, const float* mean, int N, int C, int HW, float* sums, float* workspace,
+                          void* stream) {
+    if (!x || !dy || !mean || !sums || !workspace) return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (N < 1 || C < 1 || HW < 1) return bn_fail(EAMM_ERR_ARG, "empty tensor [%d,%d,%d]", N, C, HW);
+    if ((long long)N * HW >= (1ll << 36)) return bn_fail(EAMM_ERR_ARG, "more than 2^36 elements per channel");
+    return bn_check(bn_bwd_sums_launch(x, dy, mean, N, C, HW, sums, workspace, reinterpret_cast<hipStream_t>(stream)), "bn_backward_sums");
+}
+
+int eamm_bn_backward_finalize(const float* local_sums, const float* reduced_sums, int C, const float* inv_std, const float* weight,
+                              float eps, int mode, float* dweight, float* dbias, float* coef, void* stream) {
+    if (!local_sums || !reduced_sums || !inv_std || !coef) return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (C < 1 || mode < 0 || mode > 2) return bn_fail(EAMM_ERR_ARG, "bad channel count or mode");
+    return bn_check(bn_bwd_finalize_launch(local_sums, reduced_sums, C, inv_std, weight, eps, mode, dweight, dbias, coef,
+                                           reinterpret_cast<hipStream_t>(stream)), "bn_backward_finalize");
+}
+
+int eamm_bn_backward_apply(const float* x, const float* dy, const float* mean, const float* coef, int N, int C, int HW, float* dx,
+                           void* stream) {
+    if (!x || !dy || !mean || !coef || !dx) return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (N < 1 || C < 1 || HW < 1) return bn_fail(EAMM_ERR_ARG, "empty tensor [%d,%d,%d]", N, C, HW);
+    return bn_check(bn_bwd_apply_launch(x, dy, mean, coef, N, C, HW, dx, reinterpret_cast<hipStream_t>(stream)), "bn_backward_apply");
 }
 
 }  // extern "C"

@@ -189,7 +189,15 @@ size_t bn_workspace_floats(int N, int C, int HW);
 hipError_t bn_local_sums_launch(const float* x /*[N,C,HW]*/, int N, int C, int HW, float* sums /*[6C+2]*/, float* workspace,
                                 hipStream_t s);
 hipError_t bn_finalize_launch(const float* sums, int C, float eps, float momentum, int mode, const float* weight,
-                              float* running_mean, float* running_var, float* mean, float* scale, hipStream_t s);
+                              float* running_mean, float* running_var, float* mean, float* scale, float* inv_std /*[C] or null*/,
+                              hipStream_t s);
+// backward (round 3): sums in the forward's packed layout [6C+2]; coef [3C] = S1/N, S2*inv_std^2/N, weight*inv_std
+hipError_t bn_bwd_sums_launch(const float* x, const float* dy, const float* mean, int N, int C, int HW, float* sums, float* workspace,
+                              hipStream_t s);
+hipError_t bn_bwd_finalize_launch(const float* local, const float* reduced, int C, const float* inv_std, const float* weight, float eps,
+                                  int mode, float* dweight, float* dbias, float* coef, hipStream_t s);
+hipError_t bn_bwd_apply_launch(const float* x, const float* dy, const float* mean, const float* coef, int N, int C, int HW, float* dx,
+                               hipStream_t s);
 hipError_t bn_apply_launch(const float* x, const float* mean, const float* scale, const float* bias, int N, int C, int HW,
                            float* y, hipStream_t s);
 hipError_t to_u8_launch(const float* pred /*[n,3,H,W]*/, int n, int H, int W, uint8_t* out /*[n,H,W,3]*/,

@@ -1,6 +1,7 @@
-"""Drop-in ``SynchronizedBatchNorm2d`` whose forward runs in libeamm_hip.so -- SURVEY.md section 8f row N4, FIRST SLICE:
-the training-mode forward (batch statistics, cross-replica reduction, running-statistics update) and the evaluation
-forward.  The backward pass is not built: outputs carry no autograd graph.
+"""Drop-in ``SynchronizedBatchNorm2d`` whose forward AND backward run in libeamm_hip.so -- SURVEY.md section 8f row N4:
+the training-mode forward (batch statistics, cross-replica reduction, running-statistics update), the evaluation forward,
+and (round 3) the gradient of both as a ``torch.autograd.Function`` -- the output is differentiable with respect to the
+input, ``weight`` and ``bias`` exactly as the reference module's is.
 
 Mirrors reference sync_batchnorm/batchnorm.py:38-125 (``_SynchronizedBatchNorm``): same constructor, same parameter and
 buffer names (it IS a ``torch.nn.modules.batchnorm._BatchNorm``), same three behaviours --
@@ -63,12 +64,48 @@ class HipBatchNormOps:
         c, dev = mod.num_features, mod.running_mean.device
         mean = torch.empty(c, dtype=torch.float32, device=dev)
         scale = torch.empty(c, dtype=torch.float32, device=dev)
+        inv_std = torch.empty(c, dtype=torch.float32, device=dev)
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         with torch.cuda.device(dev):
             _check(_lib.lib().eamm_bn_finalize(ptr(sums), c, float(mod.eps), float(mod.momentum), mode, ptr(mod.weight),
-                                               ptr(mod.running_mean), ptr(mod.running_var), ptr(mean), ptr(scale),
+                                               ptr(mod.running_mean), ptr(mod.running_var), ptr(mean), ptr(scale), ptr(inv_std),
                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        return mean, scale
+        return mean, scale, inv_std
+
+    # ---- backward: eamm_bn_backward_sums / _finalize / _apply ------------------------------------------------------
+    def backward_sums(self, x: torch.Tensor, dy: torch.Tensor, mean: torch.Tensor) -> torch.Tensor:
+        n, c = x.shape[0], x.shape[1]
+        hw = x.numel() // (n * c)
+        L = _lib.lib()
+        sums = torch.empty(6 * c + 2, dtype=torch.float32, device=x.device)
+        work = torch.empty(max(1, L.eamm_bn_workspace_floats(n, c, hw)), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _check(L.eamm_bn_backward_sums(C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), C.c_void_p(mean.data_ptr()), n, c, hw,
+                                           C.c_void_p(sums.data_ptr()), C.c_void_p(work.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return sums
+
+    def backward_finalize(self, local: torch.Tensor, reduced: torch.Tensor, inv_std: torch.Tensor, weight: Optional[torch.Tensor],
+                          eps: float, mode: int, want_wb: bool):
+        c = inv_std.numel()
+        coef = torch.empty(3 * c, dtype=torch.float32, device=inv_std.device)
+        dw = torch.empty(c, dtype=torch.float32, device=inv_std.device) if want_wb else None
+        db = torch.empty(c, dtype=torch.float32, device=inv_std.device) if want_wb else None
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        with torch.cuda.device(inv_std.device):
+            _check(_lib.lib().eamm_bn_backward_finalize(ptr(local), ptr(reduced), c, ptr(inv_std), ptr(weight), float(eps), mode,
+                                                        ptr(dw), ptr(db), ptr(coef), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return coef, dw, db
+
+    def backward_apply(self, x: torch.Tensor, dy: torch.Tensor, mean: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
+        n, c = x.shape[0], x.shape[1]
+        hw = x.numel() // (n * c)
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _check(_lib.lib().eamm_bn_backward_apply(C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), C.c_void_p(mean.data_ptr()),
+                                                     C.c_void_p(coef.data_ptr()), n, c, hw, C.c_void_p(dx.data_ptr()),
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return dx
 
     def apply(self, x: torch.Tensor, mean: torch.Tensor, scale: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
         n, c = x.shape[0], x.shape[1]
@@ -81,8 +118,53 @@ class HipBatchNormOps:
         return y
 
 
+class _BatchNormFunction(torch.autograd.Function):
+    """y = BatchNorm(x) with the statistics chosen by the module's state; forward and backward are the library's kernels.
+
+    The gradient is the one autograd derives from the reference's forward (sync_batchnorm/batchnorm.py:61-79, 110-125), whose
+    ReduceAddCoalesced / Broadcast carry it across the replicas: dx needs sum dy and sum dy * xhat over ALL replicas -- one
+    all-reduce of 2C + 2 floats, like the forward's -- while dweight / dbias are this replica's sums (the reference adds the
+    replicas' parameter gradients on the DataParallel master; with one process per replica that addition is the
+    gradient all-reduce of DistributedDataParallel or of the training loop)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mod):
+        ops = mod._ops
+        if not mod.training:                                            # batchnorm.py:48-53, eval branch
+            mode = BN_EVAL
+            mean, scale, inv_std = ops.finalize(None, mod, BN_EVAL)
+        else:
+            world = mod._replicas()
+            parallel = world > 1 if mod.sync is None else bool(mod.sync)
+            sums = ops.local_sums(x)                                     # batchnorm.py:61-64
+            if world > 1 and parallel:                                   # batchnorm.py:66-70, 102-105
+                mod._all_reduce(sums[:2 * mod.num_features + 2])
+            mode = BN_SYNC if parallel else BN_SINGLE
+            mean, scale, inv_std = ops.finalize(sums, mod, mode)         # batchnorm.py:110-125
+        y = ops.apply(x, mean, scale, bias)                              # batchnorm.py:72-79
+        ctx.mod, ctx.mode = mod, mode
+        ctx.reduce = mode == BN_SYNC and mod._replicas() > 1
+        ctx.save_for_backward(x, mean, inv_std, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, inv_std, weight = ctx.saved_tensors
+        mod, ops = ctx.mod, ctx.mod._ops
+        dy = dy.contiguous()
+        local = ops.backward_sums(x, dy, mean)
+        reduced = local
+        if ctx.reduce:
+            reduced = local.clone()
+            mod._all_reduce(reduced[:2 * mod.num_features + 2])
+        want_wb = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        coef, dw, db = ops.backward_finalize(local, reduced, inv_std, weight, mod.eps, ctx.mode, want_wb)
+        dx = ops.backward_apply(x, dy, mean, coef) if ctx.needs_input_grad[0] else None
+        return dx, (dw if ctx.needs_input_grad[1] else None), (db if ctx.needs_input_grad[2] else None), None
+
+
 class SynchronizedBatchNorm2d(_BatchNorm):
-    """MI355X-native stand-in for reference sync_batchnorm/batchnorm.py:SynchronizedBatchNorm2d (forward only).
+    """MI355X-native stand-in for reference sync_batchnorm/batchnorm.py:SynchronizedBatchNorm2d (forward and backward).
 
     ``process_group``: the replicas (default: the world group when ``torch.distributed`` is initialised with more than one
     rank -- the analogue of the reference's ``_is_parallel`` flag, set when ``DataParallel`` replicates the module).
@@ -106,23 +188,12 @@ class SynchronizedBatchNorm2d(_BatchNorm):
             return dist.get_world_size(self.process_group)
         return 1
 
-    @torch.no_grad()
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         self._check_input_dim(input)
         if input.shape[1] != self.num_features:
             raise RuntimeError(f"expected {self.num_features} channels, got {input.shape[1]}")
         self._check_device(input)
-        x = input.contiguous()
-        if not self.training:                                            # batchnorm.py:48-53, eval branch
-            mean, scale = self._ops.finalize(None, self, BN_EVAL)
-            return self._ops.apply(x, mean, scale, self.bias)
-        world = self._replicas()
-        parallel = world > 1 if self.sync is None else bool(self.sync)
-        sums = self._ops.local_sums(x)                                   # batchnorm.py:61-64
-        if world > 1 and parallel:                                       # batchnorm.py:66-70, 102-105
-            self._all_reduce(sums[:2 * self.num_features + 2])
-        mean, scale = self._ops.finalize(sums, self, BN_SYNC if parallel else BN_SINGLE)   # batchnorm.py:110-125
-        return self._ops.apply(x, mean, scale, self.bias)                # batchnorm.py:72-79
+        return _BatchNormFunction.apply(input.contiguous(), self.weight, self.bias, self)
 
     def _check_device(self, input: torch.Tensor):
         self._ops.check(input, self)

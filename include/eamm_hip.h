@@ -211,7 +211,7 @@ int eamm_deconv_finalize_weights(eamm_deconv_ctx* ctx);
 int eamm_deconv_forward(eamm_deconv_ctx* ctx, const float* x, int B, float* out, void* stream);
 
 /*
- * ---- N4, first slice: training-mode BatchNorm forward ------------------------------------------------------
+ * ---- N4: training-mode BatchNorm, forward (round 2) and backward (round 3) --------------------------------------
  * Replaces the arithmetic of _SynchronizedBatchNorm.forward (reference sync_batchnorm/batchnorm.py:46-125) on NCHW
  * float32 device tensors; the reduction over replicas (ReduceAddCoalesced / Broadcast, batchnorm.py:102-105) is the
  * caller's all-reduce of `sums` between eamm_bn_local_sums and eamm_bn_finalize (torch.distributed / RCCL).
@@ -226,7 +226,17 @@ int eamm_deconv_forward(eamm_deconv_ctx* ctx, const float* x, int B, float* out,
  *                        inv_std = clamp(biased var, eps)^-0.5; EAMM_BN_SINGLE: F.batch_norm(training=True)
  *                        (batchnorm.py:48-53), inv_std = 1/sqrt(biased var + eps); EAMM_BN_EVAL: running statistics,
  *                        nothing updated (sums may be NULL).  weight may be NULL (affine=False).
+ *                        inv_std (optional, [C]): the inverse standard deviation alone -- what the backward needs.
  *   eamm_bn_apply        y = (x - mean[c]) * scale[c] + bias[c] (batchnorm.py:74-79); bias may be NULL.
+ * Backward (round 3) -- the gradient autograd derives from those lines, with xhat = (x - mean) * inv_std:
+ *   eamm_bn_backward_sums      sums[c] = sum dy, sums[C + c] = sum dy * (x - mean[c]) over this replica's shard, packed like
+ *                              eamm_bn_local_sums' output (6C+2 floats): all-reduce the first 2C+2 floats INTO A COPY --
+ *   eamm_bn_backward_finalize  takes both: dbias = local sum dy, dweight = local sum dy * xhat (this replica's shard; the
+ *                              reduction of parameter gradients over replicas is the caller's, as under DistributedDataParallel),
+ *                              and coef[3C] = (S1 / N, S2 * inv_std^2 / N, weight * inv_std) from the REDUCED sums (all replicas);
+ *                              mode as eamm_bn_finalize (EAMM_BN_EVAL: statistics are constants, S-terms vanish; EAMM_BN_SYNC: a
+ *                              channel whose variance was clamped to eps has no gradient through the variance).
+ *   eamm_bn_backward_apply     dx = coef_s * (dy - coef_a - (x - mean) * coef_b).
  */
 #define EAMM_BN_SYNC 0
 #define EAMM_BN_SINGLE 1
@@ -234,7 +244,15 @@ int eamm_deconv_forward(eamm_deconv_ctx* ctx, const float* x, int B, float* out,
 size_t eamm_bn_workspace_floats(int N, int C, int HW);
 int eamm_bn_local_sums(const float* x, int N, int C, int HW, float* sums /*[6C+2]*/, float* workspace, void* stream);
 int eamm_bn_finalize(const float* sums, int C, float eps, float momentum, int mode, const float* weight,
-                     float* running_mean, float* running_var, float* mean /*[C]*/, float* scale /*[C]*/, void* stream);
+                     float* running_mean, float* running_var, float* mean /*[C]*/, float* scale /*[C]*/, float* inv_std /*[C] or NULL*/,
+                     void* stream);
+int eamm_bn_backward_sums(const float* x, const float* dy, const float* mean, int N, int C, int HW, float* sums /*[6C+2]*/,
+                          float* workspace, void* stream);
+int eamm_bn_backward_finalize(const float* local_sums, const float* reduced_sums, int C, const float* inv_std, const float* weight,
+                              float eps, int mode, float* dweight /*[C] or NULL*/, float* dbias /*[C] or NULL*/, float* coef /*[3C]*/,
+                              void* stream);
+int eamm_bn_backward_apply(const float* x, const float* dy, const float* mean, const float* coef, int N, int C, int HW, float* dx,
+                           void* stream);
 int eamm_bn_apply(const float* x, const float* mean, const float* scale, const float* bias, int N, int C, int HW, float* y,
                   void* stream);
 const char* eamm_bn_last_error(void);

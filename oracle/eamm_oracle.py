@@ -279,8 +279,10 @@ def sync_batchnorm_forward(shards, weight, bias, running_mean, running_var, eps=
     rv = (1 - momentum) * rv + momentum * unbias_var
     inv_std = bias_var.clamp(eps) ** -0.5
     outs = []
-    for x, v in zip(shards, flat):
-        if weight is not None:
+    for r, (x, v) in enumerate(zip(shards, flat)):
+        if isinstance(weight, (list, tuple)):   # one parameter copy per replica (DataParallel's broadcast copies): their
+            o = (v - mean[None, :, None]) * (inv_std * weight[r])[None, :, None] + bias[r][None, :, None]   # gradients stay apart
+        elif weight is not None:
             o = (v - mean[None, :, None]) * (inv_std * weight)[None, :, None] + bias[None, :, None]
         else:
             o = (v - mean[None, :, None]) * inv_std[None, :, None]

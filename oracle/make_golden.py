@@ -325,7 +325,7 @@ def deconv_tail_case():
 
 
 def batchnorm_case():
-    """Fixture for the training-mode BatchNorm forward (N4, first slice): the reference's own SynchronizedBatchNorm2d
+    """Fixture for the training-mode BatchNorm forward and backward (N4): the reference's own SynchronizedBatchNorm2d
     (sync_batchnorm/batchnorm.py) -- evaluation, training on one replica (F.batch_norm branch), and training on two
     replicas with UNEQUAL shards.  The two-replica case runs the reference's real protocol: a master and a slave copy
     registered through __data_parallel_replicate__, the two forwards on two threads talking through SyncMaster; only the
@@ -391,6 +391,58 @@ def batchnorm_case():
         d = float((torch.cat(o, 0) - torch.from_numpy(blob["sync_out"])).abs().max())
         assert d == 0.0 and torch.equal(rm, torch.from_numpy(blob["sync_running_mean"])) and torch.equal(rv, torch.from_numpy(blob["sync_running_var"])), d
     assert float(np.abs(blob["sync_out"] - blob["single_out"]).max()) < 1e-4   # same statistics, two formulas for inv_std
+    # ---- backward (round 3): the reference modules under autograd with a fixed upstream gradient dy -- evaluation, one
+    # replica, two replicas (the gradient crosses the replicas through the add / copy that stand for ReduceAddCoalesced /
+    # Broadcast, exactly as it does through the CUDA originals); parameter gradients are each replica's own
+    dy = torch.from_numpy(rs.standard_normal(x.shape).astype(np.float32))
+    blob["dy"] = dy.numpy()
+
+    def grads(m, xin, g):
+        xin = xin.clone().requires_grad_(True)
+        m.zero_grad()
+        m(xin).backward(g)
+        return xin.grad.numpy().copy(), m.weight.grad.numpy().copy(), m.bias.grad.numpy().copy()
+
+    blob["eval_dx"], blob["eval_dw"], blob["eval_db"] = grads(fresh().eval(), x, dy)
+    blob["single_dx"], blob["single_dw"], blob["single_db"] = grads(fresh().train(), x, dy)
+    master = fresh().train()
+    slave = copy.deepcopy(master)
+    ctx = CallbackContext()
+    master.__data_parallel_replicate__(ctx, 0)
+    slave.__data_parallel_replicate__(ctx, 1)
+    xs = [x[:4].clone().requires_grad_(True), x[4:].clone().requires_grad_(True)]
+    outs = [None, None]
+
+    def run_grad(i, mod, inp):
+        with torch.enable_grad():
+            outs[i] = mod(inp)
+
+    threads = [threading.Thread(target=run_grad, args=(0, master, xs[0])), threading.Thread(target=run_grad, args=(1, slave, xs[1]))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    ((outs[0] * dy[:4]).sum() + (outs[1] * dy[4:]).sum()).backward()
+    blob["sync_dx"] = torch.cat([xs[0].grad, xs[1].grad], 0).numpy()
+    blob["sync_dw0"], blob["sync_db0"] = master.weight.grad.numpy().copy(), master.bias.grad.numpy().copy()
+    blob["sync_dw1"], blob["sync_db1"] = slave.weight.grad.numpy().copy(), slave.bias.grad.numpy().copy()
+    # the oracle under autograd must give the same gradients
+    for key, shards, training in (("eval", [x], False), ("single", [x], True), ("sync", [x[:4], x[4:]], True)):
+        ws = [params["weight"].clone().requires_grad_(True) for _ in shards]   # one parameter copy per replica, as above
+        bs = [params["bias"].clone().requires_grad_(True) for _ in shards]
+        xin = [t.clone().requires_grad_(True) for t in shards]
+        if len(shards) == 1:
+            o, _, _ = orc.sync_batchnorm_forward(xin, ws[0], bs[0], params["running_mean"], params["running_var"], training=training)
+        else:
+            o, _, _ = orc.sync_batchnorm_forward(xin, ws, bs, params["running_mean"], params["running_var"], training=training)
+        (torch.cat(o, 0) * dy).sum().backward()
+        d = float((torch.cat([t.grad for t in xin], 0) - torch.from_numpy(blob[key + "_dx"])).abs().max())
+        assert d <= 2e-6, (key, d)
+        if len(shards) == 1:
+            assert float((ws[0].grad - torch.from_numpy(blob[key + "_dw"])).abs().max()) <= 2e-5
+            assert float((bs[0].grad - torch.from_numpy(blob[key + "_db"])).abs().max()) <= 2e-5
+        else:
+            for r in (0, 1):
+                assert float((ws[r].grad - torch.from_numpy(blob[f"sync_dw{r}"])).abs().max()) <= 2e-5
+                assert float((bs[r].grad - torch.from_numpy(blob[f"sync_db{r}"])).abs().max()) <= 2e-5
     np.savez_compressed(os.path.join(GOLDEN, "batchnorm_train.npz"), **blob)
     print("batchnorm_train: wrote", {k: v.shape for k, v in blob.items() if hasattr(v, "shape")})
 

@@ -1,4 +1,4 @@
-"""Training-mode BatchNorm forward (first slice) -- reference sync_batchnorm/batchnorm.py:46-125.
+"""Training-mode BatchNorm forward and backward -- reference sync_batchnorm/batchnorm.py:46-125.
 
 CPU: the oracle against the fixture produced by the reference's own SynchronizedBatchNorm2d (evaluation, one replica,
 two replicas with unequal shards driven through the reference's SyncMaster protocol), and the module's replica protocol
@@ -39,8 +39,26 @@ def test_oracle_matches_reference_fixture():
     assert torch.equal(rm, g["sync_running_mean"]) and torch.equal(rv, g["sync_running_var"])
 
 
+def test_oracle_gradients_match_reference_fixture():
+    """Round 3: the oracle under autograd against the gradients of the reference modules (evaluation, one replica, and two
+    replicas whose gradient crosses the reference's SyncMaster exchange); parameter gradients are per replica."""
+    g = fixture()
+    k, dy = g["split"], g["dy"]
+    for key, shards, training in (("eval", [g["x"]], False), ("single", [g["x"]], True), ("sync", [g["x"][:k], g["x"][k:]], True)):
+        xin = [t.clone().requires_grad_(True) for t in shards]
+        ws = [g["weight"].clone().requires_grad_(True) for _ in shards]
+        bs = [g["bias"].clone().requires_grad_(True) for _ in shards]
+        w_arg, b_arg = (ws[0], bs[0]) if len(shards) == 1 else (ws, bs)
+        o, _, _ = orc.sync_batchnorm_forward(xin, w_arg, b_arg, g["running_mean"], g["running_var"], training=training)
+        (torch.cat(o, 0) * dy).sum().backward()
+        assert float((torch.cat([t.grad for t in xin], 0) - g[key + "_dx"]).abs().max()) <= 2e-6
+        for r in range(len(shards)):
+            sfx = "" if len(shards) == 1 else str(r)
+            assert float((ws[r].grad - g[f"{key}_dw{sfx}"]).abs().max()) <= 2e-5 and float((bs[r].grad - g[f"{key}_db{sfx}"]).abs().max()) <= 2e-5
+
+
 class OracleOps:
-    """CPU stand-in for HipBatchNormOps (tests only): same three steps, same `sums` layout."""
+    """CPU stand-in for HipBatchNormOps (tests only): same steps, same `sums` / `coef` layouts."""
 
     def check(self, input, mod):
         pass
@@ -60,7 +78,30 @@ class OracleOps:
         sumvar = sums[c:2 * c] - sums[:c] * mean
         mod.running_mean.copy_((1 - mod.momentum) * mod.running_mean + mod.momentum * mean)
         mod.running_var.copy_((1 - mod.momentum) * mod.running_var + mod.momentum * sumvar / (size - 1))
-        return mean, (sumvar / size).clamp(mod.eps) ** -0.5 * mod.weight
+        inv_std = (sumvar / size).clamp(mod.eps) ** -0.5
+        return mean, inv_std * mod.weight.detach(), inv_std
+
+    def backward_sums(self, x, dy, mean):
+        c = x.shape[1]
+        n = x.numel() // c
+        d = x - mean[None, :, None, None]
+        sa, sb = dy.sum(dim=(0, 2, 3)), (dy * d).sum(dim=(0, 2, 3))
+        exact = torch.cat([sa.double(), sb.double()]).view(torch.float32)       # the 2C doubles behind the exchanged floats
+        return torch.cat([sa, sb, torch.tensor([float(n % 4096), float(n // 4096)]), exact])
+
+    def backward_finalize(self, local, reduced, inv_std, weight, eps, mode, want_wb):
+        c = inv_std.numel()
+        assert mode == 0
+        size = float(reduced[2 * c] + 4096.0 * reduced[2 * c + 1])
+        clamped = inv_std >= eps ** -0.5
+        coef = torch.cat([reduced[:c] / size, torch.where(clamped, torch.zeros(c), reduced[c:2 * c] * inv_std * inv_std / size),
+                          inv_std * weight.detach()])
+        return coef, local[c:2 * c] * inv_std, local[:c].clone()
+
+    def backward_apply(self, x, dy, mean, coef):
+        c = x.shape[1]
+        e = lambda v: v[None, :, None, None]
+        return e(coef[2 * c:]) * (dy - e(coef[:c]) - (x - e(mean)) * e(coef[c:2 * c]))
 
     def apply(self, x, mean, scale, bias):
         return (x - mean[None, :, None, None]) * scale[None, :, None, None] + bias[None, :, None, None]
@@ -81,10 +122,16 @@ def _cpu_worker(rank, world, port, tmp):
     k = g["split"]
     mod = _load(SynchronizedBatchNorm2d(g["x"].shape[1]), g).train()
     mod._ops = OracleOps()
-    out = mod(g["x"][:k] if rank == 0 else g["x"][k:])        # unequal shards: 4 and 2 images
-    np.save(os.path.join(tmp, f"out{rank}.npy"), out.numpy())
+    sl = slice(0, k) if rank == 0 else slice(k, None)          # unequal shards: 4 and 2 images
+    x = g["x"][sl].clone().requires_grad_(True)
+    out = mod(x)
+    out.backward(g["dy"][sl])                                  # second all-reduce of 2C+2 floats: sum dy, sum dy * (x - mean)
+    np.save(os.path.join(tmp, f"out{rank}.npy"), out.detach().numpy())
     np.save(os.path.join(tmp, f"rm{rank}.npy"), mod.running_mean.numpy())
     np.save(os.path.join(tmp, f"rv{rank}.npy"), mod.running_var.numpy())
+    np.save(os.path.join(tmp, f"dx{rank}.npy"), x.grad.numpy())
+    np.save(os.path.join(tmp, f"dw{rank}.npy"), mod.weight.grad.numpy())
+    np.save(os.path.join(tmp, f"db{rank}.npy"), mod.bias.grad.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -102,6 +149,11 @@ def test_two_rank_protocol_on_cpu(tmp_path):
     for r in (0, 1):
         assert np.abs(np.load(tmp_path / f"rm{r}.npy") - g["sync_running_mean"].numpy()).max() <= 1e-7
         assert np.abs(np.load(tmp_path / f"rv{r}.npy") - g["sync_running_var"].numpy()).max() <= 1e-6
+        # backward: each rank's parameter gradients are its replica's, the input gradient needs the totals of both
+        assert np.abs(np.load(tmp_path / f"dw{r}.npy") - g[f"sync_dw{r}"].numpy()).max() <= 2e-5
+        assert np.abs(np.load(tmp_path / f"db{r}.npy") - g[f"sync_db{r}"].numpy()).max() <= 2e-5
+    dx = np.concatenate([np.load(tmp_path / "dx0.npy"), np.load(tmp_path / "dx1.npy")])
+    assert np.abs(dx - g["sync_dx"].numpy()).max() <= 2e-6
 
 
 def test_module_interface_without_gpu():
@@ -140,6 +192,59 @@ def test_gpu_module_matches_reference_fixture():
     assert float((m.running_var.cpu() - g["sync_running_var"]).abs().max()) <= TOL_STAT
 
 
+TOL_DX, TOL_DW = 1e-5, 1e-4    # max abs: dx is O(1); dweight / dbias are sums of ~1150 O(1) terms
+
+
+@pytest.mark.gpu
+def test_gpu_module_gradients_match_reference_fixture():
+    """Round 3: backward through the HIP kernels (autograd.Function) against the reference modules' gradients."""
+    from eamm_amd import SynchronizedBatchNorm2d
+    g = fixture()
+    dy = g["dy"].to(DEV)
+    for key, kw, train in (("eval", {}, False), ("single", {}, True), ("sync", {"sync": True}, True)):
+        m = _load(SynchronizedBatchNorm2d(g["x"].shape[1], **kw), g).to(DEV).train(train)
+        x = g["x"].to(DEV).requires_grad_(True)
+        out = m(x)
+        assert out.requires_grad and out.grad_fn is not None           # ADVICE r02: the output used to be graph-less
+        out.backward(dy)
+        assert float((x.grad.cpu() - g[key + "_dx"]).abs().max()) <= TOL_DX, key
+        # the replicas' formula on one rank sees the whole batch: its parameter gradients are the two replicas' added
+        dw = g["sync_dw0"] + g["sync_dw1"] if key == "sync" else g[key + "_dw"]
+        db = g["sync_db0"] + g["sync_db1"] if key == "sync" else g[key + "_db"]
+        assert float((m.weight.grad.cpu() - dw).abs().max()) <= TOL_DW and float((m.bias.grad.cpu() - db).abs().max()) <= TOL_DW, key
+    # gradient only with respect to the input (frozen parameters), and a non-contiguous upstream gradient
+    m = _load(SynchronizedBatchNorm2d(g["x"].shape[1]), g).to(DEV).train()
+    m.weight.requires_grad_(False); m.bias.requires_grad_(False)
+    x = g["x"].to(DEV).requires_grad_(True)
+    m(x).backward(dy.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2))
+    assert float((x.grad.cpu() - g["single_dx"]).abs().max()) <= TOL_DX and m.weight.grad is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(16, 256, 64, 64), (2, 64, 128, 128), (3, 5, 7, 9), (4, 33, 1, 1)])
+def test_gpu_gradients_against_float64_autograd(shape):
+    """Generator-sized and awkward shapes: dx / dweight / dbias against float64 autograd through F.batch_norm."""
+    import torch.nn.functional as F
+    from eamm_amd import SynchronizedBatchNorm2d
+    rs = np.random.RandomState(sum(shape) + 1)
+    c = shape[1]
+    x = torch.from_numpy((rs.standard_normal(shape) * rs.uniform(0.5, 2, (1, c, 1, 1)) + rs.standard_normal((1, c, 1, 1))).astype(np.float32))
+    dy = torch.from_numpy(rs.standard_normal(shape).astype(np.float32))
+    w = torch.from_numpy(rs.uniform(0.5, 1.5, c).astype(np.float32))
+    m = SynchronizedBatchNorm2d(c).to(DEV).train()
+    with torch.no_grad():
+        m.weight.copy_(w)
+    xg = x.to(DEV).requires_grad_(True)
+    m(xg).backward(dy.to(DEV))
+    xd = x.double().requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), torch.zeros(c, dtype=torch.float64, requires_grad=True)
+    F.batch_norm(xd, None, None, wd, bd, True, 0.1, 1e-5).backward(dy.double())
+    n = x.numel() // c
+    assert float((xg.grad.cpu().double() - xd.grad).abs().max()) <= 2e-5 * max(1.0, float(xd.grad.abs().max()))
+    assert float((m.weight.grad.cpu().double() - wd.grad).abs().max()) <= 2e-6 * n ** 0.5 + 1e-5
+    assert float((m.bias.grad.cpu().double() - bd.grad).abs().max()) <= 2e-6 * n ** 0.5 + 1e-5
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(16, 256, 64, 64), (1, 64, 256, 256), (3, 5, 7, 9), (2, 33, 1, 1), (5, 128, 32, 32)])
 def test_gpu_statistics_against_float64(shape):
@@ -171,9 +276,14 @@ def _gpu_worker(rank, world, port, tmp):
     g = fixture()
     k = g["split"]
     mod = _load(SynchronizedBatchNorm2d(g["x"].shape[1]), g).to(DEV).train()
-    out = mod((g["x"][:k] if rank == 0 else g["x"][k:]).to(DEV))
-    np.save(os.path.join(tmp, f"out{rank}.npy"), out.cpu().numpy())
+    sl = slice(0, k) if rank == 0 else slice(k, None)
+    x = g["x"][sl].to(DEV).requires_grad_(True)
+    out = mod(x)
+    out.backward(g["dy"][sl].to(DEV))
+    np.save(os.path.join(tmp, f"out{rank}.npy"), out.detach().cpu().numpy())
     np.save(os.path.join(tmp, f"rv{rank}.npy"), mod.running_var.cpu().numpy())
+    np.save(os.path.join(tmp, f"dx{rank}.npy"), x.grad.cpu().numpy())
+    np.save(os.path.join(tmp, f"dw{rank}.npy"), mod.weight.grad.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -191,3 +301,6 @@ def test_gpu_two_ranks_unequal_shards(tmp_path):
     assert np.abs(out - g["sync_out"].numpy()).max() <= TOL_OUT
     for r in (0, 1):
         assert np.abs(np.load(tmp_path / f"rv{r}.npy") - g["sync_running_var"].numpy()).max() <= TOL_STAT
+        assert np.abs(np.load(tmp_path / f"dw{r}.npy") - g[f"sync_dw{r}"].numpy()).max() <= TOL_DW
+    dx = np.concatenate([np.load(tmp_path / "dx0.npy"), np.load(tmp_path / "dx1.npy")])
+    assert np.abs(dx - g["sync_dx"].numpy()).max() <= TOL_DX
