@@ -50,6 +50,10 @@ class EammDeconvConfig(C.Structure):
     _fields_ = [("num_layers", C.c_int32), ("channels", C.c_int32 * 9), ("max_batch", C.c_int32)]
 
 
+class EammBnSite(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
+
+
 class EammKpOutputs(C.Structure):
     _fields_ = [("value", C.c_void_p), ("jacobian", C.c_void_p), ("heatmap", C.c_void_p)]
 
@@ -107,6 +111,14 @@ SIGNATURES = {
     "eamm_op_conv": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "eamm_set_training": (C.c_int, [C.c_void_p, C.c_int]),
+    "eamm_train_num_sites": (C.c_int, [C.c_void_p]),
+    "eamm_train_site_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "eamm_train_max_channels": (C.c_int, [C.c_void_p]),
+    "eamm_train_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(EammBnSite), C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.POINTER(EammOutputs),
+                                   C.c_void_p]),
+    "eamm_train_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "eamm_op_warp": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
 }

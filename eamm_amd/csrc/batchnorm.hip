@@ -288,6 +288,11 @@ hipError_t bn_local_sums_launch(const float* x, int N, int C, int HW, float* sum
     return hipGetLastError();
 }
 
+hipError_t bn_combine_launch(const double* partial, int C, int P, long long count, float* sums, hipStream_t s) {
+    hipLaunchKernelGGL(bn_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, C, P, count, sums);
+    return hipGetLastError();
+}
+
 hipError_t bn_finalize_launch(const float* sums, int C, float eps, float momentum, int mode, const float* weight,
                               float* running_mean, float* running_var, float* mean, float* scale, float* inv_std, hipStream_t s) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, eps, momentum, mode, weight,

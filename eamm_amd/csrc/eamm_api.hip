@@ -4,107 +4,7 @@
 //   eamm_encode_source  -- frame-invariant: first 7x7 block, down blocks, anti-alias down-sampling
 //   eamm_forward_frames -- per frame batch: key-point records, motion front end, hourglass, flow head,
 //                          feature warp, bottleneck, up blocks, final 7x7 + sigmoid
-#include "../../include/eamm_hip.h"
-#include "api_common.h"
-
-
-using namespace eamm;
-
-struct eamm_ctx : eamm::CtxBase {
-    eamm_config cfg{};
-    int ns_cached = 0;
-
-    // derived geometry
-    int H = 0, W = 0, h = 0, w = 0, hf = 0, wf = 0, K = 0, nb = 0, nd = 0;
-    int Cb = 0;                 // bottleneck channels
-    int Cp0 = 0;                // hourglass input channels padded to a multiple of 32
-    int Csrc = 32;              // RGB source padded for the 7x7 MFMA encoder conv
-    std::vector<int> enc_c;     // hourglass encoder output channels e_1..e_nb
-    std::vector<int> dec_c;     // hourglass decoder output channels u_0..u_{nb-1}
-    std::vector<int> down_c;    // generator encoder channels [be, ...]
-    std::vector<int> up_c;      // generator decoder output channels
-
-    // layers
-    ConvLayer first, final_conv, head;
-    float *first7_w = nullptr, *first7_bias = nullptr;   // the first block on its dedicated 3-channel kernel (conv_first.hip), or null
-    int first7 = 1;                                       // EAMM_FIRST7: 0 = the generic 7x7 kernel on the 32-channel-padded source
-    std::vector<LayerSet> down, hg_enc, hg_dec, res1, res2, up;
-    std::vector<WinoLayer> wres1, wres2;   // Winograd F(2x2,3x3) packing of the bottleneck convolutions
-    std::vector<WinoLayer> w4res1, w4res2; // Winograd F(4x4,3x3) packing (bottleneck maps with sides divisible by 4)
-    std::vector<WinoLayer> w4down;         // ... and of the generator encoder's DownBlock2d levels (source encoding, once per clip / per module call without cache)
-    std::vector<WinoLayer> w4enc;          // F(4x4,3x3) packing of the hourglass encoder convolutions (Cout == 0: level not eligible)
-    int enc_wino = 1;                      // hourglass DownBlock2d levels in F(4x4,3x3) form + pooled output transform (EAMM_ENC_WINO)
-    int enc_wino_min_mflop = 3000;         // ... for levels of at least this many direct-form MFLOP per call (EAMM_ENC_WINO_MIN_MFLOP): smaller ones are
-                                           // launch-bound and one launch beats three (measured 256x256: 1 frame 810 vs 804, 4 frames equal,
-                                           // 8 frames 2896 -> 2960, 12 frames 2849 -> 2968, 16 frames 3529 -> 3659; 512x512 x 8: 911 -> 948 frames/s)
-    int enc_wino_min_tiles = 32;           // ... and of at least this many 4x4 tiles (EAMM_ENC_WINO_MIN_TILES; x4 for levels with > 100 MB of transformed
-                                           // weights): the 4x4-map level has 16 tiles at 16 frames against 151 MB and stays direct
-    int bneck_chains = 2;                  // bottleneck as this many chains of frames on as many streams (EAMM_BNECK_CHAINS; 1 = off)
-    int pass_chains = 0;                   // the whole per-frame pass as this many chains (EAMM_PASS_CHAINS; 1 = off; 0 = the default: two chains
-                                           // when each chain's F(4x4) GEMM keeps enough workgroups (pass_chains_min_blocks); otherwise off)
-    int pass_chains_min_blocks = 80;       // automatic mode: fewest bottleneck-GEMM workgroups per chain (EAMM_PASS_CHAINS_MIN_BLOCKS)
-    int pass_chains_min_frames = 8;        // ... from this many frames per call (EAMM_PASS_CHAINS_MIN_FRAMES)
-    std::vector<hipStream_t> side_streams; // the other chains' streams + fork / join events
-    hipEvent_t ev_fork = nullptr;
-    std::vector<hipEvent_t> ev_join;
-    int wino_tile = 4;                     // preferred output tile (EAMM_WINO_TILE): 4 -> F(4x4) where it applies, 2 -> F(2x2)
-    int wino4_variant = 3;                 // wino4_gemm_kernel pipeline variant (3: one DMA piece per 8 MFMAs; 2.062 -> 2.047 ms per step vs one per 4)
-    float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] (F(2x2)) or [36][F*hf*wf/16][Cb] transformed activations
-    float* wino_z = nullptr;               // [24][F*hf*wf/16][Cb] x-folded products of the split F(4x4) form (few tiles)
-    int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd F(2x2) form
-    int wino4_min_m = 0;                   // ... in F(4x4) form: with the transform-point rows split over workgroups it wins from one frame up
-    int wino_variant = 0;                  // wino_gemm_kernel pipeline variant (see wino_gemm_launch); in-pipeline all are within noise
-    std::vector<float*> pre_s, pre_t;  // res-block pre-activation scale/shift (norm1)
-    float* aa_w = nullptr;
-    float* head_bias = nullptr;    // mask / occlusion biases when the head runs row-split (applied by the head kernel)
-    int head_nc = 0;               // > 0: head is a 7x1 convolution over (dx, co), co < head_nc
-    float* head_w_swz = nullptr;   // its weights with a 96-wide N tile in LDS-DMA layout (conv_col7s_kernel), or null
-    float* final_bias = nullptr;   // bias of the final conv, applied by the shift-sum kernel
-    float* final_part = nullptr;   // [F,H,W,32] (dx,co) partial products of the final 7x7 conv
-    float* final_w_swz = nullptr;  // the 7x1 weights in LDS-DMA layout for the column-patch kernel (conv_col7.hip)
-    int col7 = 1;                  // EAMM_COL7: 0 = im2col-style kernel for the final convolution
-    int head_col7_min_tiles = 128; // fewest 16x16 tiles for which the flow head uses the column-patch kernel (EAMM_HEAD_COL7_MIN_TILES)
-
-    // source cache (exportable): feat [S,hf,wf,Cb], src_small [S,h,w,4], src_full [S,3,H,W]
-    float *feat = nullptr, *src_small = nullptr, *src_full = nullptr;
-    // encoder temporaries
-    float* src_nhwc = nullptr;
-    std::vector<float*> enc_tmp;  // first output, then each down-block output except the last (= feat)
-    // per-frame workspace
-    float* kp_rec = nullptr;
-    int* bad_flag = nullptr;
-    float* hg_in = nullptr;
-    std::vector<float*> e_buf, u_buf;
-    float *logits = nullptr, *deformation = nullptr, *occlusion = nullptr;
-    float *xa = nullptr, *xb = nullptr, *act = nullptr, *tmp = nullptr;
-    std::vector<float*> up_buf;
-    float* partial = nullptr;
-    size_t partial_elems = 0;
-
-    double flops_frame = 0, flops_encode = 0;
-
-    // optional stage timing with HIP events on the caller's stream (bench.py roofline leg)
-    static constexpr int NSTAGE = 14;      // front, hg_enc, hg_dec, head, warp, bneck_transform, bneck_conv, up, final + bneck_gemm_kernel
-                                           // + bneck_union_ms (wall time during which ANY chain is in its bottleneck stage), bneck_windows_ms (sum of
-                                           // the chains' bottleneck windows), exec_gflop / bneck_exec_gflop (executed MFMA GFLOP of the recorded
-                                           // calls, all chains: whole pass / bottleneck GEMMs)
-    static constexpr int MAXCHAIN = 4;     // chains whose bottleneck window is recorded per call
-    static constexpr int NMARK = 8;        // stage boundaries recorded per call (bottleneck is split from sub-events)
-    static constexpr int NSUB = 64;        // per-launch events inside the bottleneck (4 per res-block + 1)
-    static constexpr int PROF_CALLS = 256; // event sets kept before the host must read them
-    bool profiling = false;
-    std::vector<hipEvent_t> prof_events;   // PROF_CALLS * (NMARK+1 + NSUB)
-    std::vector<hipEvent_t> prof_chain_ev; // PROF_CALLS * MAXCHAIN * 2: start / end of each whole-pass chain's bottleneck stage
-    std::vector<int> prof_nchain;          // chains recorded by each call
-    std::vector<double> prof_flops, prof_flops_bneck;   // executed MFMA flops of each recorded call
-    double call_flops = 0, call_flops_bneck = 0;         // ... of the call being enqueued
-    std::vector<int> prof_sub;             // sub-events used by each recorded call (0: direct form)
-    std::vector<int> prof_marks;           // stage marks each recorded call completed (NMARK + 1 unless it failed midway)
-    int prof_used = 0;
-    double prof_ms[NSTAGE] = {0};
-    long prof_calls = 0, prof_frames = 0;
-    std::vector<int> prof_n;
-};
+#include "eamm_ctx.h"
 
 namespace {
 
@@ -267,13 +167,17 @@ int eamm_finalize_weights(eamm_ctx* c) {
     }
     const std::string dm = "dense_motion_network.";
     int rc;
+    // training mode (eamm_set_training): batch statistics cannot be folded -- every convolution is packed with its raw
+    // weights and the BatchNorm runs as its own kernels (eamm_train_api.hip)
+    const bool tr = c->train_mode;
+    auto nm = [&](const std::string& norm) { return tr ? std::string() : norm; };
     // hourglass encoder: e_0 = 44-channel motion tensor (padded to Cp0), e_i = DownBlock2d_i(e_{i-1})
     c->hg_enc.resize(c->nb);
     const int cin0 = (c->K + 1) * 4;
     for (int i = 0; i < c->nb; ++i) {
         const std::string p = dm + "hourglass.encoder.down_blocks." + std::to_string(i);
         const int cr = i == 0 ? cin0 : c->enc_c[i - 1], cp = i == 0 ? c->Cp0 : c->enc_c[i - 1];
-        if ((rc = build_set(c, {{p + ".conv", p + ".norm"}}, cr, cp, 0, 0, &c->hg_enc[i], MODE_PLAIN))) return rc;
+        if ((rc = build_set(c, {{p + ".conv", nm(p + ".norm")}}, cr, cp, 0, 0, &c->hg_enc[i], MODE_PLAIN))) return rc;
     }
     // hourglass decoder: u_i = UpBlock2d_i(cat[u_{i-1}, e_{nb-i}])  (util.py:981-987)
     c->hg_dec.resize(c->nb);
@@ -281,7 +185,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
         const std::string p = dm + "hourglass.decoder.up_blocks." + std::to_string(i);
         const int c0 = i == 0 ? c->enc_c[c->nb - 1] : c->dec_c[i - 1];
         const int c1 = i == 0 ? 0 : c->enc_c[c->nb - 1 - i];
-        if ((rc = build_set(c, {{p + ".conv", p + ".norm"}}, c0, c0, c1, c1, &c->hg_dec[i], MODE_PHASE))) return rc;
+        if ((rc = build_set(c, {{p + ".conv", nm(p + ".norm")}}, c0, c0, c1, c1, &c->hg_dec[i], MODE_PHASE))) return rc;
     }
     // flow head: mask (K+1) and occlusion (1) 7x7 convolutions share one launch (dense_motion.py:98,110)
     if (c->nb > 0) {
@@ -303,7 +207,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
         }
     }
     // generator encoder
-    if ((rc = build_layer(c, {{"first.conv", "first.norm"}}, 7, 3, c->Csrc, 0, 0, &c->first))) return rc;
+    if ((rc = build_layer(c, {{"first.conv", nm("first.norm")}}, 7, 3, c->Csrc, 0, 0, &c->first))) return rc;
     if (c->first7 && first7_supported(c->down_c[0])) {   // K = 147 (196 with the zero rows) instead of 49 x 32
         const HostTensor *wt = find(c, "first.conv.weight"), *bt = find(c, "first.conv.bias"), *gm = find(c, "first.norm.weight"),
                          *be = find(c, "first.norm.bias"), *mu = find(c, "first.norm.running_mean"), *vr = find(c, "first.norm.running_var");
@@ -324,7 +228,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
     c->down.resize(c->nd);
     for (int i = 0; i < c->nd; ++i) {
         const std::string p = "down_blocks." + std::to_string(i);
-        if ((rc = build_set(c, {{p + ".conv", p + ".norm"}}, c->down_c[i], c->down_c[i], 0, 0, &c->down[i], MODE_PLAIN)))
+        if ((rc = build_set(c, {{p + ".conv", nm(p + ".norm")}}, c->down_c[i], c->down_c[i], 0, 0, &c->down[i], MODE_PLAIN)))
             return rc;
     }
     // bottleneck: conv1 absorbs norm2 (conv1 -> norm2 -> relu), norm1 becomes the producer's second output
@@ -335,7 +239,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
     c->pre_t.resize(nr);
     for (int i = 0; i < nr; ++i) {
         const std::string r = "bottleneck.r" + std::to_string(i);
-        if ((rc = build_set(c, {{r + ".conv1", r + ".norm2"}}, c->Cb, c->Cb, 0, 0, &c->res1[i], MODE_PLAIN))) return rc;
+        if ((rc = build_set(c, {{r + ".conv1", nm(r + ".norm2")}}, c->Cb, c->Cb, 0, 0, &c->res1[i], MODE_PLAIN))) return rc;
         if ((rc = build_set(c, {{r + ".conv2", ""}}, c->Cb, c->Cb, 0, 0, &c->res2[i], MODE_PLAIN))) return rc;
         if (c->wino_min_m >= 0 && c->Cb % 64 == 0) {
             c->wres1.resize(nr);
@@ -391,7 +295,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
     for (int i = 0; i < c->nd; ++i) {
         const std::string p = "up_blocks." + std::to_string(i);
         const int ci = i == 0 ? c->Cb : c->up_c[i - 1];
-        if ((rc = build_set(c, {{p + ".conv", p + ".norm"}}, ci, ci, 0, 0, &c->up[i], MODE_PHASE))) return rc;
+        if ((rc = build_set(c, {{p + ".conv", nm(p + ".norm")}}, ci, ci, 0, 0, &c->up[i], MODE_PHASE))) return rc;
     }
     {   // final 7x7 (Cout = 3): 7x1 MFMA convolution over (dx, co) + horizontal gather
         std::vector<float> fb;
@@ -455,6 +359,26 @@ int eamm_finalize_weights(eamm_ctx* c) {
     c->up_buf.resize(c->nd);
     for (int i = 0; i < c->nd; ++i)
         if ((rc = dev_alloc(c, &c->up_buf[i], F * (hwf << (2 * (i + 1))) * c->up_c[i]))) return rc;
+    if (tr) {   // pre-BatchNorm convolution outputs (DownBlock2d: at the un-pooled size) and the statistics of the site in flight
+        size_t raw_elems = F * HW * c->down_c[0];
+        int cmax = std::max(c->down_c[0], c->Cb);
+        for (int i = 0; i < c->nd; ++i) {
+            raw_elems = std::max(raw_elems, F * (HW >> (2 * i)) * c->down_c[i + 1]);
+            raw_elems = std::max(raw_elems, F * (hwf << (2 * (i + 1))) * c->up_c[i]);
+            cmax = std::max({cmax, c->down_c[i + 1], c->up_c[i]});
+        }
+        for (int i = 0; i < c->nb; ++i) {
+            raw_elems = std::max(raw_elems, F * (hw >> (2 * i)) * c->enc_c[i]);
+            raw_elems = std::max(raw_elems, F * (hw >> (2 * (c->nb - 1 - i))) * c->dec_c[i]);
+            cmax = std::max({cmax, c->enc_c[i], c->dec_c[i]});
+        }
+        if (cmax > 1024 || (cmax & 3)) return fail(c, EAMM_ERR_ARG, "training mode: BatchNorm sites of up to 1024 channels (got %d)", cmax);
+        if (S < F) return fail(c, EAMM_ERR_ARG, "training mode needs max_sources >= max_frames (one source per frame of the batch)");
+        c->train_cmax = cmax;
+        if ((rc = dev_alloc(c, &c->raw, raw_elems))) return rc;
+        if ((rc = dev_alloc(c, &c->train_stat, (size_t)2 * cmax))) return rc;
+        if ((rc = dev_alloc(c, &c->bn_work, (size_t)cmax * 1024 * 4))) return rc;
+    }
     // split-K slab: the largest any layer asks for at any batch size up to the maximum (a smaller batch
     // can pick more K slices than the full one); conv_launch also clamps its slice count to the slab.
     {

@@ -200,6 +200,12 @@ hipError_t bn_bwd_apply_launch(const float* x, const float* dy, const float* mea
                                hipStream_t s);
 hipError_t bn_apply_launch(const float* x, const float* mean, const float* scale, const float* bias, int N, int C, int HW,
                            float* y, hipStream_t s);
+// NHWC variants for the engine's training-mode forward (batchnorm_nhwc.hip); sums / finalize as above
+hipError_t bn_combine_launch(const double* partial /*[C][P][2]*/, int C, int P, long long count, float* sums /*[6C+2]*/, hipStream_t s);
+size_t bn_nhwc_workspace_floats(long long M, int C);
+hipError_t bn_nhwc_sums_launch(const float* x /*[M,C]*/, long long M, int C, float* sums /*[6C+2]*/, float* workspace, hipStream_t s);
+hipError_t bn_nhwc_apply_launch(const float* x /*[B,H,W,C]*/, const float* mean, const float* scale, const float* bias, int B, int H,
+                                int W, int C, int relu, int pool, float* y, hipStream_t s);
 hipError_t to_u8_launch(const float* pred /*[n,3,H,W]*/, int n, int H, int W, uint8_t* out /*[n,H,W,3]*/,
                         hipStream_t s);
 

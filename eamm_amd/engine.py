@@ -49,7 +49,7 @@ def _dev_ptr(t: Optional[torch.Tensor]):
 
 class Engine:
     def __init__(self, cfg: dict, height: int, width: int, max_frames: int = 16, max_sources: int = 1,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, training: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("eamm_amd.Engine needs a ROCm GPU: the path has no CPU fallback")
         self.cfg = dict(cfg)
@@ -71,6 +71,11 @@ class Engine:
         _lib.check(self._L.eamm_create(C.byref(self._cs), self.device.index, C.byref(ctx)), None)
         self._ctx = ctx
         self._finalized = False
+        # training-mode handle (eamm_set_training): raw convolution weights, BatchNorm as separate kernels with batch
+        # statistics -- only train_forward() may be used on it
+        self.training = bool(training)
+        if self.training:
+            _lib.check(self._L.eamm_set_training(self._ctx, 1), self._ctx)
         self.ns_cached = 0
         # bumped by every encode / import: lets a caller that caches "my source is the encoded one" (the module's
         # forward()) notice that somebody else (the clip pipeline) has replaced the engine's source cache since
@@ -118,6 +123,8 @@ class Engine:
         return t.contiguous()
 
     def encode_source(self, source: torch.Tensor) -> int:
+        if self.training:
+            raise RuntimeError("a training-mode engine has no BatchNorm folded into its convolutions: use train_forward()")
         src = self._check_dev(source, "source_image", (3, self.height, self.width))
         ns = src.shape[0]
         with torch.cuda.device(self.device):
@@ -126,8 +133,76 @@ class Engine:
         self.cache_generation += 1
         return ns
 
+    # -- training-mode forward (include/eamm_hip.h, "N4, second slice") ------------------------------------------------
+    def train_sites(self):
+        """State-dict prefixes of the BatchNorm sites of one forward, in execution order."""
+        return [self._L.eamm_train_site_name(self._ctx, i).decode() for i in range(self._L.eamm_train_num_sites(self._ctx))]
+
+    def train_forward(self, source: torch.Tensor, kp_driving: dict, kp_source: dict, norms: Dict[str, torch.nn.Module],
+                      outputs: Iterable[str] = ("prediction",), sync: bool = False, reduce=None) -> Dict[str, torch.Tensor]:
+        """One forward with batch statistics.  ``norms``: BatchNorm module per site name (weight, bias and -- updated in
+        place -- running_mean / running_var are read through their device pointers).  ``reduce(t)``: all-reduce (sum) of the
+        float tensor ``t`` over the replicas, called once per site between the statistics and the normalisation; None on
+        one replica."""
+        if not self.training:
+            raise RuntimeError("train_forward needs an Engine(training=True)")
+        K, H, W, h, w = self.num_kp, self.height, self.width, self.h, self.w
+        src = self._check_dev(source, "source_image", (3, H, W))
+        n = src.shape[0]
+        kd = ks = kdj = ksj = None
+        if self.has_motion:
+            kd = self._check_dev(kp_driving["value"], "kp_driving['value']", (K, 2))
+            ks = self._check_dev(kp_source["value"], "kp_source['value']", (K, 2))
+            if kd.shape[0] != n or ks.shape[0] != n:
+                raise RuntimeError("key-point batch size does not match source_image batch size")
+            if "jacobian" in kp_driving:
+                kdj = self._check_dev(kp_driving["jacobian"], "kp_driving['jacobian']", (K, 2, 2))
+                ksj = self._check_dev(kp_source["jacobian"], "kp_source['jacobian']", (K, 2, 2))
+        want = set(outputs) | {"prediction"}
+        if "occlusion_map" in want and not self.has_occlusion:
+            want.discard("occlusion_map")
+        shapes = {"prediction": (n, 3, H, W), "mask": (n, K + 1, h, w), "sparse_deformed": (n, K + 1, 3, h, w),
+                  "occlusion_map": (n, 1, h, w), "deformed": (n, 3, H, W), "deformation": (n, h, w, 2)}
+        res = {k: torch.empty(shapes[k], dtype=torch.float32, device=self.device) for k in _OUTPUT_KEYS if k in want}
+        o = _lib.EammOutputs()
+        for k, t in res.items():
+            setattr(o, k, t.data_ptr())
+        names = self.train_sites()
+        sites = (_lib.EammBnSite * len(names))()
+        momentum = eps = None
+        for i, name in enumerate(names):
+            m = norms[name]
+            for t in (m.weight, m.bias, m.running_mean, m.running_var):
+                if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+                    raise RuntimeError(f"BatchNorm tensors of {name} must be contiguous float32 on {self.device}")
+            sites[i].weight, sites[i].bias = m.weight.data_ptr(), m.bias.data_ptr()
+            sites[i].running_mean, sites[i].running_var = m.running_mean.data_ptr(), m.running_var.data_ptr()
+            if momentum is None:
+                momentum, eps = float(m.momentum), float(m.eps)
+            elif (float(m.momentum), float(m.eps)) != (momentum, eps):
+                raise RuntimeError("all BatchNorm sites must share momentum and eps (they do in the reference)")
+        sums = torch.empty(6 * self._L.eamm_train_max_channels(self._ctx) + 2, dtype=torch.float32, device=self.device)
+        nfl = C.c_int(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.eamm_train_begin(self._ctx, _dev_ptr(src), n, _dev_ptr(kd), _dev_ptr(kdj), _dev_ptr(ks), _dev_ptr(ksj),
+                                                sites, len(names), momentum, eps, int(bool(sync)), _dev_ptr(sums), C.byref(o),
+                                                self._stream()), self._ctx)
+            while True:
+                rc = self._L.eamm_train_next(self._ctx, C.byref(nfl))
+                if rc < 0:
+                    _lib.check(rc, self._ctx)
+                if rc == 0:
+                    break
+                if reduce is not None:
+                    reduce(sums[:nfl.value])
+        self.ns_cached = 0
+        self.cache_generation += 1
+        return res
+
     def forward_frames(self, kp_driving: dict, kp_source: dict, outputs: Iterable[str] = ("prediction",),
                        uint8_frames: bool = False) -> Dict[str, torch.Tensor]:
+        if self.training:
+            raise RuntimeError("a training-mode engine has no BatchNorm folded into its convolutions: use train_forward()")
         K, H, W, h, w = self.num_kp, self.height, self.width, self.h, self.w
         kd = self._check_dev(kp_driving["value"], "kp_driving['value']", (K, 2))
         ks = self._check_dev(kp_source["value"], "kp_source['value']", (K, 2))

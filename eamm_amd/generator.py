@@ -6,7 +6,9 @@ same constructor keywords (``demo.py:54-55`` splats the YAML sections into it), 
 set, so ``generator.load_state_dict(checkpoint['generator'])`` / ``.cuda()`` / ``.eval()``
 (demo.py:56-57, 91, 105) work unchanged.  The sub-modules below only HOLD parameters under the
 reference's names; they are never called.  All computation happens in the HIP library; there is no
-PyTorch/CPU fallback and ``forward`` raises when the module is not on a GPU.
+PyTorch/CPU fallback and ``forward`` raises when the module is not on a GPU.  ``.train()`` is supported for the FORWARD
+(batch statistics in every BatchNorm, running statistics updated, replicas' statistics all-reduced -- SURVEY.md 8f row N4);
+there is no backward through the generator.
 
 Beyond the reference interface the module exposes the two halves of forward separately
 (``encode_source`` / ``forward_frames``) so that a clip can reuse the frame-invariant source
@@ -115,7 +117,14 @@ class OcclusionAwareGenerator(nn.Module):
         self._src_generation = -1
         self._engine: Optional[Engine] = None
         self._engine_key = None
-        for p in self.parameters():  # inference-only path
+        self._train_engine: Optional[Engine] = None
+        self._train_key = None
+        # .train() mode: replicas for the BatchNorm statistics (None: the world group when torch.distributed runs with more
+        # than one rank -- the analogue of DataParallel replicating the reference module); sync_batchnorm forces the
+        # replicas' formula on or off (sync_batchnorm/batchnorm.py:48-53 vs :55-125)
+        self.process_group = None
+        self.sync_batchnorm: Optional[bool] = None
+        for p in self.parameters():  # the forward carries no autograd graph (convolution / warp backward are not built)
             p.requires_grad_(False)
 
     # -- engine management ---------------------------------------------------------------------------
@@ -127,9 +136,6 @@ class OcclusionAwareGenerator(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("eamm_amd.OcclusionAwareGenerator runs only on a ROCm GPU: move the module with "
                                ".cuda() first (there is no CPU fallback for this path)")
-        if self.training:
-            raise RuntimeError("inference-only: BatchNorm uses running statistics (sync_batchnorm/batchnorm.py:48-53);"
-                               " call .eval() as demo.py:105 does")
         e = self._engine
         key = (dev, height, width, self._weights_version())
         if e is None or self._engine_key != key or e.max_frames < frames or e.max_sources < sources:
@@ -141,12 +147,80 @@ class OcclusionAwareGenerator(nn.Module):
             self._engine, self._engine_key = e, key
         return e
 
+    # -- .train(): batch statistics in every BatchNorm (sync_batchnorm/batchnorm.py:55-125) -----------------------------
+    def _norm_modules(self):
+        return {name: mod for name, mod in self.named_modules() if isinstance(mod, nn.BatchNorm2d)}
+
+    def _ensure_train_engine(self, height: int, width: int, frames: int) -> Engine:
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("eamm_amd.OcclusionAwareGenerator runs only on a ROCm GPU: move the module with "
+                               ".cuda() first (there is no CPU fallback for this path)")
+        # convolution weights only: the BatchNorm tensors are read (and the running statistics written) in place
+        conv_version = tuple(t._version for k, t in self.state_dict(keep_vars=True).items() if ".norm" not in k)
+        e = self._train_engine
+        key = (dev, height, width, conv_version)
+        if e is None or self._train_key != key or e.max_frames < frames:
+            if e is not None:
+                e.close()
+            n = max(frames, self.max_frames)
+            e = Engine(self._cfg, height, width, max_frames=n, max_sources=n, device=dev, training=True)
+            e.load_state_dict(self.state_dict())
+            self._train_engine, self._train_key = e, key
+        return e
+
+    def _replicas(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.process_group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _all_reduce(self, t: torch.Tensor):
+        import torch.distributed as dist
+        if dist.get_backend(self.process_group) == "nccl":       # RCCL: device tensor, in place, over xGMI
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+        else:                                                    # gloo (tests): staged through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.process_group)
+            t.copy_(h)
+
+    def _forward_train(self, source_image, kp_driving, kp_source):
+        b, _, hh, ww = source_image.shape
+        e = self._ensure_train_engine(hh, ww, b)
+        world = self._replicas()
+        sync = world > 1 if self.sync_batchnorm is None else bool(self.sync_batchnorm)
+        want = ["prediction"]
+        if self.dense_motion_network is not None:
+            want += ["mask", "sparse_deformed", "deformed"]
+            if self.estimate_occlusion_map:
+                want.append("occlusion_map")
+            kd = {k: kp_driving[k] for k in ("value", "jacobian") if k in kp_driving}
+            ks = {k: kp_source[k] for k in ("value", "jacobian") if k in kp_source}
+        else:
+            kd = ks = None
+        norms = self._norm_modules()
+        out = e.train_forward(source_image, kd, ks, norms, outputs=want, sync=sync,
+                              reduce=self._all_reduce if (sync and world > 1) else None)
+        # the library wrote the running statistics through raw pointers: bump the tensors' version counters so that every
+        # cache keyed on them (the evaluation engine's folded weights) sees the change
+        stats = [t for m in norms.values() for t in (m.running_mean, m.running_var)]
+        try:
+            torch._C._increment_version(stats)
+        except (AttributeError, TypeError):   # older / newer torch without the list form: a no-op in-place write
+            for t in stats:
+                t.add_(0)
+        self._src_ref = None
+        e.check_numeric()
+        return {k: out[k] for k in ("mask", "sparse_deformed", "occlusion_map", "deformed", "prediction") if k in out}
+
     # -- the reference contract -----------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, source_image, kp_driving, kp_source):
-        """Reference generator.py:59-97: batch of independent (source, kp_source, kp_driving) triples."""
+        """Reference generator.py:59-97: batch of independent (source, kp_source, kp_driving) triples.  In ``.train()`` mode
+        every BatchNorm normalises with the statistics of the batch and updates its running statistics, as the reference's
+        blocks do (modules/util.py:858-938); the outputs carry no autograd graph in either mode."""
         if source_image.dim() != 4:
             raise RuntimeError(f"source_image must be [B,3,H,W], got {tuple(source_image.shape)}")
+        if self.training:
+            return self._forward_train(source_image, kp_driving, kp_source)
         b, _, hh, ww = source_image.shape
         e = self._ensure_engine(hh, ww, b, b)
         fresh = not (self.cache_source and self._src_ref is source_image and self._src_version == source_image._version
@@ -174,6 +248,9 @@ class OcclusionAwareGenerator(nn.Module):
     # -- clip interface: encoder hoisted out of the frame loop ------------------------------------------
     @torch.no_grad()
     def encode_source(self, source_image: torch.Tensor, max_frames: Optional[int] = None) -> Engine:
+        if self.training:
+            raise RuntimeError("the clip interface (encode_source / forward_frames) is the inference path: BatchNorm uses "
+                               "running statistics (sync_batchnorm/batchnorm.py:48-53); call .eval() as demo.py:105 does")
         ns, _, hh, ww = source_image.shape
         e = self._ensure_engine(hh, ww, max_frames or self.max_frames, ns)
         e.encode_source(source_image)

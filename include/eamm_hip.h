@@ -258,6 +258,45 @@ int eamm_bn_apply(const float* x, const float* mean, const float* scale, const f
 const char* eamm_bn_last_error(void);
 
 /*
+ * ---- N4, second slice (round 3): the generator's forward in TRAINING mode ------------------------------------------------
+ * Replaces OcclusionAwareGenerator.forward when the module is in .train() (the fine-tuning loop, reference train.py:133):
+ * every SynchronizedBatchNorm2d inside SameBlock2d / DownBlock2d / UpBlock2d / ResBlock2d (modules/util.py:858-938) then
+ * normalises with the statistics of the batch (sync_batchnorm/batchnorm.py:55-125) and updates its running statistics.
+ *   eamm_set_training(ctx, 1)  before eamm_finalize_weights: convolutions are packed with their RAW weights (no BatchNorm
+ *                              folded in); eamm_encode_source / eamm_forward_frames of such a handle would run without
+ *                              any normalisation and must not be used.
+ *   eamm_train_num_sites / eamm_train_site_name   the BatchNorm sites of one forward in execution order, named by their
+ *                              state_dict prefix ("first.norm", "bottleneck.r0.norm1", ...).
+ *   eamm_train_begin           lays out one forward over n (source, key point) pairs -- source [n,3,H,W]; key points as for
+ *                              eamm_forward_frames with one source set per frame -- and the caller's BatchNorm tensors
+ *                              (device pointers, one eamm_bn_site per site: running_mean / running_var are UPDATED in place
+ *                              with `momentum`, batchnorm.py:110-125).  sync = 0: F.batch_norm's formula (one replica,
+ *                              batchnorm.py:48-53), 1: the replicas' formula.  sums_buffer: caller-owned device buffer of
+ *                              6 * eamm_train_max_channels(ctx) + 2 floats, 8-byte aligned, that stays valid until the
+ *                              last eamm_train_next.  Nothing is enqueued yet.
+ *   eamm_train_next            enqueues the forward up to the next BatchNorm's statistics and returns 1 with
+ *                              *nfloats = 2C + 2: the first 2C + 2 floats of sums_buffer hold per-channel sum, sum of
+ *                              squares and the element count as in eamm_bn_local_sums -- ALL-REDUCE them over the replicas on the
+ *                              same stream (nothing to do on one replica) and call again; returns 0 when the outputs given
+ *                              to eamm_train_begin are complete (stream-ordered), < 0 on error.
+ * Forward only: the outputs carry no gradient (the convolution and warp backward kernels are not built).
+ */
+typedef struct eamm_bn_site {
+    const float* weight;     /* [C] device                                  */
+    const float* bias;       /* [C] device                                  */
+    float* running_mean;     /* [C] device, updated                         */
+    float* running_var;      /* [C] device, updated (unbiased batch variance) */
+} eamm_bn_site;
+int eamm_set_training(eamm_ctx* ctx, int on);
+int eamm_train_num_sites(const eamm_ctx* ctx);
+const char* eamm_train_site_name(const eamm_ctx* ctx, int i);
+int eamm_train_max_channels(const eamm_ctx* ctx);
+int eamm_train_begin(eamm_ctx* ctx, const float* source, int n, const float* kp_driving_value, const float* kp_driving_jacobian,
+                     const float* kp_source_value, const float* kp_source_jacobian, const eamm_bn_site* sites, int nsites,
+                     float momentum, float eps, int sync, float* sums_buffer, const eamm_outputs* outputs, void* stream);
+int eamm_train_next(eamm_ctx* ctx, int* nfloats);
+
+/*
  * Stage timing for roofline accounting (bench.py): while enabled, every eamm_forward_frames call
  * records HIP events on the caller's stream at its stage boundaries and around every bottleneck launch
  * (up to 256 calls between reads).  eamm_profile_read waits for the recorded calls and returns

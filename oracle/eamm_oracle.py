@@ -41,8 +41,17 @@ def gaussian_heatmaps(kp_value: torch.Tensor, h: int, w: int, variance: float) -
     return torch.exp(-0.5 * (diff ** 2).sum(-1) / variance)
 
 
+_TRAIN = None   # generator_forward_train's context: {"parallel": bool, "stats": {prefix: (running_mean, running_var)}}
+
+
 def batch_norm_eval(x, sd, prefix):
-    """Eval-mode BatchNorm with running statistics -- sync_batchnorm/batchnorm.py:48-53."""
+    """Eval-mode BatchNorm with running statistics -- sync_batchnorm/batchnorm.py:48-53.  Inside generator_forward_train the
+    same call sites take the training branch instead (batch statistics, running statistics updated: batchnorm.py:55-125)."""
+    if _TRAIN is not None:
+        outs, rm, rv = sync_batchnorm_forward([x], sd[prefix + ".weight"], sd[prefix + ".bias"], sd[prefix + ".running_mean"],
+                                              sd[prefix + ".running_var"], parallel=_TRAIN["parallel"])
+        _TRAIN["stats"][prefix] = (rm, rv)
+        return outs[0]
     return F.batch_norm(x, sd[prefix + ".running_mean"].to(x.dtype), sd[prefix + ".running_var"].to(x.dtype),
                         sd[prefix + ".weight"].to(x.dtype), sd[prefix + ".bias"].to(x.dtype),
                         False, 0.0, BN_EPS)
@@ -188,6 +197,21 @@ def generator_forward(sd, cfg, source_image, kp_driving, kp_source):
         outputs["deformed"] = warp_by_flow(source_image, dmo["deformation"])
     outputs["prediction"] = decode(sd, cfg, feat)
     return outputs
+
+
+def generator_forward_train(sd, cfg, source_image, kp_driving, kp_source, parallel=False):
+    """OcclusionAwareGenerator.forward in .train() mode: every SynchronizedBatchNorm2d of the blocks (modules/util.py:858-938)
+    normalises with the statistics of the batch.  `parallel` = the replicas' formula (inv_std = clamp(var, eps) ** -0.5,
+    batchnorm.py:125) applied to the WHOLE batch -- what R replicas compute together, up to the order in which their float
+    sums are added; False = F.batch_norm (one replica, batchnorm.py:48-53).
+    Returns (outputs, {norm prefix: (new running_mean, new running_var)})."""
+    global _TRAIN
+    assert _TRAIN is None
+    _TRAIN = {"parallel": parallel, "stats": {}}
+    try:
+        return generator_forward(sd, cfg, source_image, kp_driving, kp_source), _TRAIN["stats"]
+    finally:
+        _TRAIN = None
 
 
 # ----------------------------------------------------------------------------------------------

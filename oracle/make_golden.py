@@ -447,7 +447,88 @@ def batchnorm_case():
     print("batchnorm_train: wrote", {k: v.shape for k, v in blob.items() if hasattr(v, "shape")})
 
 
+def train_mode_case(OAG):
+    """Fixture for the generator's forward in .train() mode (N4, second slice): the reference generator with batch statistics
+    in every SynchronizedBatchNorm2d, on ONE replica (F.batch_norm branch) and on TWO replicas with unequal shards (3 + 1
+    pairs) driven through the reference's own replication callbacks and SyncMaster protocol on two threads (only the two
+    CUDA-only transport functions are replaced by their CPU meaning, as in batchnorm_case).  Stored: every output key and
+    the running statistics every BatchNorm ends up with (two replicas: the master's -- the slaves' are never updated)."""
+    import copy
+    import threading
+    import sync_batchnorm.batchnorm as ref_bn  # type: ignore
+    from sync_batchnorm.replicate import execute_replication_callbacks  # type: ignore
+
+    def reduce_add(dest, n, *ts):
+        groups = [ts[i:i + n] for i in range(0, len(ts), n)]
+        return tuple(sum(g[k] for g in groups[1:]) + groups[0][k] if len(groups) > 1 else groups[0][k] for k in range(n))
+
+    ref_bn.ReduceAddCoalesced = type("ReduceAddCoalesced", (), {"apply": staticmethod(reduce_add)})
+    ref_bn.Broadcast = type("Broadcast", (), {"apply": staticmethod(lambda gpus, *ts: tuple(t.clone() for _ in gpus for t in ts))})
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    n, split = 4, 3
+    source = synthetic_source(64, seed=1, batch=n)
+    kp_s = synthetic_keypoints(n, cfg["num_kp"], seed=0)
+    kp_d = synthetic_keypoints(n, cfg["num_kp"], seed=2)
+    keys = ("prediction", "mask", "sparse_deformed", "occlusion_map", "deformed")
+    norm_names = [k[:-len(".running_mean")] for k in sd if k.endswith(".running_mean")]
+
+    def fresh():
+        g = OAG(**cfg)
+        g.load_state_dict(sd, strict=True)
+        return g.train()
+
+    blob = {"weight_seed": np.int64(1234), "n": np.int64(n), "split": np.int64(split), "norm_names": np.array(norm_names)}
+    with torch.no_grad():
+        g1 = fresh()
+        out = g1(source, kp_source=kp_s, kp_driving=kp_d)
+        st1 = g1.state_dict()
+        for k in keys:
+            blob["single_" + k] = out[k].numpy()
+        for p in norm_names:
+            blob["single_rm/" + p], blob["single_rv/" + p] = st1[p + ".running_mean"].numpy().copy(), st1[p + ".running_var"].numpy().copy()
+        master = fresh()
+        slave = copy.deepcopy(master)
+        execute_replication_callbacks([master, slave])
+        outs = [None, None]
+
+        def run(i, mod, sl):
+            with torch.no_grad():
+                outs[i] = mod(source[sl], kp_source={k: v[sl] for k, v in kp_s.items()}, kp_driving={k: v[sl] for k, v in kp_d.items()})
+
+        th = [threading.Thread(target=run, args=(0, master, slice(0, split))), threading.Thread(target=run, args=(1, slave, slice(split, n)))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        stm = master.state_dict()
+        for k in keys:
+            blob["sync_" + k] = torch.cat([outs[0][k], outs[1][k]], 0).numpy()
+        for p in norm_names:
+            blob["sync_rm/" + p], blob["sync_rv/" + p] = stm[p + ".running_mean"].numpy().copy(), stm[p + ".running_var"].numpy().copy()
+        assert all(torch.equal(slave.state_dict()[p + ".running_var"], sd[p + ".running_var"]) for p in norm_names)   # never updated
+        # the oracle's training branch must reproduce both runs
+        worst = {}
+        for tag, par in (("single", False), ("sync", True)):
+            mine, stats = orc.generator_forward_train(sd, cfg, source, kp_d, kp_s, parallel=par)
+            assert sorted(stats) == sorted(norm_names)
+            for k in keys:
+                worst[tag + "_" + k] = float((mine[k] - torch.from_numpy(blob[tag + "_" + k])).abs().max())
+            worst[tag + "_rm"] = max(float((stats[p][0] - torch.from_numpy(blob[tag + "_rm/" + p])).abs().max()) for p in norm_names)
+            worst[tag + "_rv"] = max(float((stats[p][1] - torch.from_numpy(blob[tag + "_rv/" + p])).abs().max()) for p in norm_names)
+        print("train_mode: oracle vs reference, worst |diff|:", {k: f"{v:.2e}" for k, v in worst.items()})
+        # (bars: the evaluation fixtures' -- 'deformed' has a 1e-4 fp32 noise floor of its own, SURVEY.md 8c)
+        bar = {"prediction": 2e-5, "mask": 5e-6, "sparse_deformed": 1e-5, "occlusion_map": 5e-6, "deformed": 1e-4, "rm": 1e-6, "rv": 1e-6}
+        assert all(v <= bar[k.split("_", 1)[1]] for k, v in worst.items()), worst
+        d = float(np.abs(blob["single_prediction"] - blob["sync_prediction"]).max())
+        assert d < 1e-3, d   # same statistics, two formulas for inv_std and two summation orders
+    np.savez_compressed(os.path.join(GOLDEN, "tiny64_train.npz"), **blob)
+    print("tiny64_train: wrote", len(blob), "arrays;", len(norm_names), "BatchNorm sites")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        os.makedirs(GOLDEN, exist_ok=True)
+        train_mode_case(import_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "nomotion":
         os.makedirs(GOLDEN, exist_ok=True)
         no_motion_case(import_reference())
@@ -493,6 +574,7 @@ def main():
     deconv_tail_case()
     smoothing_case()
     batchnorm_case()
+    train_mode_case(OAG)
     with open(os.path.join(GOLDEN, "summary.json"), "w") as f:
         json.dump({"torch": torch.__version__, "cases": summary}, f, indent=1, sort_keys=True)
     for name, rep in summary.items():

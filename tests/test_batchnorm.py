@@ -177,17 +177,17 @@ def test_gpu_module_matches_reference_fixture():
     g = fixture()
     x = g["x"].to(DEV)
     m = _load(SynchronizedBatchNorm2d(x.shape[1]), g).to(DEV).eval()
-    assert float((m(x).cpu() - g["eval_out"]).abs().max()) <= TOL_OUT
+    assert float((m(x).detach().cpu() - g["eval_out"]).abs().max()) <= TOL_OUT
     assert torch.equal(m.running_mean.cpu(), g["running_mean"])                 # evaluation updates nothing
     m = _load(SynchronizedBatchNorm2d(x.shape[1]), g).to(DEV).train()
-    out = m(x)
+    out = m(x).detach()
     assert float((out.cpu() - g["single_out"]).abs().max()) <= TOL_OUT
     assert float((m.running_mean.cpu() - g["single_running_mean"]).abs().max()) <= TOL_STAT
     assert float((m.running_var.cpu() - g["single_running_var"]).abs().max()) <= TOL_STAT
     assert int(m.num_batches_tracked) == 0      # the reference's forward never touches it (batchnorm.py:46-82)
     # the replicas' formula on one rank: whole batch as one shard == the two-replica statistics of the fixture
     m = _load(SynchronizedBatchNorm2d(x.shape[1], sync=True), g).to(DEV).train()
-    out = m(x)
+    out = m(x).detach()
     assert float((out.cpu() - g["sync_out"]).abs().max()) <= TOL_OUT
     assert float((m.running_var.cpu() - g["sync_running_var"]).abs().max()) <= TOL_STAT
 
@@ -255,7 +255,7 @@ def test_gpu_statistics_against_float64(shape):
     c = shape[1]
     x = torch.from_numpy((rs.standard_normal(shape) * rs.uniform(0.5, 2, (1, c, 1, 1)) + rs.standard_normal((1, c, 1, 1))).astype(np.float32))
     m = SynchronizedBatchNorm2d(c).to(DEV).train()
-    out = m(x.to(DEV)).cpu()
+    out = m(x.to(DEV)).detach().cpu()
     xd = x.double()
     mean, var = xd.mean(dim=(0, 2, 3)), xd.var(dim=(0, 2, 3), unbiased=False)
     n = x.numel() // c

@@ -1,0 +1,172 @@
+"""The generator's forward in .train() mode (second slice): batch statistics in every BatchNorm,
+running statistics updated, replicas' statistics all-reduced -- reference sync_batchnorm/batchnorm.py:55-125 inside the blocks
+of modules/util.py:858-938 (the fine-tuning loop, train.py:133).
+
+Fixture tests/golden/tiny64_train.npz (oracle/make_golden.py::train_mode_case): the REFERENCE generator in .train() on one
+replica and on two replicas (3 + 1 pairs) driven through its own replication callbacks and SyncMaster protocol.
+CPU: the oracle's training branch against it.  GPU (-m gpu): eamm_amd.OcclusionAwareGenerator.train() through the C ABI
+(eamm_set_training / eamm_train_begin / eamm_train_next) against it -- outputs and the running statistics left in the
+module's buffers -- on one rank, with the replicas' formula, and as two gloo ranks sharing the GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, TOL
+from eamm_amd import tiny_config
+from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict
+from oracle import eamm_oracle as orc
+
+KEYS = ("prediction", "mask", "sparse_deformed", "occlusion_map", "deformed")
+TOL_STAT = 1e-5          # running statistics (values are O(0.1..1)); the reference's own fp32 floor is ~1e-7
+DEV = "cuda:0"
+
+
+def fixture():
+    z = np.load(os.path.join(GOLDEN, "tiny64_train.npz"))
+    return z, [str(s) for s in z["norm_names"]], int(z["n"]), int(z["split"])
+
+
+def inputs(n):
+    return synthetic_source(64, seed=1, batch=n), synthetic_keypoints(n, 10, seed=0), synthetic_keypoints(n, 10, seed=2)
+
+
+def test_oracle_training_branch_matches_reference_fixture():
+    z, names, n, _ = fixture()
+    cfg, sd = tiny_config(), synthetic_state_dict(tiny_config(), seed=int(z["weight_seed"]))
+    src, kp_s, kp_d = inputs(n)
+    with torch.no_grad():
+        for tag, par in (("single", False), ("sync", True)):
+            out, stats = orc.generator_forward_train(sd, cfg, src, kp_d, kp_s, parallel=par)
+            assert sorted(stats) == sorted(names) and len(names) == 15
+            for k in KEYS:
+                assert float((out[k] - torch.from_numpy(z[f"{tag}_{k}"])).abs().max()) <= TOL[k] / 2, (tag, k)
+            for p in names:
+                assert float((stats[p][0] - torch.from_numpy(z[f"{tag}_rm/{p}"])).abs().max()) <= 1e-6
+                assert float((stats[p][1] - torch.from_numpy(z[f"{tag}_rv/{p}"])).abs().max()) <= 1e-6
+            # the statistics really are the batch's: the running statistics moved
+            assert max(float((stats[p][1] - sd[p + ".running_var"]).abs().max()) for p in names) > 1e-3
+
+
+def test_site_names_follow_execution_order():
+    """The library's BatchNorm sites are named by state_dict prefix; the module looks its BatchNorm2d holders up by them."""
+    from eamm_amd import OcclusionAwareGenerator
+    gen = OcclusionAwareGenerator(**tiny_config())
+    names = sorted(n for n, m in gen.named_modules() if isinstance(m, torch.nn.BatchNorm2d))
+    _, fix_names, _, _ = fixture()
+    assert names == sorted(fix_names)
+    gen.train()
+    with pytest.raises(RuntimeError):
+        gen.encode_source(torch.zeros(1, 3, 64, 64))       # the clip interface is the inference path
+    with pytest.raises(RuntimeError):
+        gen(torch.zeros(2, 3, 64, 64), {}, {})              # CPU module: no fallback in training mode either
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _make(cfg, seed):
+    from eamm_amd import OcclusionAwareGenerator
+    gen = OcclusionAwareGenerator(**cfg)
+    gen.load_state_dict(synthetic_state_dict(cfg, seed=seed), strict=True)
+    return gen.to(DEV)
+
+
+def _cuda(d):
+    return {k: v.to(DEV) for k, v in d.items()}
+
+
+def _check(out, gen, z, names, tag, sl=slice(None)):
+    for k in KEYS:
+        err = float((out[k].cpu() - torch.from_numpy(z[f"{tag}_{k}"])[sl]).abs().max())
+        print(f"train {tag:6s} {k:16s} max|hip - reference| = {err:.2e} (tol {TOL[k]:g})")
+        assert err <= TOL[k], (tag, k, err)
+    sd = gen.state_dict()
+    for p in names:
+        assert float((sd[p + ".running_mean"].cpu() - torch.from_numpy(z[f"{tag}_rm/{p}"])).abs().max()) <= TOL_STAT, p
+        assert float((sd[p + ".running_var"].cpu() - torch.from_numpy(z[f"{tag}_rv/{p}"])).abs().max()) <= TOL_STAT, p
+
+
+@pytest.mark.gpu
+def test_gpu_train_forward_matches_reference_fixture():
+    z, names, n, _ = fixture()
+    cfg = tiny_config()
+    src, kp_s, kp_d = inputs(n)
+    gen = _make(cfg, int(z["weight_seed"])).train()
+    out = gen(src.to(DEV), kp_source=_cuda(kp_s), kp_driving=_cuda(kp_d))
+    assert set(out) == set(KEYS) and not out["prediction"].requires_grad
+    _check(out, gen, z, names, "single")
+    # .eval() afterwards folds the UPDATED running statistics (the version counters of the buffers were bumped)
+    sd_new = {k: v.cpu() for k, v in gen.state_dict().items()}
+    gen.eval()
+    ev = gen(src.to(DEV), kp_source=_cuda(kp_s), kp_driving=_cuda(kp_d))
+    with torch.no_grad():
+        ref = orc.generator_forward(sd_new, cfg, src, kp_d, kp_s)
+    assert float((ev["prediction"].cpu() - ref["prediction"]).abs().max()) <= TOL["prediction"]
+    # the replicas' formula on one rank sees the whole batch = what the reference's two replicas compute together
+    gen = _make(cfg, int(z["weight_seed"])).train()
+    gen.sync_batchnorm = True
+    out = gen(src.to(DEV), kp_source=_cuda(kp_s), kp_driving=_cuda(kp_d))
+    _check(out, gen, z, names, "sync")
+    # a second call moves the running statistics again (momentum 0.1) and reuses the packed weights
+    rv = gen.first.norm.running_var.clone()
+    gen(src.to(DEV), kp_source=_cuda(kp_s), kp_driving=_cuda(kp_d))
+    assert float((gen.first.norm.running_var - rv).abs().max()) > 1e-4
+
+
+@pytest.mark.gpu
+def test_gpu_train_forward_full_size_against_oracle():
+    """The shipped configuration at 256x256, two pairs: every output key and three sites' running statistics vs the oracle."""
+    from eamm_amd import hot_path_config
+    cfg = hot_path_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    src, kp_s, kp_d = synthetic_source(256, seed=1, batch=2), synthetic_keypoints(2, 10, seed=0), synthetic_keypoints(2, 10, seed=2)
+    gen = _make(cfg, 1234).train()
+    out = gen(src.to(DEV), kp_source=_cuda(kp_s), kp_driving=_cuda(kp_d))
+    with torch.no_grad():
+        ref, stats = orc.generator_forward_train(sd, cfg, src, kp_d, kp_s)
+    # Batch statistics over two pairs (eight values per channel at the deepest hourglass level) amplify fp32 rounding: the
+    # REFERENCE's own fp32-vs-fp64 difference in this mode at this size is 7.9e-5 on 'prediction' and 1.6e-4 on 'deformed'
+    # (measured with the oracle in float64; evaluation mode: 3e-6 / 4e-5), so two fp32 implementations may differ by twice that.
+    tol = dict(TOL, prediction=4e-4, deformed=1e-3)
+    for k in KEYS:
+        err = float((out[k].cpu() - ref[k]).abs().max())
+        print(f"train 256 {k:16s} max|hip - oracle| = {err:.2e} (tol {tol[k]:g})")
+        assert err <= tol[k], (k, err)
+    for p in ("first.norm", "bottleneck.r5.norm2", "dense_motion_network.hourglass.encoder.down_blocks.4.norm"):
+        assert float((gen.state_dict()[p + ".running_var"].cpu() - stats[p][1]).abs().max()) <= TOL_STAT, p
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    z, names, n, split = fixture()
+    sl = slice(0, split) if rank == 0 else slice(split, n)
+    src, kp_s, kp_d = inputs(n)
+    gen = _make(tiny_config(), int(z["weight_seed"])).train()          # sync_batchnorm None: replicas because world > 1
+    out = gen(src[sl].to(DEV), kp_source=_cuda({k: v[sl] for k, v in kp_s.items()}), kp_driving=_cuda({k: v[sl] for k, v in kp_d.items()}))
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), **{k: out[k].cpu().numpy() for k in KEYS},
+             **{"rv/" + p: gen.state_dict()[p + ".running_var"].cpu().numpy() for p in names})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gpu_two_ranks_unequal_shards_match_the_reference_replicas(tmp_path):
+    """Two processes sharing GPU 0 under gloo, shards of 3 and 1 pairs: 15 all-reduces of 2C+2 floats; outputs and running
+    statistics must equal the reference's two-replica run on BOTH ranks (the reference updates its master only)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    z, names, n, split = fixture()
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in (0, 1)]
+    for k in KEYS:
+        got = np.concatenate([r[0][k], r[1][k]])
+        assert np.abs(got - z["sync_" + k]).max() <= TOL[k], k
+    for i in (0, 1):
+        for p in names:
+            assert np.abs(r[i]["rv/" + p] - z["sync_rv/" + p]).max() <= TOL_STAT, (i, p)
