@@ -34,18 +34,30 @@ struct Col7Args {
     int C, B, H, W;
     int tiles_x, tiles_y, tiles;   // tiles per row / column / in total (B * tiles_y * tiles_x)
     const float* w;        // packed [C/32][7][32][32], LDS-DMA swizzle
-    float* out;            // [B,H,W,32]
+    float* out;            // [B,H,W,32]   (plain form)
+    const float* bias;     // [3]          (fused form)
+    float* final_out;      // [B,3,H,W]    (fused form): sigmoid(7x7 convolution + bias)
 };
 
+// FUSED (round 3): the horizontal gather of the seven dx taps, the bias and the sigmoid happen in the tile's epilogue instead
+// of in final_shift_sum_kernel -- the [B,H,W,32] partial products (65.5 MB written + read back per 8 frames at 256x256)
+// never leave the CU.  Output column x needs the partial columns x-3 .. x+3, so a workgroup owns whole ROWS of tiles and
+// walks them left to right: when tile T (columns c0 .. c0+15) is finished its partial products go to LDS (the patch stage
+// that has just been consumed), the outputs of columns c0-3 .. c0+12 are formed from them and from the last six partial
+// columns of tile T-1 (a 2 x 8 KB carry ring in the last 16 KB of LDS), and columns 10..15 become the next carry.
+template <bool FUSED>
 __global__ __launch_bounds__(CWAVES * 64) void conv_col7_kernel(const Col7Args p) {
     constexpr int BK = CONV_BK;
     constexpr int A_STAGE = CPIX * BK;             // floats (44 KiB)
     constexpr int W_TAP = 32 * BK;                 // one (chunk, tap) weight tile
     constexpr int A_PIECES = CPIX / 8;             // 44
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [cchunks*7][32][32] weights, [2][A_STAGE] patches
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [cchunks*7][32][32] weights, [2][A_STAGE] patches, FUSED: [2][CARRY]
     const int cchunks = p.C / BK;
     float* const Ws = smem;
     float* const As = smem + cchunks * 7 * W_TAP;
+    constexpr int PS = 21;                         // partial products per pixel kept: (dx, co); odd stride: conflict-free column walks
+    constexpr int CARRY = CT * 6 * PS;             // six partial columns of a tile
+    float* const Carry = As + 2 * A_STAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -56,16 +68,25 @@ __global__ __launch_bounds__(CWAVES * 64) void conv_col7_kernel(const Col7Args p
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
 
-    // unit u of this workgroup = (tile first + (u / cchunks) * gridDim.x, chunk u % cchunks)
+    // unit u of this workgroup = (tile first + (u / cchunks) * gridDim.x, chunk u % cchunks); FUSED: the workgroup's items are
+    // tile ROWS (first + k * gridDim.x), each walked tile by tile from the left
     const int first = blockIdx.x;
-    const int my_tiles = first < p.tiles ? (p.tiles - first + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    const int units = my_tiles * cchunks;
+    const int items = FUSED ? p.B * p.tiles_y : p.tiles;
+    const int my_items = first < items ? (items - first + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int units = my_items * (FUSED ? p.tiles_x : 1) * cchunks;
     auto tile_of = [&](int u, int& b, int& ty0, int& tx0, int& cc) {
         const int k = u / cchunks;
         cc = u - k * cchunks;
-        int t = first + k * (int)gridDim.x;
-        tx0 = (t % p.tiles_x) * CT;
-        t /= p.tiles_x;
+        int t;
+        if constexpr (FUSED) {
+            const int r = k / p.tiles_x;
+            tx0 = (k - r * p.tiles_x) * CT;
+            t = first + r * (int)gridDim.x;
+        } else {
+            t = first + k * (int)gridDim.x;
+            tx0 = (t % p.tiles_x) * CT;
+            t /= p.tiles_x;
+        }
         ty0 = (t % p.tiles_y) * CT;
         b = t / p.tiles_y;
     };
@@ -133,14 +154,59 @@ __global__ __launch_bounds__(CWAVES * 64) void conv_col7_kernel(const Col7Args p
             }
         });
         if (cc == cchunks - 1) {
-            // epilogue of the tile: lanes 0..31 of a wave hold the 32 channels of one pixel -> 128-byte rows
-            static_for<16>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;   // pixel of the wave's 32: row m / 16, column m % 16
-                const int y = ty0 + 2 * wave + (m >> 4), x = tx0 + (m & 15);
-                if (y < p.H && x < p.W) p.out[((size_t)(b * p.H + y) * p.W + x) * 32 + l31] = acc[r];
-                acc[r] = 0.f;
-            });
+            if constexpr (!FUSED) {
+                // epilogue of the tile: lanes 0..31 of a wave hold the 32 channels of one pixel -> 128-byte rows
+                static_for<16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;   // pixel of the wave's 32: row m / 16, column m % 16
+                    const int y = ty0 + 2 * wave + (m >> 4), x = tx0 + (m & 15);
+                    if (y < p.H && x < p.W) p.out[((size_t)(b * p.H + y) * p.W + x) * 32 + l31] = acc[r];
+                    acc[r] = 0.f;
+                });
+            } else {
+                // every wave is done with this unit's patch stage (the next unit reads the other one; its refill starts inside
+                // the next unit): it becomes the scratch for the tile's partial products P[row][column][dx*3 + co]
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                float* const scratch = As + st * A_STAGE;
+                static_for<16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int row = 2 * wave + (m >> 4), col = m & 15;
+                    if (l31 < PS) scratch[(row * CT + col) * PS + l31] = acc[r];
+                    acc[r] = 0.f;
+                });
+                __syncthreads();
+                const int tix = tx0 / CT;
+                const bool last = tix == p.tiles_x - 1;
+                const float* carry_in = Carry + (tix & 1) * CARRY;          // columns tx0-6 .. tx0-1 (from tile T-1)
+                float* carry_out = Carry + ((tix + 1) & 1) * CARRY;
+                const int ncol = last ? CT + 3 : CT;                          // the row's last tile also finishes its last three columns
+                for (int i = tid; i < 3 * CT * ncol; i += CWAVES * 64) {
+                    const int xl = i % ncol, t2 = i / ncol;
+                    const int row = t2 % CT, co = t2 / CT;
+                    const int x = tx0 - 3 + xl, y = ty0 + row;
+                    if (x < 0 || x >= p.W || y >= p.H) continue;
+                    float v = p.bias[co];
+#pragma unroll
+                    for (int dx = 0; dx < 7; ++dx) {
+                        const int c = xl - 6 + dx;                            // partial column relative to tx0: x + dx - 3 - tx0
+                        float pv = 0.f;
+                        if (c >= 0) {
+                            if (c < CT) pv = scratch[(row * CT + c) * PS + dx * 3 + co];          // (c >= 16: beyond the row's last tile: zero padding)
+                        } else if (tix > 0) {
+                            pv = carry_in[(row * 6 + c + 6) * PS + dx * 3 + co];                   // (tix == 0: left of the image: zero padding)
+                        }
+                        v += pv;
+                    }
+                    p.final_out[(((size_t)b * 3 + co) * p.H + y) * p.W + x] = 1.f / (1.f + __expf(-v));
+                }
+                for (int i = tid; i < CARRY; i += CWAVES * 64) {                // columns 10..15 -> the next tile's carry
+                    const int n = i % PS, t2 = i / PS;
+                    const int c6 = t2 % 6, row = t2 / 6;
+                    carry_out[i] = scratch[(row * CT + 10 + c6) * PS + n];
+                }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -304,8 +370,9 @@ hipError_t conv_col7s_launch(const float* in0, int C0, const float* in1, int C1,
     return hipGetLastError();
 }
 
-hipError_t conv_col7_launch(const float* in, int C, int B, int H, int W, const float* w_swizzled, float* out,
-                            hipStream_t stream) {
+static hipError_t col7_launch_impl(const float* in, int C, int B, int H, int W, const float* w_swizzled, float* out, const float* bias,
+                                   float* final_out, hipStream_t stream) {
+    const bool fused = final_out != nullptr;
     if (C % CONV_BK || C / CONV_BK > CMAXCH || C < CONV_BK) return hipErrorInvalidValue;
     Col7Args a{};
     a.in = in;
@@ -322,17 +389,36 @@ hipError_t conv_col7_launch(const float* in, int C, int B, int H, int W, const f
     a.tiles = B * a.tiles_x * a.tiles_y;
     a.w = w_swizzled;
     a.out = out;
-    const size_t lds = wb + sizeof(float) * 2 * CPIX * CONV_BK;
+    a.bias = bias;
+    a.final_out = final_out;
+    const size_t lds = wb + sizeof(float) * (2 * CPIX * CONV_BK + (fused ? 2 * CT * 6 * 21 : 0));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static lds_once_mask configured{0};
-    if (hipError_t e = ensure_dynamic_lds(conv_col7_kernel, 160 * 1024, &configured); e != hipSuccess) return e;
+    static lds_once_mask configured{0}, configured_fused{0};
+    if (hipError_t e = fused ? ensure_dynamic_lds(conv_col7_kernel<true>, 160 * 1024, &configured_fused)
+                             : ensure_dynamic_lds(conv_col7_kernel<false>, 160 * 1024, &configured);
+        e != hipSuccess)
+        return e;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int blocks = std::min(a.tiles, cus);
+    const int blocks = std::min(fused ? B * a.tiles_y : a.tiles, cus);
     note_mfma_flops(2.0 * a.tiles * (CT * CT) * 7.0 * 32 * C);
-    hipLaunchKernelGGL(conv_col7_kernel, dim3(blocks), dim3(CWAVES * 64), lds, stream, a);
+    if (fused)
+        hipLaunchKernelGGL(conv_col7_kernel<true>, dim3(blocks), dim3(CWAVES * 64), lds, stream, a);
+    else
+        hipLaunchKernelGGL(conv_col7_kernel<false>, dim3(blocks), dim3(CWAVES * 64), lds, stream, a);
     return hipGetLastError();
+}
+
+hipError_t conv_col7_launch(const float* in, int C, int B, int H, int W, const float* w_swizzled, float* out,
+                            hipStream_t stream) {
+    return col7_launch_impl(in, C, B, H, W, w_swizzled, out, nullptr, nullptr, stream);
+}
+
+hipError_t conv_col7_fused_launch(const float* in, int C, int B, int H, int W, const float* w_swizzled, const float* bias,
+                                  float* out_nchw, hipStream_t stream) {
+    if (!bias || !out_nchw) return hipErrorInvalidValue;
+    return col7_launch_impl(in, C, B, H, W, w_swizzled, nullptr, bias, out_nchw, stream);
 }
 
 }  // namespace eamm

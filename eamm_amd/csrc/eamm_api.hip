@@ -117,6 +117,8 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->wino_variant = env_int("EAMM_WINO_VARIANT", c->wino_variant);   // pipeline variant of wino_gemm_kernel (EAMM_WINO_MIN_M < 0 disables the Winograd bottleneck)
     c->wino_tile = env_int("EAMM_WINO_TILE", c->wino_tile);
     c->col7 = env_int("EAMM_COL7", c->col7);
+    c->final_fused = env_int("EAMM_FINAL_FUSED", c->final_fused);
+    c->final_fused_min_rows = env_int("EAMM_FINAL_FUSED_MIN_ROWS", c->final_fused_min_rows);
     c->bneck_chains = env_int("EAMM_BNECK_CHAINS", c->bneck_chains);
     c->pass_chains = env_int("EAMM_PASS_CHAINS", c->pass_chains);
     // clamped ONCE, here: negative = off (as the other knobs), at most four chains; the split-K slab count and the runtime
@@ -895,11 +897,19 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         io.partial_cap = v.partial_elems;
         ConvLayer fl = c->final_conv;
         fl.Cout = 32;  // 32-float pixel stride; channels >= 21 have zero weights
-        if (c->final_w_swz && fl.BN == 32)
-            HIP_TRY(c, conv_col7_launch(cur, fl.C0, n, c->H, c->W, c->final_w_swz, v.final_part, s));
-        else
-            HIP_TRY(c, conv_launch(fl, io, s));
-        HIP_TRY(c, final_shift_sum_launch(v.final_part, c->final_bias, n, c->H, c->W, v.out.prediction, s));
+        // fused form: one workgroup per ROW of 16x16 tiles -- only when those rows fill at least half the chip (measured
+        // 256x256: 16 frames 0.289 -> 0.283 ms per step, 65 MB written + read back per 8 frames gone; ONE frame has 16 tile rows:
+        // 0.029 -> 0.262 ms, so small calls keep the two-kernel form)
+        if (c->final_w_swz && fl.BN == 32 && c->final_fused && n * ((c->H + 15) / 16) >= c->final_fused_min_rows) {
+            // gather of the seven horizontal taps + bias + sigmoid in the column-patch kernel's tile epilogue (round 3)
+            HIP_TRY(c, conv_col7_fused_launch(cur, fl.C0, n, c->H, c->W, c->final_w_swz, c->final_bias, v.out.prediction, s));
+        } else {
+            if (c->final_w_swz && fl.BN == 32)
+                HIP_TRY(c, conv_col7_launch(cur, fl.C0, n, c->H, c->W, c->final_w_swz, v.final_part, s));
+            else
+                HIP_TRY(c, conv_launch(fl, io, s));
+            HIP_TRY(c, final_shift_sum_launch(v.final_part, c->final_bias, n, c->H, c->W, v.out.prediction, s));
+        }
     }
     if (v.out.frames_u8) HIP_TRY(c, to_u8_launch(v.out.prediction, n, c->H, c->W, v.out.frames_u8, s));
     c->call_flops += take_mfma_flops();
@@ -1148,6 +1158,41 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
     DeviceGuard guard(device);
     if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (tile_n == 4002) {   // the final layer whole: 7x7, 3 output channels, bias, sigmoid -> NCHW, on the fused column-patch kernel
+        if (kh != 7 || kw != 7 || Cout != 3 || act != 2 || up || pool || resid || C1 || C0 % 32 || C0 > 64 || C0 < 32)
+            return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv: unsupported fused final-layer configuration");
+        std::vector<float> wr((size_t)21 * C0 * 7), packed(conv_packed_elems(7, C0, 21, 32, 1));
+        for (int dx = 0; dx < 7; ++dx)          // w'[dx*3+co][c][dy] = w[co][c][dy][dx]  (MODE_ROWSPLIT of build_layer)
+            for (int co = 0; co < 3; ++co)
+                for (int ci = 0; ci < C0; ++ci)
+                    for (int dy = 0; dy < 7; ++dy)
+                        wr[((size_t)(dx * 3 + co) * C0 + ci) * 7 + dy] = w_host[((size_t)co * C0 + ci) * 49 + dy * 7 + dx];
+        conv_pack_host(wr.data(), 21, C0, 7, 1, nullptr, C0, 32, false, true, packed.data());
+        float *wd = nullptr, *bd = nullptr;
+        hipError_t e = hipMalloc((void**)&wd, packed.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&bd, 3 * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(wd, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(bd, b_host, 3 * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = conv_col7_fused_launch(in0, C0, B, Hin, Win, wd, bd, out, s);
+        if (e == hipSuccess && iters > 0 && avg_ms) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, s);
+            for (int i = 0; i < iters && e == hipSuccess; ++i) e = conv_col7_fused_launch(in0, C0, B, Hin, Win, wd, bd, out, s);
+            (void)hipEventRecord(e1, s);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            *avg_ms = ms / iters;
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (wd) (void)hipFree(wd);
+        if (bd) (void)hipFree(bd);
+        return e == hipSuccess ? EAMM_OK : fail(nullptr, EAMM_ERR_HIP, "fused final layer failed: %s", hipGetErrorString(e));
+    }
     if (tile_n == 4000 || tile_n == 4001) {  // column-patch kernels of the 7x1 convolutions: 4000 final layer (Cout = the 32-float
         // pixel stride, weights resident), 4001 flow head (two inputs, Cout = 96, streamed weights); no bias (the gather kernels add it)
         const bool streamed = tile_n == 4001;

@@ -60,6 +60,8 @@ struct eamm_ctx : eamm::CtxBase {
     float* final_part = nullptr;   // [F,H,W,32] (dx,co) partial products of the final 7x7 conv
     float* final_w_swz = nullptr;  // the 7x1 weights in LDS-DMA layout for the column-patch kernel (conv_col7.hip)
     int col7 = 1;                  // EAMM_COL7: 0 = im2col-style kernel for the final convolution
+    int final_fused = 1;           // EAMM_FINAL_FUSED: 0 = partial products to HBM + final_shift_sum_kernel (round 2)
+    int final_fused_min_rows = 128; // ... from this many rows of 16x16 tiles per call (EAMM_FINAL_FUSED_MIN_ROWS)
     int head_col7_min_tiles = 128; // fewest 16x16 tiles for which the flow head uses the column-patch kernel (EAMM_HEAD_COL7_MIN_TILES)
 
     // source cache (exportable): feat [S,hf,wf,Cb], src_small [S,h,w,4], src_full [S,3,H,W]

@@ -112,6 +112,10 @@ hipError_t patch_phase_launch(const PatchLayer& L, const float* in0, const float
 // w = conv_pack_host(..., kh 7, kw 1, BN 32, swizzle) image [C/32][7][32][32], out [B,H,W,32]
 hipError_t conv_col7_launch(const float* in, int C, int B, int H, int W, const float* w_swizzled, float* out,
                             hipStream_t stream);
+// the same with the horizontal gather, bias and sigmoid in the tile epilogue: out_nchw [B,3,H,W] = sigmoid(conv7x7 + bias)
+// (weights: the row-split image above built from a 3-output-channel 7x7 filter, bias [3] on the device)
+hipError_t conv_col7_fused_launch(const float* in, int C, int B, int H, int W, const float* w_swizzled, const float* bias,
+                                  float* out_nchw, hipStream_t stream);
 
 // streamed-weight variant for the row-split flow head: two concatenated inputs, N = ntile32*32 (3 -> 96), weights packed with
 // conv_pack_host(..., kh 7, kw 1, BN 96, swizzle); out [B,H,W,pixel_stride]

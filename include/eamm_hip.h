@@ -326,7 +326,7 @@ int eamm_profile_read(eamm_ctx* ctx, double* stage_ms, int nstage, int64_t* call
  * collapsed four-phase 2x2 form; act: 0 none, 1 relu, 2 sigmoid; pool = 1 applies avgpool2x2 after the
  * activation; resid: NHWC tensor added before the activation; splitk 0 = automatic; tile_n 0 =
  * automatic, 32/64/128 = register-staged 128 x tile_n kernel, 1000+id = LDS-DMA big-tile kernel (1: 256x256,
- * 2: 256x128, 3: 512x64), 2000 = Winograd F(2x2,3x3) (input transform + GEMM; 3x3, single input, no pool); out NHWC [B,H(/2),W(/2),Cout] with H = Hin << up.  iters > 0 additionally times `iters`
+ * 2: 256x128, 3: 512x64), 4002 = the generator's final layer whole (7x7, Cout 3, act 2: out is NCHW [B,3,H,W]), 2000 = Winograd F(2x2,3x3) (input transform + GEMM; 3x3, single input, no pool); out NHWC [B,H(/2),W(/2),Cout] with H = Hin << up.  iters > 0 additionally times `iters`
  * back-to-back launches with HIP events on `stream` and stores the average milliseconds in *avg_ms. */
 int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1, int B, int Hin, int Win, int up,
                  const float* weight_host, const float* bias_host, int Cout, int kh, int kw,

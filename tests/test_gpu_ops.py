@@ -244,3 +244,33 @@ def test_warp_zero_padding_is_exact_beside_a_non_finite_border_pixel():
     fin = torch.isfinite(want)
     assert torch.equal(torch.isfinite(got), fin)
     assert float((got[fin] - want[fin]).abs().max()) <= 2e-5 * max(1.0, float(want[fin].abs().max()))
+
+
+# ---- the generator's final layer whole: 7x7 conv (64 -> 3) + bias + sigmoid on the fused column-patch kernel (round 3) ------
+@pytest.mark.parametrize("name,B,H,W,C", [
+    ("one_tile_row", 1, 16, 64, 64),          # tiles_y = 1: four tiles walked left to right, carries between them
+    ("final_like", 2, 64, 64, 64),
+    ("one_chunk", 1, 32, 48, 32),
+    ("ragged", 3, 20, 24, 64),                # H, W not multiples of the 16x16 tile: partial last tile in both directions
+    ("narrow", 2, 40, 12, 64),                # one tile per row: first and last at once
+    ("many_rows", 5, 128, 128, 64),           # more tile rows (40) than ... not than CUs; several images
+    ("more_rows_than_cus", 20, 256, 16, 32),  # 320 tile rows on <= 256 persistent workgroups: a workgroup walks two rows
+])
+def test_fused_final_layer_matches_torch(name, B, H, W, C):
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(3, C, 7, 7, generator=g) * (2.0 / (C * 49)) ** 0.5
+    b = 0.1 * torch.randn(3, generator=g)
+    want = torch.sigmoid(F.conv2d(x, w, b, padding=3))
+    dev = torch.device("cuda:0")
+    xd = nhwc(x).to(dev)
+    out = torch.full((B, 3, H, W), float("nan"), device=dev)
+    wc, bc = w.contiguous(), b.contiguous()
+    rc = _lib.lib().eamm_op_conv(0, xd.data_ptr(), C, None, 0, B, H, W, 0, wc.data_ptr(), bc.data_ptr(), 3, 7, 7, 2, 0, None, 0, 4002,
+                                 out.data_ptr(), 0, None, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, None)
+    got = out.cpu()
+    assert torch.isfinite(got).all(), "output has unwritten / non-finite elements"
+    err = float((got - want).abs().max())
+    print(f"fused final {name}: max|hip - torch| = {err:.2e}")
+    assert err <= 2e-6, (name, err)
