@@ -5,6 +5,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
+ROUND=${ROUND:-r03}
 SIZE=${1:-256}; BATCH=${2:-16}; TAG=${3:-${SIZE}_b${BATCH}}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
@@ -19,7 +20,7 @@ pmc write WRITE_SIZE
 pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES
 pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU
 CHAINS=$(python -c "import json;print(json.load(open('$O/bench_under_kernel_trace.json'))['roofline'].get('chains',1))" 2>/dev/null || echo 1)
-python tools/pmc_traffic.py $O/fetch/fetch_results.db $O/write/write_results.db $SIZE $BATCH "profiles/r02_${SIZE}_b${BATCH}_pmc_{fetch,write}.txt" $O/pmc_traffic.json $CHAINS > $O/pmc_traffic.log 2>&1
+python tools/pmc_traffic.py $O/fetch/fetch_results.db $O/write/write_results.db $SIZE $BATCH "profiles/${ROUND}_${SIZE}_b${BATCH}_pmc_{fetch,write}.txt" $O/pmc_traffic.json $CHAINS > $O/pmc_traffic.log 2>&1
 # only gpurun_out/ travels back and it is capped at 64 MiB: keep the text summaries, drop the raw rocprofv3 databases
 rm -rf $O/kt $O/fetch $O/write $O/sq $O/lds
 head -30 $O/kernel_trace_stats.txt; cat $O/pmc_traffic.log

@@ -9,12 +9,12 @@ from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_st
 
 cfg = hot_path_config()
 sd = synthetic_state_dict(cfg)
-for cache in (False, True):
+for cache in (False, True, False, True):   # each setting twice: the first pass of a process also pays allocator warm-up
     gen = OcclusionAwareGenerator(**cfg, cache_source=cache); gen.load_state_dict(sd); gen = gen.cuda().eval()
     src = synthetic_source(256).cuda()
     kp_s = {k: v.cuda() for k, v in synthetic_keypoints(1, 10, seed=0).items()}
     kps = [{k: v.cuda() for k, v in synthetic_keypoints(1, 10, seed=2 + t).items()} for t in range(64)]
-    for t in range(4): gen(src, kp_source=kp_s, kp_driving=kps[t])
+    for t in range(16): gen(src, kp_source=kp_s, kp_driving=kps[t])
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for t in range(64):
         out = gen(src, kp_source=kp_s, kp_driving=kps[t])
