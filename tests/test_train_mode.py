@@ -170,3 +170,35 @@ def test_gpu_two_ranks_unequal_shards_match_the_reference_replicas(tmp_path):
     for i in (0, 1):
         for p in names:
             assert np.abs(r[i]["rv/" + p] - z["sync_rv/" + p]).max() <= TOL_STAT, (i, p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["no_jacobian", "no_motion_network", "one_pair_more_than_max_frames"])
+def test_gpu_train_forward_variants_against_oracle(variant):
+    """Branches of the forward in training mode against the oracle's training branch: key points without jacobians
+    (dense_motion.py:55), a generator built without a motion network (generator.py:22-23), and a batch larger than the
+    module's max_frames (the training engine is re-created for it)."""
+    cfg = tiny_config()
+    n = 3
+    if variant == "no_motion_network":
+        cfg = dict(cfg, dense_motion_params=None, estimate_occlusion_map=False)
+    if variant == "one_pair_more_than_max_frames":
+        n = 5
+    sd = synthetic_state_dict(cfg, seed=77)
+    src = synthetic_source(64, seed=3, batch=n)
+    kp_s = synthetic_keypoints(n, 10, seed=4, jacobian=variant != "no_jacobian")
+    kp_d = synthetic_keypoints(n, 10, seed=5, jacobian=variant != "no_jacobian")
+    from eamm_amd import OcclusionAwareGenerator
+    gen = OcclusionAwareGenerator(**cfg, max_frames=4)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).train()
+    out = gen(src.to(DEV), kp_source=_cuda(kp_s), kp_driving=_cuda(kp_d))
+    with torch.no_grad():
+        ref, stats = orc.generator_forward_train(sd, cfg, src, kp_d, kp_s)
+    keys = ("prediction",) if variant == "no_motion_network" else ("prediction", "mask", "sparse_deformed", "deformed")
+    assert set(out) >= set(keys)
+    for k in keys:
+        assert float((out[k].cpu() - ref[k]).abs().max()) <= TOL[k], (variant, k)
+    new = gen.state_dict()
+    for p in stats:
+        assert float((new[p + ".running_var"].cpu() - stats[p][1]).abs().max()) <= TOL_STAT, (variant, p)
