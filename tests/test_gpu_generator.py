@@ -395,3 +395,28 @@ def test_chained_bottleneck_graph_capture_and_equivalence(monkeypatch):
     assert e1.bottleneck_chains(16) == 1
     one = e1.forward_frames(kd, ks)["prediction"]
     assert float((one - ref).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("n", [9, 11, 13])
+def test_odd_frame_counts_across_the_chain_thresholds(n):
+    """Calls whose frame count straddles the launch-plan switches at 256x256: 9 frames (bottleneck chains only), 11 and 13
+    (two whole-pass chains of UNEQUAL length: 6 + 5, 7 + 6).  First, middle and last frame of each call against the oracle,
+    and every frame against the same frames computed in a 16-frame call (frames are independent: launch plans must not
+    change them beyond rounding)."""
+    from eamm_amd import hot_path_config as hot
+    cfg = hot()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    gen = OcclusionAwareGenerator(**cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    src, kp_s, kp_d = synthetic_source(256, seed=1), synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(16, 10, seed=2)
+    eng = gen.encode_source(src.to(DEV), max_frames=16)
+    kd, ks = cuda(kp_d), cuda(kp_s)
+    full = eng.forward_frames(kd, ks)["prediction"].clone()
+    part = eng.forward_frames({k: v[:n] for k, v in kd.items()}, ks)["prediction"]
+    assert part.shape[0] == n
+    assert float((part - full[:n]).abs().max()) <= 2e-5
+    for t in (0, n // 2, n - 1):
+        with torch.no_grad():
+            ref = orc.generator_forward(sd, cfg, src, {k: v[t:t + 1] for k, v in kp_d.items()}, kp_s)["prediction"]
+        assert float((part[t].cpu() - ref[0]).abs().max()) <= TOL["prediction"], (n, t)

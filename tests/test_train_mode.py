@@ -202,3 +202,39 @@ def test_gpu_train_forward_variants_against_oracle(variant):
     new = gen.state_dict()
     for p in stats:
         assert float((new[p + ".running_var"].cpu() - stats[p][1]).abs().max()) <= TOL_STAT, (variant, p)
+
+
+TRAIN_VARIANTS = {
+    # name: (config overrides, dense_motion overrides, H, W) -- the constructor variants of tests/test_gpu_generator.py
+    "rect_64x96": ({}, {}, 64, 96),
+    "scale_half": ({}, {"scale_factor": 0.5}, 64, 64),
+    "no_occlusion": ({"estimate_occlusion_map": False}, {}, 64, 64),
+    "three_down": ({"num_down_blocks": 3, "max_features": 256}, {}, 64, 64),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(TRAIN_VARIANTS))
+def test_gpu_train_forward_constructor_variants(name):
+    over, dm_over, H, W = TRAIN_VARIANTS[name]
+    cfg = tiny_config()
+    cfg.update(over)
+    cfg["dense_motion_params"] = {**cfg["dense_motion_params"], **dm_over}
+    sd = synthetic_state_dict(cfg, seed=4321)
+    from eamm_amd import OcclusionAwareGenerator
+    gen = OcclusionAwareGenerator(**cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).train()
+    n = 3
+    rs = np.random.RandomState(11)
+    src = torch.from_numpy(rs.uniform(0, 1, (n, 3, H, W)).astype(np.float32))
+    kp_s, kp_d = synthetic_keypoints(n, 10, seed=0), synthetic_keypoints(n, 10, seed=2)
+    out = gen(src.to(DEV), kp_source=_cuda(kp_s), kp_driving=_cuda(kp_d))
+    with torch.no_grad():
+        ref, stats = orc.generator_forward_train(sd, cfg, src, kp_d, kp_s)
+    for k in out:
+        assert out[k].shape == ref[k].shape
+        assert float((out[k].cpu() - ref[k]).abs().max()) <= 2 * TOL[k], (name, k)     # small batches: twice the evaluation bars
+    new = gen.state_dict()
+    for p in stats:
+        assert float((new[p + ".running_mean"].cpu() - stats[p][0]).abs().max()) <= TOL_STAT, (name, p)
