@@ -121,6 +121,11 @@ SIGNATURES = {
     "eamm_train_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "eamm_op_warp": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "eamm_op_warp_backward": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eamm_op_conv_wgrad_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "eamm_op_conv_wgrad": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

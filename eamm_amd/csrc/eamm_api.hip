@@ -1463,4 +1463,43 @@ int eamm_op_warp(int device, const float* feat, const float* deformation, const 
     return EAMM_OK;
 }
 
+int eamm_op_warp_backward(int device, const float* feat, const float* deformation, const float* occlusion, const float* grad_out,
+                          int n, int ns, int hf, int wf, int C, float* grad_feat, float* grad_deformation, float* grad_occlusion,
+                          void* stream_) {
+    if (!feat || !deformation || !grad_out || n < 1 || (ns != 1 && ns != n) || hf < 1 || wf < 1 || C < 4 || (C & 3) ||
+        (!grad_feat && !grad_deformation && !grad_occlusion) || (grad_occlusion && !occlusion))
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_warp_backward: bad argument");
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    // the kernel accumulates: the gradients start from zero here, on the caller's stream
+    hipError_t e = hipSuccess;
+    if (grad_feat) e = hipMemsetAsync(grad_feat, 0, (size_t)ns * hf * wf * C * sizeof(float), s);
+    if (e == hipSuccess && grad_deformation) e = hipMemsetAsync(grad_deformation, 0, (size_t)n * hf * wf * 2 * sizeof(float), s);
+    if (e == hipSuccess && grad_occlusion) e = hipMemsetAsync(grad_occlusion, 0, (size_t)n * hf * wf * sizeof(float), s);
+    if (e == hipSuccess)
+        e = warp_features_backward_launch(feat, deformation, occlusion, grad_out, n, ns, hf, wf, C, grad_feat, grad_deformation,
+                                          grad_occlusion, s);
+    if (e != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "eamm_op_warp_backward failed: %s", hipGetErrorString(e));
+    return EAMM_OK;
+}
+
+size_t eamm_op_conv_wgrad_workspace_floats(int Cin, int Cout, int kh, int kw) {
+    if (Cin < 1 || Cout < 1 || kh < 1 || kw < 1) return 0;
+    return conv_wgrad_workspace_floats(Cin, Cout, kh, kw);
+}
+
+int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                       float* grad_weight, float* grad_bias, float* workspace, size_t workspace_floats, void* stream_) {
+    if (!x || !grad_out || !grad_weight || !workspace || B < 1 || H < 1 || W < 1 || Cin < 4 || Cout < 4 || (Cin & 3) || (Cout & 3) ||
+        kh < 1 || kw < 1 || !(kh & 1) || !(kw & 1) || kh > 7 || kw > 7)
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv_wgrad: bad argument (channels multiples of 4, odd filter up to 7x7)");
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
+    hipError_t e = conv_wgrad_launch(x, grad_out, B, H, W, Cin, Cout, kh, kw, grad_weight, grad_bias, workspace, workspace_floats,
+                                     reinterpret_cast<hipStream_t>(stream_));
+    if (e != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "eamm_op_conv_wgrad failed: %s", hipGetErrorString(e));
+    return EAMM_OK;
+}
+
 }  // extern "C"

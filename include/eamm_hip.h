@@ -341,6 +341,31 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
 int eamm_op_warp(int device, const float* feat, const float* deformation, const float* occlusion, int n, int ns, int hf,
                  int wf, int C, int h, int w, float* out, int iters, float* avg_ms, void* stream);
 
+/*
+ * Backward kernels of the path's two operator kinds, op level.  The reference gets these from
+ * autograd (train.py:133 `loss.backward()` through modules/generator.py and modules/util.py); the BatchNorm backward is
+ * eamm_bn_backward_* above.
+ */
+
+/* Gradient of eamm_op_warp at (h,w) == (hf,wf): grad_out NHWC [n,hf,wf,C] -> grad_feat [ns,hf,wf,C] (ns = 1: summed over the
+ * frames), grad_deformation [n,hf,wf,2], grad_occlusion [n,hf,wf]; any of the three may be NULL (not wanted), occlusion NULL
+ * means the forward had none.  What autograd derives for F.grid_sample(bilinear, zeros, align_corners=False) * occlusion
+ * (generator.py:50-57, 79-84).  The entry zeroes the gradients on `stream`, then accumulates with float atomics (grad_feat is
+ * therefore equal to the fixed-order sum up to fp32 rounding of the order, as ATen's own grid_sampler backward is). */
+int eamm_op_warp_backward(int device, const float* feat, const float* deformation, const float* occlusion, const float* grad_out,
+                          int n, int ns, int hf, int wf, int C, float* grad_feat, float* grad_deformation, float* grad_occlusion,
+                          void* stream);
+
+/* Weight and bias gradient of a stride-1 "same" KHxKW convolution (every Conv2d of modules/util.py:858-938): x NHWC
+ * [B,H,W,Cin], grad_out NHWC [B,H,W,Cout] -> grad_weight OIHW [Cout,Cin,kh,kw] (device), grad_bias [Cout] (device, or NULL).
+ * One fp32-MFMA GEMM per filter tap, K = the B*H*W pixels split over workgroups, partial sums in `workspace`
+ * (eamm_op_conv_wgrad_workspace_floats floats) and summed in a fixed order: deterministic.  Cin, Cout multiples of 4; kh, kw
+ * odd and at most 7.  The DATA gradient of such a convolution is eamm_op_conv on grad_out with the filter transposed and
+ * flipped (weight.permute(1,0,2,3).flip(2,3)), which eamm_amd/autograd_ops.py does. */
+size_t eamm_op_conv_wgrad_workspace_floats(int Cin, int Cout, int kh, int kw);
+int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                       float* grad_weight, float* grad_bias, float* workspace, size_t workspace_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,170 @@
+"""Backward kernels of the path's operator kinds against torch-CPU autograd of the reference's
+ops: F.grid_sample(...) * occlusion (reference modules/generator.py:50-57, 79-84) and F.conv2d (modules/util.py:858-938).
+Through the C ABI (eamm_op_warp_backward, eamm_op_conv_wgrad, eamm_op_conv) via eamm_amd.autograd_ops."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from eamm_amd import _lib, autograd_ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _identity_grid(n, h, w):
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, h), torch.linspace(-1, 1, w), indexing="ij")
+    return torch.stack([xs, ys], -1)[None].expand(n, -1, -1, -1)
+
+
+def _warp_inputs(n, ns, h, w, c, occ, seed, spread=0.3):
+    g = torch.Generator().manual_seed(seed)
+    feat = torch.randn(ns, c, h, w, generator=g)
+    defo = _identity_grid(n, h, w) + spread * torch.randn(n, h, w, 2, generator=g)   # some samples leave the map: zero padding
+    om = torch.rand(n, 1, h, w, generator=g) if occ else None
+    gout = torch.randn(n, c, h, w, generator=g)
+    return feat, defo, om, gout
+
+
+def _warp_reference(feat, defo, om, gout):
+    f, d = feat.double().requires_grad_(), defo.double().requires_grad_()
+    o = om.double().requires_grad_() if om is not None else None
+    src = f if f.shape[0] == d.shape[0] else f.expand(d.shape[0], -1, -1, -1)
+    y = F.grid_sample(src, d, mode="bilinear", padding_mode="zeros", align_corners=False)
+    if o is not None:
+        y = y * o
+    y.backward(gout.double())
+    return y.detach(), f.grad, d.grad, (o.grad if o is not None else None)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("one_source", dict(n=3, ns=1, h=16, w=16, c=64, occ=True, seed=0)),
+    ("per_frame_source", dict(n=2, ns=2, h=12, w=20, c=32, occ=True, seed=1)),
+    ("no_occlusion", dict(n=2, ns=1, h=16, w=16, c=256, occ=False, seed=2)),
+    ("wide_channels", dict(n=1, ns=1, h=8, w=8, c=512, occ=True, seed=3)),          # 128 lanes per pixel: no in-wave reduction
+    ("odd_channel_groups", dict(n=2, ns=2, h=10, w=6, c=24, occ=True, seed=4)),      # 6 lanes per pixel: not a power of two
+    ("generator_shape", dict(n=2, ns=1, h=64, w=64, c=256, occ=True, seed=5, spread=0.1)),
+])
+def test_warp_backward_matches_autograd(name, kw):
+    feat, defo, om, gout = _warp_inputs(**kw)
+    want_y, want_f, want_d, want_o = _warp_reference(feat, defo, om, gout)
+    f = feat.to(DEV).requires_grad_()
+    d = defo.to(DEV).requires_grad_()
+    o = om.to(DEV).requires_grad_() if om is not None else None
+    y = autograd_ops.warp(f, d, o)
+    y.backward(gout.to(DEV))
+    torch.cuda.synchronize()
+
+    def rel(got, want):
+        return float((got.detach().cpu().double() - want).abs().max()) / max(1.0, float(want.abs().max()))
+
+    errs = {"out": rel(y, want_y), "d_feat": rel(f.grad, want_f), "d_flow": rel(d.grad, want_d)}
+    if om is not None:
+        errs["d_occ"] = rel(o.grad, want_o)
+    print(f"warp backward {name}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    # fp32 kernel vs float64 autograd (the sample coordinate itself rounds at 2^-24 * W); d_flow carries the W/2 factor and a difference of corner values
+    assert errs["out"] <= 1e-5 and errs["d_feat"] <= 5e-6 and errs["d_flow"] <= 2e-5, (name, errs)
+    assert errs.get("d_occ", 0.0) <= 1e-5, (name, errs)
+
+
+def test_warp_backward_of_out_of_range_samples_is_zero():
+    # every sample outside the map by more than a pixel: zero output, zero gradients, nothing non-finite
+    n, h, w, c = 2, 8, 8, 32
+    feat = torch.randn(1, c, h, w)
+    defo = torch.full((n, h, w, 2), 1.9)
+    om = torch.rand(n, 1, h, w)
+    f, d, o = feat.to(DEV).requires_grad_(), defo.to(DEV).requires_grad_(), om.to(DEV).requires_grad_()
+    y = autograd_ops.warp(f, d, o)
+    y.backward(torch.ones_like(y))
+    for t in (y, f.grad, d.grad, o.grad):
+        assert float(t.detach().abs().max()) == 0.0
+
+
+def test_warp_backward_partial_gradients():
+    # only the flow needs a gradient (the dense-motion branch with a detached source): the other outputs are not computed
+    feat, defo, om, gout = _warp_inputs(2, 1, 16, 16, 64, True, 7)
+    _, _, want_d, _ = _warp_reference(feat, defo, om, gout)
+    d = defo.to(DEV).requires_grad_()
+    y = autograd_ops.warp(feat.to(DEV), d, om.to(DEV))
+    y.backward(gout.to(DEV))
+    assert float((d.grad.cpu().double() - want_d).abs().max()) <= 2e-5 * max(1.0, float(want_d.abs().max()))
+
+
+CONV_CASES = {
+    # the generator's layer shapes at reduced extents
+    "3x3_64_64":     dict(B=2, H=16, W=16, cin=64, cout=64, k=3, bias=True),
+    "3x3_256_256":   dict(B=2, H=16, W=16, cin=256, cout=256, k=3, bias=True),        # bottleneck ResBlock2d
+    "3x3_128_256":   dict(B=1, H=20, W=12, cin=128, cout=256, k=3, bias=True),        # ragged extents, DownBlock2d
+    "3x3_96_32":     dict(B=3, H=9, W=7, cin=96, cout=32, k=3, bias=False),           # tile tails in both channel dims
+    "7x7_64_32":     dict(B=1, H=24, W=24, cin=64, cout=32, k=7, bias=True),          # 7x7 (final / first layer kind)
+    "3x3_pixels_not_multiple_of_32": dict(B=1, H=5, W=5, cin=32, cout=32, k=3, bias=True),
+}
+
+
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv_backward_matches_autograd(name):
+    kw = CONV_CASES[name]
+    g = torch.Generator().manual_seed(100 + list(CONV_CASES).index(name))
+    B, H, W, cin, cout, k = kw["B"], kw["H"], kw["W"], kw["cin"], kw["cout"], kw["k"]
+    x = torch.randn(B, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = 0.1 * torch.randn(cout, generator=g) if kw["bias"] else None
+    gout = torch.randn(B, cout, H, W, generator=g)
+
+    xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+    br = b.double().requires_grad_() if b is not None else None
+    yr = F.conv2d(xr, wr, br, padding=k // 2)
+    yr.backward(gout.double())
+
+    xd, wd = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_()
+    bd = b.to(DEV).requires_grad_() if b is not None else None
+    y = autograd_ops.conv2d_same(xd, wd, bd)
+    y.backward(gout.to(DEV))
+    torch.cuda.synchronize()
+
+    def rel(got, want):
+        return float((got.detach().cpu().double() - want).abs().max()) / max(1.0, float(want.abs().max()))
+
+    errs = {"out": rel(y, yr.detach()), "dx": rel(xd.grad, xr.grad), "dw": rel(wd.grad, wr.grad)}
+    if b is not None:
+        errs["db"] = rel(bd.grad, br.grad)
+    print(f"conv backward {name}: " + ", ".join(f"{k_} {v:.2e}" for k_, v in errs.items()))
+    # fp32 MFMA accumulation vs float64: K = cin*k*k for out/dx, K = B*H*W pixels for dw
+    assert all(v <= 2e-5 for v in errs.values()), (name, errs)
+
+
+def test_conv_wgrad_is_deterministic_and_linear():
+    # fixed-order split reduction: bit-identical across runs; linear in grad_out
+    B, H, W, cin, cout, k = 2, 32, 32, 64, 64, 3
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, W, cin, generator=g).to(DEV)
+    g1 = torch.randn(B, H, W, cout, generator=g).to(DEV)
+    g2 = torch.randn(B, H, W, cout, generator=g).to(DEV)
+    L = _lib.lib()
+    nwork = L.eamm_op_conv_wgrad_workspace_floats(cin, cout, k, k)
+    work = torch.empty(nwork, device=DEV)
+
+    def wgrad(go):
+        dw = torch.full((cout, cin, k, k), float("nan"), device=DEV)
+        db = torch.full((cout,), float("nan"), device=DEV)
+        _lib.check(L.eamm_op_conv_wgrad(0, x.data_ptr(), go.data_ptr(), B, H, W, cin, cout, k, k, dw.data_ptr(), db.data_ptr(),
+                                        work.data_ptr(), nwork, torch.cuda.current_stream().cuda_stream), None)
+        torch.cuda.synchronize()
+        return dw, db
+
+    a1, b1 = wgrad(g1)
+    a1b, b1b = wgrad(g1)
+    assert torch.equal(a1, a1b) and torch.equal(b1, b1b)
+    a2, _ = wgrad(g2)
+    a12, _ = wgrad(g1 + g2)
+    assert float((a12 - (a1 + a2)).abs().max()) <= 1e-4 * float(a12.abs().max())
+
+
+def test_backward_entry_points_reject_bad_arguments():
+    L = _lib.lib()
+    t = torch.zeros(64, device=DEV)
+    assert L.eamm_op_warp_backward(0, t.data_ptr(), t.data_ptr(), None, t.data_ptr(), 1, 1, 2, 2, 6, t.data_ptr(), None, None, None) != 0
+    assert L.eamm_op_warp_backward(0, t.data_ptr(), t.data_ptr(), None, t.data_ptr(), 1, 1, 2, 2, 8, None, None, None, None) != 0
+    assert L.eamm_op_conv_wgrad(0, t.data_ptr(), t.data_ptr(), 1, 2, 2, 4, 4, 2, 2, t.data_ptr(), None, t.data_ptr(), 64, None) != 0
+    assert L.eamm_op_conv_wgrad(0, t.data_ptr(), t.data_ptr(), 1, 2, 2, 4, 4, 3, 3, t.data_ptr(), None, t.data_ptr(), 1, None) != 0   # workspace too small
+    with pytest.raises(RuntimeError):
+        autograd_ops.warp(torch.zeros(1, 8, 4, 4), torch.zeros(1, 4, 4, 2))   # CPU tensors: no fallback
