@@ -15,6 +15,7 @@
 #include "conv_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace eamm {
 
@@ -56,7 +57,10 @@ __global__ __launch_bounds__(256) void warp_features_backward_kernel(const float
         const float2 g = reinterpret_cast<const float2*>(defo)[pix];
         const float o = occ ? occ[pix] : 1.f;
         const BilinearB b = bilinear_setup_b(g.x, g.y, wf, hf);
-        const float4 go = reinterpret_cast<const float4*>(dout)[idx];
+        // a thread owns channels c4 + k * c4n (k = 0..3): the lanes of a pixel touch CONSECUTIVE floats, so each atomic
+        // instruction of the wave lands on whole cache lines (4 x fewer L2 atomic operations than a float4 per lane)
+        const float* gp = dout + pix * C + c4;
+        const float go[4] = {gp[0], gp[c4n], gp[2 * c4n], gp[3 * c4n]};
         const size_t sbase = (size_t)((ns == 1) ? 0 : f) * hf * wf;
         float dgx = 0.f, dgy = 0.f, dsum = 0.f;
         if (b.valid) {
@@ -67,17 +71,18 @@ __global__ __launch_bounds__(256) void warp_features_backward_kernel(const float
                 for (int cx = 0; cx < 2; ++cx) {
                     const int yy = b.y0 + cy, xx = b.x0 + cx;
                     if ((unsigned)yy >= (unsigned)hf || (unsigned)xx >= (unsigned)wf) continue;   // zeros padding: no value, no gradient
-                    const size_t src = (sbase + (size_t)yy * wf + xx) * c4n + c4;
-                    const float4 v = reinterpret_cast<const float4*>(feat)[src];
-                    const float dot = go.x * v.x + go.y * v.y + go.z * v.z + go.w * v.w;       // sum_c dout * feat at this corner
+                    const size_t src = (sbase + (size_t)yy * wf + xx) * C + c4;
+                    const float* vp = feat + src;
+                    const float dot = go[0] * vp[0] + go[1] * vp[c4n] + go[2] * vp[2 * c4n] + go[3] * vp[3 * c4n];   // sum_c dout * feat
                     const float w = wx[cx] * wy[cy];
                     dsum = fmaf(w, dot, dsum);
                     dgx = fmaf((cx ? 1.f : -1.f) * wy[cy], dot, dgx);                            // d w / d ix
                     dgy = fmaf((cy ? 1.f : -1.f) * wx[cx], dot, dgy);                            // d w / d iy
                     if (dfeat != nullptr) {
-                        float* d = dfeat + src * 4;
+                        float* d = dfeat + src;
                         const float s = w * o;
-                        atomicAdd(d + 0, go.x * s); atomicAdd(d + 1, go.y * s); atomicAdd(d + 2, go.z * s); atomicAdd(d + 3, go.w * s);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) atomicAdd(d + k * c4n, go[k] * s);
                     }
                 }
         }
@@ -127,15 +132,18 @@ struct WgradArgs {
     const float* dy;     // [B,H,W,Cout]
     int B, H, W, Cin, Cout, kh, kw;
     long long P;         // B*H*W
-    long long per_split; // pixels per split (multiple of 32)
+    long long per_split; // pixels per split (multiple of 64)
     int splits, mt, nt;  // pixel splits, Cout tiles, Cin tiles (64 each)
     float* partial;      // [splits][kh*kw][mt*64][nt*64]
 };
 
 // block (tile pair, tap, split): D[64 co][64 ci] += sum over the split's pixels; 4 waves of 32 x 32, v_mfma_f32_32x32x2_f32.
-// LDS per 32-pixel chunk: dY rows [32][64] and (shifted, zero-padded) X rows [32][64]: both read as they lie in HBM.
+// LDS per KC-pixel chunk: dY rows [KC][64] and (shifted, zero-padded) X rows [KC][64]: both as they lie in HBM.  The next
+// chunk's rows are in flight in registers while this chunk's MFMAs run; a row's (x, y) advances incrementally -- on gfx950 a
+// wave streaming f32 MFMAs starves the VALU instructions of its SIMD's other waves, so the loop carries as few as it can.
+template <int KC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
-    constexpr int KC = 32, TM = 64, TN = 64, LD = TM + 4;   // +4: the two K rows of an MFMA step land on different banks
+    constexpr int TM = 64, TN = 64, LD = TM + 4, RPT = KC / 16;   // +4: the two K rows of an MFMA step land on different banks
     __shared__ __attribute__((aligned(16))) float As[KC * LD];
     __shared__ __attribute__((aligned(16))) float Bs[KC * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,30 +155,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     const int tap = L % taps; L /= taps;
     const int split = L;
     const int dyo = tap / p.kw - p.kh / 2, dxo = tap % p.kw - p.kw / 2;
-    const long long p0 = (long long)split * p.per_split, p1 = std::min<long long>(p.P, p0 + p.per_split);
+    const int p0 = (int)((long long)split * p.per_split), p1 = (int)std::min<long long>(p.P, (long long)p0 + p.per_split);
     f32x16 acc;
     static_for<16>([&](auto rc) { acc[decltype(rc)::value] = 0.f; });
-    // loader: thread -> (row r of the chunk, 16-byte group q of the 64 channels); 256 threads cover 16 rows x 16 groups, twice
+    // loader: thread -> (rows lr + 16 j of the chunk, 16-byte group lq of the 64 channels)
     const int lq = tid & 15, lr = tid >> 4;
-    for (long long pc = p0; pc < p1; pc += KC) {
+    const int co = mti * TM + lq * 4, ci = nti * TN + lq * 4;
+    const bool co_ok = co < p.Cout, ci_ok = ci < p.Cin;
+    int px[RPT], py[RPT];
+#pragma unroll
+    for (int h2 = 0; h2 < RPT; ++h2) {
+        const unsigned pp = (unsigned)(p0 + lr + 16 * h2);
+        px[h2] = (int)(pp % (unsigned)p.W);
+        py[h2] = (int)((pp / (unsigned)p.W) % (unsigned)p.H);
+    }
+    const float* ap = p.dy + (size_t)(p0 + lr) * p.Cout + co;                                   // row lr of the current chunk
+    const float* bp = p.x + ((long long)(p0 + lr) + (long long)dyo * p.W + dxo) * p.Cin + ci;   // the tap's shifted pixel
+    const size_t a16 = (size_t)16 * p.Cout, b16 = (size_t)16 * p.Cin;
+    f32x4 ra[RPT], rb[RPT];
+    auto fetch = [&](int pc) {
+#pragma unroll
+        for (int h2 = 0; h2 < RPT; ++h2) {
+            const bool in = pc + lr + 16 * h2 < p1;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            ra[h2] = (in && co_ok) ? *reinterpret_cast<const f32x4*>(ap + h2 * a16) : z;
+            const bool tap_in = (unsigned)(py[h2] + dyo) < (unsigned)p.H && (unsigned)(px[h2] + dxo) < (unsigned)p.W;
+            rb[h2] = (in && ci_ok && tap_in) ? *reinterpret_cast<const f32x4*>(bp + h2 * b16) : z;
+        }
+    };
+    auto advance = [&]() {
+        ap += RPT * a16;
+        bp += RPT * b16;
+#pragma unroll
+        for (int h2 = 0; h2 < RPT; ++h2) {
+            px[h2] += KC;
+            if (p.W >= KC) {
+                if (px[h2] >= p.W) { px[h2] -= p.W; ++py[h2]; }
+            } else {
+                py[h2] += px[h2] / p.W;
+                px[h2] %= p.W;
+            }
+            if (py[h2] >= p.H) py[h2] = (p.W >= KC) ? py[h2] - p.H : py[h2] % p.H;
+        }
+    };
+    fetch(p0);
+    for (int pc = p0; pc < p1; pc += KC) {
         __syncthreads();
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int r = lr + 16 * h2;
-            const long long pp = pc + r;
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-            if (pp < p1) {
-                const int co = mti * TM + lq * 4, ci = nti * TN + lq * 4;
-                if (co < p.Cout) a = *reinterpret_cast<const f32x4*>(p.dy + pp * p.Cout + co);      // (Cout, Cin multiples of 4)
-                const int xx = (int)(pp % p.W), yy = (int)((pp / p.W) % p.H);
-                const int ys = yy + dyo, xs = xx + dxo;
-                if (ci < p.Cin && (unsigned)ys < (unsigned)p.H && (unsigned)xs < (unsigned)p.W)
-                    b = *reinterpret_cast<const f32x4*>(p.x + (pp + (long long)dyo * p.W + dxo) * p.Cin + ci);
-            }
-            *reinterpret_cast<f32x4*>(As + r * LD + lq * 4) = a;
-            *reinterpret_cast<f32x4*>(Bs + r * LD + lq * 4) = b;
+        for (int h2 = 0; h2 < RPT; ++h2) {
+            *reinterpret_cast<f32x4*>(As + (lr + 16 * h2) * LD + lq * 4) = ra[h2];
+            *reinterpret_cast<f32x4*>(Bs + (lr + 16 * h2) * LD + lq * 4) = rb[h2];
         }
         __syncthreads();
+        if (pc + KC < p1) {
+            advance();
+            fetch(pc + KC);
+        }
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {   // A[m][k]: lane -> m = lane % 32, k = lane / 32
             const float av = As[(2 * s + (lane >> 5)) * LD + wm * 32 + (lane & 31)];
@@ -184,6 +224,98 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         constexpr int r = decltype(rc)::value;
         const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         out[(size_t)m * (p.nt * TN) + (lane & 31)] = acc[r];
+    });
+}
+
+// The same GEMM with the KW taps of one filter ROW in one block, for maps whose width is a multiple of the 32-pixel K chunk
+// (every layer of the generator at 64 x 64 and above): a chunk is then a segment of ONE image row, the taps' shifted operands
+// are the same X rows offset by one (LDS rows k + t), the zero padding is exact on the B side (the KW - 1 halo rows are
+// loaded as zeros at the row ends, the whole chunk as zeros when the tap row leaves the map) and the loop has no masking.
+// HBM/L2 bytes per flop drop KW-fold against the per-tap kernel (which moves 16 flop per byte and is L2-bound at ~0.5 of
+// the matrix peak): dY 8 KB + X 8.5 KB per 3 x 262144 flop at 3x3.
+template <int KW>
+__global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs p) {
+    constexpr int KC = 32, TM = 64, TN = 64, LD = TM + 4, HALF = KW / 2;
+    __shared__ __attribute__((aligned(16))) float As[KC * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[(KC + KW - 1) * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int L = blockIdx.x;
+    const int nti = L % p.nt; L /= p.nt;
+    const int mti = L % p.mt; L /= p.mt;
+    const int trow = L % p.kh; L /= p.kh;
+    const int split = L;
+    const int dyo = trow - p.kh / 2;
+    const int p0 = (int)((long long)split * p.per_split), p1 = (int)std::min<long long>(p.P, (long long)p0 + p.per_split);   // multiples of 32
+    f32x16 acc[KW];
+    static_for<KW>([&](auto tc) { static_for<16>([&](auto rc) { acc[decltype(tc)::value][decltype(rc)::value] = 0.f; }); });
+    const int lq = tid & 15, lr = tid >> 4;
+    const int co = mti * TM + lq * 4, ci = nti * TN + lq * 4;
+    const bool co_ok = co < p.Cout, ci_ok = ci < p.Cin;
+    int x0 = (int)((unsigned)p0 % (unsigned)p.W), y = (int)(((unsigned)p0 / (unsigned)p.W) % (unsigned)p.H);
+    long long aoff = (long long)(p0 + lr) * p.Cout + co;
+    long long boff = ((long long)(p0 + lr) + (long long)dyo * p.W) * p.Cin + ci;
+    // halo rows: threads 0 .. 16 (KW - 1) - 1 own one each; pixel offset from the chunk start -HALF..-1 and 32..32 + HALF - 1
+    const bool is_halo = tid < 16 * (KW - 1);
+    const int hrow = lr, hoff = hrow < HALF ? hrow - HALF : KC + hrow - HALF;
+    long long hoffs = ((long long)p0 + hoff + (long long)dyo * p.W) * p.Cin + ci;
+    const long long a16 = (long long)16 * p.Cout, b16 = (long long)16 * p.Cin;
+    f32x4 ra[2], rb[2], rh;
+    auto fetch = [&]() {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const bool yv = (unsigned)(y + dyo) < (unsigned)p.H;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            ra[h2] = co_ok ? *reinterpret_cast<const f32x4*>(p.dy + aoff + h2 * a16) : z;
+            rb[h2] = (ci_ok && yv) ? *reinterpret_cast<const f32x4*>(p.x + boff + h2 * b16) : z;
+        }
+        if (KW > 1) {
+            const bool xv = hrow < HALF ? x0 > 0 : x0 + KC < p.W;
+            rh = (is_halo && ci_ok && yv && xv) ? *reinterpret_cast<const f32x4*>(p.x + hoffs) : z;
+        }
+    };
+    fetch();
+    for (int pc = p0; pc < p1; pc += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            *reinterpret_cast<f32x4*>(As + (lr + 16 * h2) * LD + lq * 4) = ra[h2];
+            *reinterpret_cast<f32x4*>(Bs + (lr + 16 * h2 + HALF) * LD + lq * 4) = rb[h2];
+        }
+        if (KW > 1 && is_halo) *reinterpret_cast<f32x4*>(Bs + (hoff + HALF) * LD + lq * 4) = rh;
+        __syncthreads();
+        if (pc + KC < p1) {
+            aoff += 2 * a16;
+            boff += 2 * b16;
+            hoffs += 2 * b16;
+            x0 += KC;
+            if (x0 == p.W) {
+                x0 = 0;
+                if (++y == p.H) y = 0;
+            }
+            fetch();
+        }
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            const int k = 2 * s + (lane >> 5);
+            const float av = As[k * LD + wm * 32 + (lane & 31)];
+            static_for<KW>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const float bv = Bs[(k + t) * LD + wn * 32 + (lane & 31)];   // pixel k + (t - HALF) of the chunk's row
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            });
+        }
+    }
+    const int taps = p.kh * KW;
+    static_for<KW>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        float* out = p.partial + (((size_t)split * taps + trow * KW + t) * (p.mt * TM) + mti * TM + wm * 32) * (size_t)(p.nt * TN) +
+                     nti * TN + wn * 32;
+        static_for<16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[(size_t)m * (p.nt * TN) + (lane & 31)] = acc[t][r];
+        });
     });
 }
 
@@ -201,21 +333,40 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int 
     }
 }
 
-// db[co] = sum_p dy[p][co]: one block per 64 channels, double accumulators, fixed order
-__global__ __launch_bounds__(256) void conv_bias_grad_kernel(const float* __restrict__ dy, long long P, int Cout, float* __restrict__ db) {
-    __shared__ double red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane_r = threadIdx.x >> 6;
-    double s = 0.0;
-    if (c < Cout)
-        for (long long pp = lane_r; pp < P; pp += 4) s += (double)dy[pp * Cout + c];
-    red[lane_r][threadIdx.x & 63] = s;
+// db[co] = sum_p dy[p][co] in two fixed-order stages: BIAS_PARTS pixel ranges (a thread owns 4 channels, the 256 / (Cout / 4)
+// row lanes of a block stride the range), then the parts per channel in double
+constexpr int BIAS_PARTS = 512;
+__global__ __launch_bounds__(256) void conv_bias_grad_partial_kernel(const float* __restrict__ dy, long long P, int Cout,
+                                                                     float* __restrict__ part /*[parts][Cout]*/) {
+    __shared__ f32x4 red[256];
+    const int c4n = Cout >> 2;                      // <= 256 (Cout <= 1024)
+    const int rows = 256 / c4n, c4 = threadIdx.x % c4n, r = threadIdx.x / c4n;
+    const long long per = (P + gridDim.x - 1) / gridDim.x, p0 = (long long)blockIdx.x * per, p1 = std::min<long long>(P, p0 + per);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows)
+        for (long long pp = p0 + r; pp < p1; pp += rows) s += reinterpret_cast<const f32x4*>(dy)[pp * c4n + c4];
+    red[threadIdx.x] = s;
     __syncthreads();
-    if (lane_r == 0 && c < Cout) db[c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (r == 0) {
+        for (int k = 1; k < rows; ++k) s += red[k * c4n + c4];
+        reinterpret_cast<f32x4*>(part)[(size_t)blockIdx.x * c4n + c4] = s;
+    }
+}
+__global__ void conv_bias_grad_final_kernel(const float* __restrict__ part, int parts, int Cout, float* __restrict__ db) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cout) return;
+    double s = 0.0;
+    for (int k = 0; k < parts; ++k) s += (double)part[(size_t)k * Cout + c];
+    db[c] = (float)s;
 }
 
 hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int kh, int kw, float* dweight,
                              float* dbias, float* workspace, size_t workspace_floats, hipStream_t s) {
-    if ((Cin & 3) || (Cout & 3) || !(kh & 1) || !(kw & 1) || B < 1) return hipErrorInvalidValue;
+    if ((Cin & 3) || (Cout & 3) || Cout > 1024 || !(kh & 1) || !(kw & 1) || B < 1 || (long long)B * H * W >= (1ll << 30)) return hipErrorInvalidValue;
+    const size_t bias_floats = (size_t)BIAS_PARTS * Cout;   // the tail of the workspace
+    if (workspace_floats < bias_floats) return hipErrorInvalidValue;
+    workspace_floats -= bias_floats;
+    float* bias_part = workspace + workspace_floats;
     WgradArgs a{};
     a.x = x;
     a.dy = dy;
@@ -224,27 +375,36 @@ hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int 
     a.mt = (Cout + 63) / 64;
     a.nt = (Cin + 63) / 64;
     const int taps = kh * kw;
-    const long long tiles = (long long)a.mt * a.nt * taps;
+    static const int row_off = [] { const char* e = getenv("EAMM_WGRAD_ROW"); return e ? atoi(e) == 0 : 0; }();
+    const bool row = !row_off && W % 32 == 0 && (kw == 1 || kw == 3 || kw == 7);   // one block per filter row (else: per tap)
+    const long long tiles = (long long)a.mt * a.nt * (row ? kh : taps);
     long long splits = std::max<long long>(1, std::min<long long>(1024 / std::max<long long>(1, tiles) + 1, a.P / 256));
     const size_t per = (size_t)taps * a.mt * 64 * a.nt * 64;
     while (splits > 1 && (size_t)splits * per > workspace_floats) --splits;
     if ((size_t)splits * per > workspace_floats) return hipErrorInvalidValue;
-    a.per_split = ((a.P + splits - 1) / splits + 31) / 32 * 32;
+    a.per_split = ((a.P + splits - 1) / splits + 63) / 64 * 64;
     a.splits = (int)((a.P + a.per_split - 1) / a.per_split);
     a.partial = workspace;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(tiles * a.splits)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)(tiles * a.splits));
+    if (row && kw == 1) hipLaunchKernelGGL(conv_wgrad_row_kernel<1>, grid, dim3(256), 0, s, a);
+    else if (row && kw == 3) hipLaunchKernelGGL(conv_wgrad_row_kernel<3>, grid, dim3(256), 0, s, a);
+    else if (row) hipLaunchKernelGGL(conv_wgrad_row_kernel<7>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<32>, grid, dim3(256), 0, s, a);
     const size_t total = (size_t)Cout * Cin * taps;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, s, workspace,
                        a.splits, taps, a.mt * 64, a.nt * 64, Cout, Cin, dweight);
-    if (dbias != nullptr)
-        hipLaunchKernelGGL(conv_bias_grad_kernel, dim3((Cout + 63) / 64), dim3(256), 0, s, dy, a.P, Cout, dbias);
+    if (dbias != nullptr) {
+        const int parts = (int)std::min<long long>(BIAS_PARTS, (a.P + 63) / 64);
+        hipLaunchKernelGGL(conv_bias_grad_partial_kernel, dim3(parts), dim3(256), 0, s, dy, a.P, Cout, bias_part);
+        hipLaunchKernelGGL(conv_bias_grad_final_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, bias_part, parts, Cout, dbias);
+    }
     return hipGetLastError();
 }
 
 size_t conv_wgrad_workspace_floats(int Cin, int Cout, int kh, int kw) {
     const size_t per = (size_t)kh * kw * ((Cout + 63) / 64) * 64 * ((Cin + 63) / 64) * 64;
-    const long long tiles = (long long)((Cout + 63) / 64) * ((Cin + 63) / 64) * kh * kw;
-    return per * (size_t)(1024 / std::max<long long>(1, tiles) + 1);
+    const long long tiles = (long long)((Cout + 63) / 64) * ((Cin + 63) / 64) * kh;   // the row kernel's count (the per-tap kernel has kw x more)
+    return per * (size_t)(1024 / std::max<long long>(1, tiles) + 1) + (size_t)BIAS_PARTS * Cout;
 }
 
 }  // namespace eamm

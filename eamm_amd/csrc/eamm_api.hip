@@ -1492,8 +1492,8 @@ size_t eamm_op_conv_wgrad_workspace_floats(int Cin, int Cout, int kh, int kw) {
 int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                        float* grad_weight, float* grad_bias, float* workspace, size_t workspace_floats, void* stream_) {
     if (!x || !grad_out || !grad_weight || !workspace || B < 1 || H < 1 || W < 1 || Cin < 4 || Cout < 4 || (Cin & 3) || (Cout & 3) ||
-        kh < 1 || kw < 1 || !(kh & 1) || !(kw & 1) || kh > 7 || kw > 7)
-        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv_wgrad: bad argument (channels multiples of 4, odd filter up to 7x7)");
+        Cout > 1024 || kh < 1 || kw < 1 || !(kh & 1) || !(kw & 1) || kh > 7 || kw > 7)
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv_wgrad: bad argument (channels multiples of 4, Cout <= 1024, odd filter up to 7x7)");
     DeviceGuard guard(device);
     if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipError_t e = conv_wgrad_launch(x, grad_out, B, H, W, Cin, Cout, kh, kw, grad_weight, grad_bias, workspace, workspace_floats,

@@ -97,6 +97,11 @@ CONV_CASES = {
     "3x3_96_32":     dict(B=3, H=9, W=7, cin=96, cout=32, k=3, bias=False),           # tile tails in both channel dims
     "7x7_64_32":     dict(B=1, H=24, W=24, cin=64, cout=32, k=7, bias=True),          # 7x7 (final / first layer kind)
     "3x3_pixels_not_multiple_of_32": dict(B=1, H=5, W=5, cin=32, cout=32, k=3, bias=True),
+    # widths that are multiples of 32: the filter-row kernel (a K chunk is a segment of one image row)
+    "row_3x3_w32":   dict(B=2, H=8, W=32, cin=64, cout=96, k=3, bias=True),
+    "row_3x3_w64":   dict(B=3, H=5, W=64, cin=128, cout=64, k=3, bias=True),
+    "row_7x7_w32":   dict(B=1, H=6, W=32, cin=32, cout=32, k=7, bias=True),           # taller filter than some maps' margin
+    "row_7x7_w96":   dict(B=2, H=10, W=96, cin=64, cout=32, k=7, bias=False),
 }
 
 
@@ -157,6 +162,27 @@ def test_conv_wgrad_is_deterministic_and_linear():
     a2, _ = wgrad(g2)
     a12, _ = wgrad(g1 + g2)
     assert float((a12 - (a1 + a2)).abs().max()) <= 1e-4 * float(a12.abs().max())
+
+
+@pytest.mark.parametrize("H,W", [(12, 32), (9, 20)])
+def test_conv_wgrad_7x1_filter(H, W):
+    # the path's column convolutions (7x1): filter-row kernel with one tap per row / per-tap kernel, against autograd
+    B, cin, cout = 2, 64, 32
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, cin, H, W, generator=g)
+    gout = torch.randn(B, cout, H, W, generator=g)
+    wr = torch.zeros(cout, cin, 7, 1, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wr, None, padding=(3, 0)).backward(gout.double())
+    L = _lib.lib()
+    xd, gd = x.permute(0, 2, 3, 1).contiguous().to(DEV), gout.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dw = torch.full((cout, cin, 7, 1), float("nan"), device=DEV)
+    nwork = L.eamm_op_conv_wgrad_workspace_floats(cin, cout, 7, 1)
+    work = torch.empty(nwork, device=DEV)
+    _lib.check(L.eamm_op_conv_wgrad(0, xd.data_ptr(), gd.data_ptr(), B, H, W, cin, cout, 7, 1, dw.data_ptr(), None, work.data_ptr(),
+                                    nwork, torch.cuda.current_stream().cuda_stream), None)
+    torch.cuda.synchronize()
+    err = float((dw.cpu().double() - wr.grad).abs().max()) / max(1.0, float(wr.grad.abs().max()))
+    assert err <= 2e-5, err
 
 
 def test_backward_entry_points_reject_bad_arguments():
