@@ -6,9 +6,10 @@ same constructor keywords (``demo.py:54-55`` splats the YAML sections into it), 
 set, so ``generator.load_state_dict(checkpoint['generator'])`` / ``.cuda()`` / ``.eval()``
 (demo.py:56-57, 91, 105) work unchanged.  The sub-modules below only HOLD parameters under the
 reference's names; they are never called.  All computation happens in the HIP library; there is no
-PyTorch/CPU fallback and ``forward`` raises when the module is not on a GPU.  ``.train()`` is supported for the FORWARD
-(batch statistics in every BatchNorm, running statistics updated, replicas' statistics all-reduced -- SURVEY.md 8f row N4);
-there is no backward through the generator.
+PyTorch/CPU fallback and ``forward`` raises when the module is not on a GPU.  ``.train()`` is supported (batch statistics in
+every BatchNorm, running statistics updated, replicas' statistics all-reduced -- SURVEY.md 8f row N4): graph-free through the
+resumable engine, and -- when something requires a gradient -- as a composition of differentiable HIP operators
+(``train_graph``), so ``loss.backward()`` reaches the parameters and the key points as in train.py:133.
 
 Beyond the reference interface the module exposes the two halves of forward separately
 (``encode_source`` / ``forward_frames``) so that a clip can reuse the frame-invariant source
@@ -124,7 +125,7 @@ class OcclusionAwareGenerator(nn.Module):
         # replicas' formula on or off (sync_batchnorm/batchnorm.py:48-53 vs :55-125)
         self.process_group = None
         self.sync_batchnorm: Optional[bool] = None
-        for p in self.parameters():  # the forward carries no autograd graph (convolution / warp backward are not built)
+        for p in self.parameters():  # inference is the default use: fine-tuning opts in with .requires_grad_(True)
             p.requires_grad_(False)
 
     # -- engine management ---------------------------------------------------------------------------
@@ -199,26 +200,47 @@ class OcclusionAwareGenerator(nn.Module):
         norms = self._norm_modules()
         out = e.train_forward(source_image, kd, ks, norms, outputs=want, sync=sync,
                               reduce=self._all_reduce if (sync and world > 1) else None)
-        # the library wrote the running statistics through raw pointers: bump the tensors' version counters so that every
-        # cache keyed on them (the evaluation engine's folded weights) sees the change
-        stats = [t for m in norms.values() for t in (m.running_mean, m.running_var)]
-        try:
-            torch._C._increment_version(stats)
-        except (AttributeError, TypeError):   # older / newer torch without the list form: a no-op in-place write
-            for t in stats:
-                t.add_(0)
+        self._bump_running_stats()
         self._src_ref = None
         e.check_numeric()
         return {k: out[k] for k in ("mask", "sparse_deformed", "occlusion_map", "deformed", "prediction") if k in out}
 
     # -- the reference contract -----------------------------------------------------------------------
-    @torch.no_grad()
+    def _wants_graph(self, source_image, kp_driving, kp_source) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        tensors = [source_image] + [v for kp in (kp_driving, kp_source) if kp for v in kp.values() if torch.is_tensor(v)]
+        return any(t.requires_grad for t in tensors) or any(p.requires_grad for p in self.parameters())
+
     def forward(self, source_image, kp_driving, kp_source):
         """Reference generator.py:59-97: batch of independent (source, kp_source, kp_driving) triples.  In ``.train()`` mode
         every BatchNorm normalises with the statistics of the batch and updates its running statistics, as the reference's
-        blocks do (modules/util.py:858-938); the outputs carry no autograd graph in either mode."""
+        blocks do (modules/util.py:858-938).  The outputs carry an autograd graph only in ``.train()`` mode with gradients
+        enabled and something to differentiate (a parameter after ``requires_grad_(True)``, or an input that requires grad):
+        then the forward is the composition of differentiable HIP operators of ``train_graph`` (train.py:133's
+        ``loss.backward()``); in every other case it is the graph-free engine."""
         if source_image.dim() != 4:
             raise RuntimeError(f"source_image must be [B,3,H,W], got {tuple(source_image.shape)}")
+        if self.training and self._wants_graph(source_image, kp_driving, kp_source):
+            from . import train_graph
+            out = train_graph.forward_train(self, source_image, kp_driving, kp_source)
+            self._bump_running_stats()
+            self._src_ref = None
+            return {k: out[k] for k in ("mask", "sparse_deformed", "occlusion_map", "deformed", "prediction") if k in out}
+        with torch.no_grad():
+            return self._forward_no_grad(source_image, kp_driving, kp_source)
+
+    def _bump_running_stats(self):
+        # the library wrote the running statistics through raw pointers: bump the tensors' version counters so that every
+        # cache keyed on them (the evaluation engine's folded weights) sees the change
+        stats = [t for m in self._norm_modules().values() for t in (m.running_mean, m.running_var)]
+        try:
+            torch._C._increment_version(stats)
+        except (AttributeError, TypeError):   # older / newer torch without the list form: a no-op in-place write
+            for t in stats:
+                t.add_(0)
+
+    def _forward_no_grad(self, source_image, kp_driving, kp_source):
         if self.training:
             return self._forward_train(source_image, kp_driving, kp_source)
         b, _, hh, ww = source_image.shape

@@ -1,0 +1,181 @@
+"""Differentiable ``.train()`` forward of OcclusionAwareGenerator -- SURVEY.md section 8f row N4, the backward half: what
+``loss.backward()`` needs in the reference's fine-tuning loop (train.py:133; the generator stays in training mode there and the
+loss reaches both the generator's parameters and, through the flow, the audio-driven key points).
+
+The reference composes ``nn.Conv2d`` / ``SynchronizedBatchNorm2d`` / ``F.grid_sample`` modules and lets autograd differentiate
+them (modules/generator.py:59-97, dense_motion.py:32-113, util.py:858-1002).  Here the same composition is built from this
+package's operators, each a ``torch.autograd.Function`` whose forward AND backward are libeamm_hip.so kernels:
+
+* every convolution          ``autograd_ops.conv2d_same``   (fp32-MFMA forward / data gradient / weight gradient)
+* every BatchNorm            ``sync_batchnorm._BatchNormFunction``  (batch statistics, replicas' all-reduce, backward)
+* every bilinear warp        ``autograd_ops.warp``          (feature warp x occlusion, the K+1 sparse warps, ``deformed``)
+
+The remaining steps are element-wise or a few hundred floats (ReLU, 2x2 average, nearest x2, softmax over the K+1 motions,
+sigmoid, heat-maps, 2x2 jacobian algebra, channel padding to the kernels' 32-channel granule) and stay torch-ROCm ops with
+their own autograd.  This is the OP-LEVEL composition: it exists so that the backward kernels are exercised and verified in
+the generator's real data flow (tests/test_gpu_train_backward.py: gradients against the reference's autograd fixture); it
+re-packs filters per call and is not the tuned path -- the inference engine and the resumable training forward are.
+GPU only: no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from . import autograd_ops
+from .sync_batchnorm import SynchronizedBatchNorm2d, _BatchNormFunction
+
+_G = 32   # channel granule of the convolution kernels
+
+
+def _round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def conv(x: torch.Tensor, mod: torch.nn.Conv2d) -> torch.Tensor:
+    """``mod(x)`` for the path's stride-1 "same" 3x3 / 7x7 convolutions; channels zero-padded to the kernels' granule
+    (the padded filter rows / columns are zeros and receive no gradient through the slice)."""
+    w, b = mod.weight, mod.bias
+    cout, cin = w.shape[:2]
+    cin_p, cout_p = _round_up(cin, _G), _round_up(cout, _G)
+    if cin_p != cin:
+        x = F.pad(x, (0, 0, 0, 0, 0, cin_p - cin))
+        w = F.pad(w, (0, 0, 0, 0, 0, cin_p - cin))
+    if cout_p != cout:
+        w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_p - cout))
+        b = F.pad(b, (0, cout_p - cout)) if b is not None else None
+    y = autograd_ops.conv2d_same(x, w, b)
+    return y[:, :cout] if cout_p != cout else y
+
+
+def warp(features: torch.Tensor, deformation: torch.Tensor, occlusion=None) -> torch.Tensor:
+    """generator.py:50-57 (+ :79-84 with an occlusion map): flow and occlusion resized bilinearly to the features first."""
+    h, w = features.shape[2:]
+    if deformation.shape[1:3] != (h, w):
+        deformation = F.interpolate(deformation.permute(0, 3, 1, 2), size=(h, w), mode="bilinear",
+                                    align_corners=False).permute(0, 2, 3, 1)
+    if occlusion is not None and occlusion.shape[2:] != (h, w):
+        occlusion = F.interpolate(occlusion, size=(h, w), mode="bilinear", align_corners=False)
+    c = features.shape[1]
+    cp = _round_up(c, 8)
+    if cp != c:
+        features = F.pad(features, (0, 0, 0, 0, 0, cp - c))
+    out = autograd_ops.warp(features, deformation.contiguous(), occlusion)
+    return out[:, :c] if cp != c else out
+
+
+class _Graph:
+    """One forward's bookkeeping: the generator (parameter holder), its BatchNorm adapters, the replicas' settings."""
+
+    def __init__(self, gen):
+        self.gen = gen
+        self.adapters: Dict[int, SynchronizedBatchNorm2d] = gen.__dict__.setdefault("_bn_adapters", {})
+
+    def norm(self, x: torch.Tensor, holder: torch.nn.BatchNorm2d) -> torch.Tensor:
+        # the holder owns the tensors (state_dict names of the reference); the adapter lends them to the Function
+        a = self.adapters.get(id(holder))
+        if a is None:
+            a = SynchronizedBatchNorm2d(holder.num_features, eps=holder.eps, momentum=holder.momentum)
+            self.adapters[id(holder)] = a
+        a._parameters["weight"], a._parameters["bias"] = holder.weight, holder.bias
+        a._buffers["running_mean"], a._buffers["running_var"] = holder.running_mean, holder.running_var
+        a.training = True
+        a.process_group, a.sync = self.gen.process_group, self.gen.sync_batchnorm
+        a._check_device(x)
+        return _BatchNormFunction.apply(x.contiguous(), holder.weight, holder.bias, a)
+
+    # ---- blocks: modules/util.py:858-938 --------------------------------------------------------------------------------
+    def same_block(self, x, blk):
+        return F.relu(self.norm(conv(x, blk.conv), blk.norm))
+
+    def down_block(self, x, blk):
+        return F.avg_pool2d(self.same_block(x, blk), kernel_size=(2, 2))
+
+    def up_block(self, x, blk):
+        return self.same_block(F.interpolate(x, scale_factor=2), blk)
+
+    def res_block(self, x, blk):
+        y = conv(F.relu(self.norm(x, blk.norm1)), blk.conv1)
+        y = conv(F.relu(self.norm(y, blk.norm2)), blk.conv2)
+        return y + x
+
+    def hourglass(self, x, hg):                                    # util.py:941-1002
+        skips = [x]
+        for blk in hg.encoder.down_blocks:
+            skips.append(self.down_block(skips[-1], blk))
+        out = skips.pop()
+        for blk in hg.decoder.up_blocks:
+            out = torch.cat([self.up_block(out, blk), skips.pop()], dim=1)
+        return out
+
+
+def _grid(h: int, w: int, like: torch.Tensor) -> torch.Tensor:
+    """util.py:839-855: [h,w,2], last dim (x, y) in [-1, 1]."""
+    xs = 2 * (torch.arange(w, device=like.device).to(like.dtype) / (w - 1)) - 1
+    ys = 2 * (torch.arange(h, device=like.device).to(like.dtype) / (h - 1)) - 1
+    return torch.stack([xs[None, :].expand(h, w), ys[:, None].expand(h, w)], dim=2)
+
+
+def _heatmaps(value: torch.Tensor, grid: torch.Tensor, variance: float) -> torch.Tensor:
+    d = grid[None, None] - value[:, :, None, None, :]              # util.py:815-836
+    return torch.exp(-0.5 * (d * d).sum(-1) / variance)
+
+
+def _dense_motion(g: _Graph, source_image, kp_driving, kp_source):
+    """dense_motion.py:32-113."""
+    dm = g.gen.dense_motion_network
+    if dm.scale_factor != 1:                                        # AntiAliasInterpolation2d, util.py:1044-1052
+        wgt = dm.down.weight
+        ka = wgt.shape[-1] // 2
+        src = F.conv2d(F.pad(source_image, (ka, ka, ka, ka)), wgt, groups=source_image.shape[1])
+        step = int(1 / dm.scale_factor)
+        src = src[:, :, ::step, ::step]
+    else:
+        src = source_image
+    b, c, h, w = src.shape
+    k = dm.num_kp
+    grid = _grid(h, w, src)
+    heat = _heatmaps(kp_driving["value"], grid, dm.kp_variance) - _heatmaps(kp_source["value"], grid, dm.kp_variance)
+    heat = torch.cat([torch.zeros_like(heat[:, :1]), heat], dim=1)[:, :, None]            # [B,K+1,1,h,w]
+    rel = grid[None, None] - kp_driving["value"][:, :, None, None, :]                      # dense_motion.py:47-67
+    if "jacobian" in kp_driving:
+        jac = torch.matmul(kp_source["jacobian"], torch.inverse(kp_driving["jacobian"]))
+        rel = (jac[:, :, None, None] @ rel[..., None])[..., 0]
+    moved = rel + kp_source["value"][:, :, None, None, :]
+    motions = torch.cat([grid[None, None].expand(b, 1, h, w, 2), moved], dim=1)            # [B,K+1,h,w,2]
+    rep = src[:, None].expand(b, k + 1, c, h, w).reshape(b * (k + 1), c, h, w)             # dense_motion.py:69-79
+    warped = warp(rep, motions.reshape(b * (k + 1), h, w, 2)).view(b, k + 1, c, h, w)
+    feat = g.hourglass(torch.cat([heat, warped], dim=2).view(b, (k + 1) * (c + 1), h, w), dm.hourglass)
+    mask = F.softmax(conv(feat, dm.mask), dim=1)                                           # dense_motion.py:98-99
+    deformation = (motions * mask[..., None]).sum(dim=1)                                   # :101-104
+    out = {"sparse_deformed": warped, "mask": mask, "deformation": deformation}
+    if dm.occlusion is not None:
+        out["occlusion_map"] = torch.sigmoid(conv(feat, dm.occlusion))
+    return out
+
+
+def forward_train(gen, source_image: torch.Tensor, kp_driving, kp_source) -> Dict[str, torch.Tensor]:
+    """OcclusionAwareGenerator.forward in ``.train()`` mode WITH an autograd graph (generator.py:59-97)."""
+    if source_image.device.type != "cuda":
+        raise RuntimeError("eamm_amd.OcclusionAwareGenerator runs only on a ROCm GPU (there is no CPU fallback for this path)")
+    g = _Graph(gen)
+    out = g.same_block(source_image, gen.first)                                           # generator.py:61-63
+    for blk in gen.down_blocks:
+        out = g.down_block(out, blk)
+    result = {}
+    if gen.dense_motion_network is not None:                                               # generator.py:64-86
+        dmo = _dense_motion(g, source_image, kp_driving, kp_source)
+        result["mask"], result["sparse_deformed"] = dmo["mask"], dmo["sparse_deformed"]
+        occ = dmo.get("occlusion_map")
+        if occ is not None:
+            result["occlusion_map"] = occ
+        out = warp(out, dmo["deformation"], occ)
+        result["deformed"] = warp(source_image, dmo["deformation"])
+    for blk in gen.bottleneck:                                                             # generator.py:89-93
+        out = g.res_block(out, blk)
+    for blk in gen.up_blocks:
+        out = g.up_block(out, blk)
+    result["prediction"] = torch.sigmoid(conv(out, gen.final))
+    return result

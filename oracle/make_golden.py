@@ -524,7 +524,105 @@ def train_mode_case(OAG):
     print("tiny64_train: wrote", len(blob), "arrays;", len(norm_names), "BatchNorm sites")
 
 
+def train_backward_case(OAG):
+    """Fixture for the generator's BACKWARD in .train() mode (N4): the reference generator on one replica, a scalar loss that
+    weighs every output with fixed random tensors, ``loss.backward()`` -- the gradients autograd derives for every parameter,
+    the key points (value + jacobian of driving and source) and the source image.  Stored in fp32 as the reference computes
+    them, with the fp32-vs-fp64 distance of each (the same computation in double) so that tests can scale their bars to the
+    algorithm's own noise floor.  The oracle's training branch must reproduce them."""
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    n = 4
+    source = synthetic_source(64, seed=1, batch=n)
+    kp_s = synthetic_keypoints(n, cfg["num_kp"], seed=0)
+    kp_d = synthetic_keypoints(n, cfg["num_kp"], seed=2)
+    keys = ("prediction", "mask", "sparse_deformed", "occlusion_map", "deformed")
+    gen = torch.Generator().manual_seed(77)
+
+    def run(dtype):
+        g = OAG(**cfg)
+        g.load_state_dict(sd, strict=True)
+        g = g.to(dtype).train()
+        src = source.detach().clone().to(dtype).requires_grad_()
+        ks = {k: v.detach().clone().to(dtype).requires_grad_() for k, v in kp_s.items()}
+        kd = {k: v.detach().clone().to(dtype).requires_grad_() for k, v in kp_d.items()}
+        out = g(src, kp_source=ks, kp_driving=kd)
+        loss = sum((out[k] * weights[k].to(dtype)).sum() for k in keys)
+        loss.backward()
+        grads = {"param/" + name: p.grad for name, p in g.named_parameters()}
+        grads["source_image"] = src.grad
+        for tag, kp in (("kp_source", ks), ("kp_driving", kd)):
+            for k, v in kp.items():
+                grads[tag + "/" + k] = v.grad
+        missing = [k for k, v in grads.items() if v is None]
+        assert not missing, (dtype, missing)
+        return loss.detach(), {k: v.detach() for k, v in grads.items()}, {k: out[k].detach() for k in keys}
+
+    with torch.no_grad():
+        g0 = OAG(**cfg)
+        g0.load_state_dict(sd, strict=True)
+        shapes = {k: v.shape for k, v in g0.train()(source, kp_source=kp_s, kp_driving=kp_d).items() if k in keys}
+    weights = {k: torch.randn(shapes[k], generator=gen) for k in keys}
+    loss32, g32, out32 = run(torch.float32)
+    loss64, g64, _ = run(torch.float64)
+    blob = {"weight_seed": np.int64(1234), "n": np.int64(n), "loss": np.float64(loss32), "loss64": np.float64(loss64),
+            "names": np.array(sorted(g32))}
+    for k in keys:
+        blob["w/" + k] = weights[k].numpy()
+        blob["out/" + k] = out32[k].numpy()
+    floor = {}
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    for k in sorted(g32):
+        # large tensors: every step-th element of the flattened gradient (step odd, so no fixed phase against the 3x3 taps)
+        step = 1 if g32[k].numel() <= 8192 else (g32[k].numel() // 8192) | 1
+        blob["step/" + k] = np.int64(step)
+        blob["grad/" + k] = g32[k].reshape(-1)[::step].numpy() if step > 1 else g32[k].numpy()
+        g64s = g64[k].reshape(-1)[::step] if step > 1 else g64[k]
+        blob["grad64/" + k] = g64s.float().numpy()           # the same gradient computed in double (rounded for storage)
+        scale = float(g64[k].abs().max())
+        # a convolution bias in front of a BatchNorm has a gradient of exactly zero (the mean is subtracted again): what the
+        # runs hold there is rounding noise, to be compared absolutely
+        blob["zero/" + k] = np.bool_(scale < 1e-9 * gmax)
+        blob["scale/" + k] = np.float64(scale)
+        floor[k] = float((g32[k].double() - g64[k]).abs().max()) / (scale if scale >= 1e-9 * gmax else gmax)
+        blob["floor/" + k] = np.float64(floor[k])
+    nz = [k for k in floor if not blob["zero/" + k]]
+    print("train_backward: loss", float(loss32), "| largest gradient", f"{gmax:.3e}", "| fp32-vs-fp64 relative floor: worst",
+          max(nz, key=floor.get), f"{max(floor[k] for k in nz):.2e}", "median", f"{float(np.median([floor[k] for k in nz])):.2e}",
+          "|", len(floor) - len(nz), "identically-zero gradients")
+    # the oracle's training branch, differentiated by autograd, must give the same gradients (in double, against the double run)
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k and "num_batches" not in k and "down.weight" not in k)
+            for k, v in sd.items()}
+    src = source.detach().double().requires_grad_()
+    ks = {k: v.detach().double().requires_grad_() for k, v in kp_s.items()}
+    kd = {k: v.detach().double().requires_grad_() for k, v in kp_d.items()}
+    mine, _ = orc.generator_forward_train(sd64, cfg, src, kd, ks, parallel=False)
+    sum((mine[k] * weights[k].double()).sum() for k in keys).backward()
+    worst = 0.0
+    for k in sorted(g64):
+        if k.startswith("param/"):
+            got = sd64[k[len("param/"):]].grad
+        elif k == "source_image":
+            got = src.grad
+        else:
+            tag, key = k.split("/")
+            got = (ks if tag == "kp_source" else kd)[key].grad
+        assert got is not None, k
+        rel = float((got - g64[k]).abs().max()) / (gmax if blob["zero/" + k] else float(g64[k].abs().max()))
+        if rel > 1e-9:
+            print('  oracle gradient differs:', k, rel, float(g64[k].abs().max()))
+        worst = max(worst, rel)
+    print(f"train_backward: oracle autograd vs reference autograd (float64), worst relative |diff| {worst:.2e}")
+    assert worst < 1e-9, worst
+    np.savez_compressed(os.path.join(GOLDEN, "tiny64_train_backward.npz"), **blob)
+    print("tiny64_train_backward: wrote", len(blob), "arrays,", os.path.getsize(os.path.join(GOLDEN, "tiny64_train_backward.npz")) >> 10, "KiB")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "train_backward":
+        os.makedirs(GOLDEN, exist_ok=True)
+        train_backward_case(import_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         os.makedirs(GOLDEN, exist_ok=True)
         train_mode_case(import_reference())
@@ -575,6 +673,7 @@ def main():
     smoothing_case()
     batchnorm_case()
     train_mode_case(OAG)
+    train_backward_case(OAG)
     with open(os.path.join(GOLDEN, "summary.json"), "w") as f:
         json.dump({"torch": torch.__version__, "cases": summary}, f, indent=1, sort_keys=True)
     for name, rep in summary.items():

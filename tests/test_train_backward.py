@@ -1,0 +1,167 @@
+"""loss.backward() through the generator in .train() mode (reference train.py:133).
+
+Fixture tests/golden/tiny64_train_backward.npz (oracle/make_golden.py::train_backward_case): the REFERENCE generator in
+.train(), a scalar loss weighing every output with fixed random tensors, the gradients of every parameter, of the key points
+(value + jacobian, driving and source) and of the source image -- as the reference computes them in fp32, the same in double
+(`grad64`), and their distance (`floor`): the algorithm's own fp32 noise floor, up to 9e-3 of a tensor's largest gradient on
+this randomly-initialised network (batch-statistics BatchNorm backward cancels heavily), median 9e-4.
+
+CPU: the oracle's training branch differentiated by autograd against the fixture.
+GPU (-m gpu): eamm_amd.OcclusionAwareGenerator.train() with requires_grad_(True) -- the composition of differentiable HIP
+operators in eamm_amd/train_graph.py -- against the double gradients, each tensor within a few of ITS OWN fp32 floors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from eamm_amd import tiny_config
+from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict
+from oracle import eamm_oracle as orc
+
+KEYS = ("prediction", "mask", "sparse_deformed", "occlusion_map", "deformed")
+DEV = "cuda:0"
+# Bar of an fp32 run against the double gradients, per tensor, relative to the tensor's largest gradient: 4 x the fixture's
+# own fp32-vs-fp64 distance for that tensor, and at least this (one run's distance is a noisy estimate of the floor: another
+# summation order lands elsewhere inside it -- the oracle in fp32 differs from the reference in fp32 by up to 1.5e-3).
+FP32_MIN_REL = 5e-3
+
+
+def fixture():
+    return np.load(os.path.join(GOLDEN, "tiny64_train_backward.npz"))
+
+
+def inputs(n):
+    return synthetic_source(64, seed=1, batch=n), synthetic_keypoints(n, 10, seed=0), synthetic_keypoints(n, 10, seed=2)
+
+
+def sampled(t, step):
+    return t.reshape(-1)[::step] if step > 1 else t
+
+
+def compare(z, grads, floors_allowed, min_rel):
+    """grads: {fixture name: tensor}.  Returns the worst ratio error / bar over all tensors (and asserts every one)."""
+    names = [str(s) for s in z["names"]]
+    assert sorted(grads) == sorted(names)
+    gmax = max(float(z["scale/" + k]) for k in names)
+    worst = (0.0, None)
+    for k in names:
+        want = torch.from_numpy(z["grad64/" + k]).double()
+        got = sampled(grads[k].detach().cpu().double(), int(z["step/" + k]))
+        scale = gmax if bool(z["zero/" + k]) else float(z["scale/" + k])
+        bar = max(floors_allowed * float(z["floor/" + k]), min_rel) * scale
+        err = float((got - want).abs().max())
+        assert err <= bar, (k, err, bar, float(z["floor/" + k]))
+        if err / bar > worst[0]:
+            worst = (err / bar, k)
+    return worst
+
+
+def test_oracle_autograd_matches_reference_gradients():
+    z = fixture()
+    cfg, n = tiny_config(), int(z["n"])
+    sd = synthetic_state_dict(cfg, seed=int(z["weight_seed"]))
+    src, kp_s, kp_d = inputs(n)
+    for dtype, floors, min_rel in ((torch.float64, 0.0, 1e-6), (torch.float32, 4.0, FP32_MIN_REL)):
+        leaf = lambda k, v: v.is_floating_point() and "running" not in k and "down.weight" not in k
+        sdd = {k: (v.to(dtype).requires_grad_() if leaf(k, v) else v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+        s = src.to(dtype).requires_grad_()
+        ks = {k: v.to(dtype).requires_grad_() for k, v in kp_s.items()}
+        kd = {k: v.to(dtype).requires_grad_() for k, v in kp_d.items()}
+        out, _ = orc.generator_forward_train(sdd, cfg, s, kd, ks, parallel=False)
+        loss = sum((out[k] * torch.from_numpy(z["w/" + k]).to(dtype)).sum() for k in KEYS)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(z["loss64"])) <= (1e-9 if dtype == torch.float64 else 2e-4) * abs(float(z["loss64"]))
+        grads = {"source_image": s.grad}
+        grads.update({"kp_source/" + k: v.grad for k, v in ks.items()})
+        grads.update({"kp_driving/" + k: v.grad for k, v in kd.items()})
+        grads.update({"param/" + k: v.grad for k, v in sdd.items() if v.requires_grad})
+        compare(z, grads, floors, min_rel)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _make(cfg, seed):
+    from eamm_amd import OcclusionAwareGenerator
+    gen = OcclusionAwareGenerator(**cfg)
+    gen.load_state_dict(synthetic_state_dict(cfg, seed=seed), strict=True)
+    return gen.to(DEV)
+
+
+def _run_graph(gen, z, n):
+    src, kp_s, kp_d = inputs(n)
+    s = src.to(DEV).requires_grad_()
+    ks = {k: v.to(DEV).requires_grad_() for k, v in kp_s.items()}
+    kd = {k: v.to(DEV).requires_grad_() for k, v in kp_d.items()}
+    out = gen(s, kp_driving=kd, kp_source=ks)
+    loss = sum((out[k] * torch.from_numpy(z["w/" + k]).to(DEV)).sum() for k in KEYS)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {"source_image": s.grad}
+    grads.update({"kp_source/" + k: v.grad for k, v in ks.items()})
+    grads.update({"kp_driving/" + k: v.grad for k, v in kd.items()})
+    grads.update({"param/" + k: p.grad for k, p in gen.named_parameters()})
+    return out, loss, grads
+
+
+@pytest.mark.gpu
+def test_generator_backward_matches_reference_gradients():
+    z = fixture()
+    n = int(z["n"])
+    gen = _make(tiny_config(), int(z["weight_seed"])).train()
+    gen.requires_grad_(True)                                   # fine-tuning opts in (inference is the default use)
+    before = {k: v.clone() for k, v in gen.state_dict().items() if "running_var" in k}
+    out, loss, grads = _run_graph(gen, z, n)
+    for k in KEYS:                                             # the forward of the graph path is the reference's
+        err = float((out[k].detach().cpu() - torch.from_numpy(z["out/" + k])).abs().max())
+        assert err <= (1e-4 if k == "deformed" else 2e-5), (k, err)
+    assert abs(float(loss.detach()) - float(z["loss64"])) <= 5e-4 * abs(float(z["loss64"]))
+    assert all(g is not None for g in grads.values())
+    worst = compare(z, grads, floors_allowed=4.0, min_rel=FP32_MIN_REL)
+    print(f"generator backward: worst error / bar = {worst[0]:.2f} at {worst[1]}")
+    # the running statistics moved, as in every training-mode forward
+    after = gen.state_dict()
+    assert max(float((after[k] - v).abs().max()) for k, v in before.items()) > 1e-3
+
+
+@pytest.mark.gpu
+def test_graph_and_engine_training_forwards_agree():
+    # the same module, the same batch: the differentiable composition and the resumable engine are two routes through the
+    # same kernels' arithmetic (different fusions): outputs and running statistics within the parity bars
+    z = fixture()
+    n = int(z["n"])
+    src, kp_s, kp_d = inputs(n)
+    cu = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    g1 = _make(tiny_config(), 1234).train()
+    with torch.no_grad():
+        o1 = g1(src.to(DEV), kp_driving=cu(kp_d), kp_source=cu(kp_s))
+    g2 = _make(tiny_config(), 1234).train()
+    g2.requires_grad_(True)
+    o2 = g2(src.to(DEV), kp_driving=cu(kp_d), kp_source=cu(kp_s))
+    assert o2["prediction"].requires_grad and not o1["prediction"].requires_grad
+    for k in KEYS:
+        assert float((o1[k] - o2[k].detach()).abs().max()) <= (1e-4 if k == "deformed" else 2e-5), k
+    s1, s2 = g1.state_dict(), g2.state_dict()
+    for k in s1:
+        if "running" in k:
+            assert float((s1[k] - s2[k]).abs().max()) <= 1e-5, k
+
+
+@pytest.mark.gpu
+def test_only_the_key_points_need_a_gradient():
+    # the audio-to-key-point stage trains THROUGH a frozen generator (train.py: optimizer_audio_feature): parameters without
+    # gradients, driving key points with -- the flow's backward alone
+    z = fixture()
+    n = int(z["n"])
+    gen = _make(tiny_config(), 1234).train()
+    src, kp_s, kp_d = inputs(n)
+    kd = {k: v.to(DEV).requires_grad_() for k, v in kp_d.items()}
+    out = gen(src.to(DEV), kp_driving=kd, kp_source={k: v.to(DEV) for k, v in kp_s.items()})
+    loss = sum((out[k] * torch.from_numpy(z["w/" + k]).to(DEV)).sum() for k in KEYS)
+    loss.backward()
+    assert all(p.grad is None for p in gen.parameters())
+    for k in ("value", "jacobian"):
+        name = "kp_driving/" + k
+        want = torch.from_numpy(z["grad64/" + name]).double()
+        err = float((kd[k].grad.cpu().double() - want).abs().max())
+        assert err <= max(4 * float(z["floor/" + name]), FP32_MIN_REL) * float(z["scale/" + name]), (name, err)
