@@ -6,12 +6,14 @@ whose forward AND backward run in libeamm_hip.so:
 * ``warp(features, deformation, occlusion)``  =  ``F.grid_sample(features, deformation) * occlusion``
   forward ``eamm_op_warp``, backward ``eamm_op_warp_backward`` (gradients of all three inputs);
 * ``conv2d_same(x, weight, bias)``  =  ``F.conv2d(x, weight, bias, padding=k // 2)`` for the path's 3x3 / 7x7 filters
-  forward ``eamm_op_conv``; data gradient = ``eamm_op_conv`` of the output gradient with the transposed, flipped filter;
-  weight / bias gradient ``eamm_op_conv_wgrad``.
+  forward ``eamm_op_conv_dev`` (parameters stay in HBM, the filter is packed on the device; F(4x4,3x3) Winograd where the
+  bottleneck's kernel applies, else the implicit GEMM); data gradient = the same entry on the output gradient with the filter
+  read transposed and flipped; weight / bias gradient ``eamm_op_conv_wgrad``.
 
 Together with ``eamm_amd.SynchronizedBatchNorm2d`` (forward and backward) these are every kernel kind a backward pass of the
-generator needs.  They are OP-LEVEL: ``eamm_op_conv`` re-packs the filter on every call, and the generator's end-to-end
-backward (a saved-activation plan over these kernels) is not composed -- DESIGN.md section 8.  GPU only: no CPU fallback.
+generator needs; ``eamm_amd/train_graph.py`` composes them into the generator's differentiable ``.train()`` forward.  They are
+OP-LEVEL: every call packs its filter again (on the device) and allocates its outputs -- DESIGN.md section 8.  GPU only: no
+CPU fallback.
 """
 from __future__ import annotations
 
@@ -97,15 +99,23 @@ class _Conv2dSameFunction(torch.autograd.Function):
     """NHWC x [B,H,W,Cin], OIHW weight, bias -> NHWC [B,H,W,Cout]."""
 
     @staticmethod
-    def _conv(x, weight, bias):
+    def _conv(x, weight, bias, transposed=False):
+        """eamm_op_conv_dev: parameters stay on the device, the filter is packed there.  transposed: `weight` is the FORWARD
+        filter [Cin,Cout,k,k] of the convolution whose data gradient this call computes (x = grad_out)."""
         b, h, w, cin = x.shape
-        cout, _, kh, kw = weight.shape
+        cout = weight.shape[1] if transposed else weight.shape[0]
+        kh, kw = weight.shape[2:]
+        L = _lib.lib()
         out = torch.empty(b, h, w, cout, dtype=torch.float32, device=x.device)
-        wh = weight.detach().to("cpu", torch.float32).contiguous()
-        bh = (bias.detach().to("cpu", torch.float32) if bias is not None else torch.zeros(cout)).contiguous()
+        nwork = L.eamm_op_conv_dev_workspace_floats(b, h, w, cin, cout, kh, kw)
+        if nwork == 0:
+            raise ValueError(f"conv2d_same: unsupported convolution {tuple(x.shape)} x {tuple(weight.shape)}")
+        work = torch.empty(nwork, dtype=torch.float32, device=x.device)
+        wt = weight.detach().contiguous()
+        bt = bias.detach().contiguous() if bias is not None else None
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().eamm_op_conv(x.device.index, _ptr(x), cin, None, 0, b, h, w, 0, _ptr(wh), _ptr(bh), cout, kh, kw,
-                                               0, 0, None, 0, 0, _ptr(out), 0, None, _stream(x.device)), None)
+            _lib.check(L.eamm_op_conv_dev(x.device.index, _ptr(x), b, h, w, cin, _ptr(wt), _ptr(bt), cout, kh, kw, int(transposed),
+                                          _ptr(out), _ptr(work), nwork, _stream(x.device)), None)
         return out
 
     @staticmethod
@@ -123,7 +133,7 @@ class _Conv2dSameFunction(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             # dX = "same" correlation of dY with the filter transposed over (out, in) and flipped over (y, x)
-            gx = _Conv2dSameFunction._conv(grad_out, weight.detach().permute(1, 0, 2, 3).flip(2, 3), None)
+            gx = _Conv2dSameFunction._conv(grad_out, weight, None, transposed=True)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             L = _lib.lib()
             gw = torch.empty_like(weight, memory_format=torch.contiguous_format)

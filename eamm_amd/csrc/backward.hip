@@ -335,7 +335,7 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int 
 
 // db[co] = sum_p dy[p][co] in two fixed-order stages: BIAS_PARTS pixel ranges (a thread owns 4 channels, the 256 / (Cout / 4)
 // row lanes of a block stride the range), then the parts per channel in double
-constexpr int BIAS_PARTS = 512;
+constexpr int BIAS_PARTS = 256;
 __global__ __launch_bounds__(256) void conv_bias_grad_partial_kernel(const float* __restrict__ dy, long long P, int Cout,
                                                                      float* __restrict__ part /*[parts][Cout]*/) {
     __shared__ f32x4 red[256];
@@ -352,12 +352,16 @@ __global__ __launch_bounds__(256) void conv_bias_grad_partial_kernel(const float
         reinterpret_cast<f32x4*>(part)[(size_t)blockIdx.x * c4n + c4] = s;
     }
 }
-__global__ void conv_bias_grad_final_kernel(const float* __restrict__ part, int parts, int Cout, float* __restrict__ db) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cout) return;
+// 64 channels x 4 part lanes per block: each lane adds every 4th part in double, LDS folds the four
+__global__ __launch_bounds__(256) void conv_bias_grad_final_kernel(const float* __restrict__ part, int parts, int Cout, float* __restrict__ db) {
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, r = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     double s = 0.0;
-    for (int k = 0; k < parts; ++k) s += (double)part[(size_t)k * Cout + c];
-    db[c] = (float)s;
+    if (c < Cout)
+        for (int k = r; k < parts; k += 4) s += (double)part[(size_t)k * Cout + c];
+    red[r][cl] = s;
+    __syncthreads();
+    if (r == 0 && c < Cout) db[c] = (float)((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 
 hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int kh, int kw, float* dweight,
@@ -396,7 +400,7 @@ hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int 
     if (dbias != nullptr) {
         const int parts = (int)std::min<long long>(BIAS_PARTS, (a.P + 63) / 64);
         hipLaunchKernelGGL(conv_bias_grad_partial_kernel, dim3(parts), dim3(256), 0, s, dy, a.P, Cout, bias_part);
-        hipLaunchKernelGGL(conv_bias_grad_final_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, bias_part, parts, Cout, dbias);
+        hipLaunchKernelGGL(conv_bias_grad_final_kernel, dim3((Cout + 63) / 64), dim3(256), 0, s, bias_part, parts, Cout, dbias);
     }
     return hipGetLastError();
 }

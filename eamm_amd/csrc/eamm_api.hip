@@ -1484,6 +1484,99 @@ int eamm_op_warp_backward(int device, const float* feat, const float* deformatio
     return EAMM_OK;
 }
 
+// ---- convolution with DEVICE weights (training path): pack on the device into the caller's workspace, then the forward kernels
+namespace {
+struct ConvDevPlan {
+    bool wino4 = false;
+    int BN = 0, ntiles = 0;
+    size_t packed = 0, bias = 0, aux = 0;   // floats: packed filter, padded bias, Winograd V or split-K partials
+    ConvLayer L;
+};
+bool conv_dev_plan(int B, int H, int W, int Cin, int Cout, int kh, int kw, ConvDevPlan* P) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || Cin % CONV_BK || (Cout & 3)) return false;
+    if (!((kh == 3 && kw == 3) || (kh == 7 && kw == 7))) return false;
+    const long long Mq = (long long)B * (H / 4) * (W / 4);
+    // F(4x4,3x3) where the bottleneck's kernel applies and the tile count fills the chip; else the register-staged implicit GEMM
+    static const int wino_off = [] { const char* e = getenv("EAMM_CONV_DEV_WINO4"); return e ? atoi(e) == 0 : 0; }();
+    P->wino4 = !wino_off && kh == 3 && kw == 3 && Cin % (2 * CONV_BK) == 0 && !(H & 3) && !(W & 3) && Mq >= 2048 &&
+               (unsigned long long)36 * Mq * Cin * sizeof(float) < 0xFFFFF000ull &&
+               wino4_packed_elems(Cout, Cin, 64) * sizeof(float) < 0xFFFFF000ull;
+    if (P->wino4) {
+        P->BN = 64;
+        P->ntiles = (Cout + 63) / 64;
+        P->packed = wino4_packed_elems(Cout, Cin, 64);
+        P->aux = (size_t)36 * Mq * Cin;
+    } else {
+        ConvLayer& L = P->L;
+        L.kh = kh;
+        L.kw = kw;
+        L.C0 = Cin;
+        L.Cout = Cout;
+        L.BN = conv_tile_n(Cout);
+        L.ntiles = (Cout + L.BN - 1) / L.BN;
+        L.nchunks = kh * kw * (Cin / CONV_BK);
+        P->BN = L.BN;
+        P->ntiles = L.ntiles;
+        P->packed = conv_packed_elems(kh * kw, Cin, Cout, L.BN, 1);
+        P->aux = conv_plan(L, B * H * W, 0).partial_elems;
+    }
+    P->bias = (size_t)P->ntiles * P->BN;
+    auto up = [](size_t n) { return (n + 63) / 64 * 64; };   // 256-byte aligned sections
+    P->packed = up(P->packed);
+    P->bias = up(P->bias);
+    P->aux = up(P->aux);
+    return true;
+}
+}  // namespace
+
+size_t eamm_op_conv_dev_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
+    ConvDevPlan P;
+    return conv_dev_plan(B, H, W, Cin, Cout, kh, kw, &P) ? P.packed + P.bias + P.aux : 0;
+}
+
+int eamm_op_conv_dev(int device, const float* x, int B, int H, int W, int Cin, const float* weight, const float* bias, int Cout, int kh,
+                     int kw, int transposed, float* out, float* workspace, size_t workspace_floats, void* stream_) {
+    ConvDevPlan P;
+    if (!x || !weight || !out || !workspace || !conv_dev_plan(B, H, W, Cin, Cout, kh, kw, &P))
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv_dev: bad argument (3x3 or 7x7, Cin a multiple of 32, Cout of 4)");
+    if (workspace_floats < P.packed + P.bias + P.aux || (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv_dev: workspace too small or misaligned (%zu floats needed)", P.packed + P.bias + P.aux);
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    float *wp = workspace, *bp = workspace + P.packed, *aux = workspace + P.packed + P.bias;
+    hipError_t e = bias_pad_dev_launch(bias, Cout, P.ntiles * P.BN, bp, s);
+    if (e == hipSuccess && P.wino4) {
+        WinoLayer WL;
+        WL.Cin = Cin;
+        WL.Cout = Cout;
+        WL.tile = 4;
+        WL.BN = 64;
+        WL.ntiles = P.ntiles;
+        WL.u = wp;
+        WL.bias = bp;
+        e = wino4_pack_dev_launch(weight, Cout, Cin, 64, transposed, wp, s);
+        if (e == hipSuccess) e = wino4_transform_launch(x, nullptr, nullptr, B, H, W, Cin, aux, s);
+        if (e == hipSuccess) e = wino4_gemm_launch(WL, aux, B, H, W, ACT_NONE, nullptr, out, s, 3, 1, nullptr, 0);
+    } else if (e == hipSuccess) {
+        ConvLayer& L = P.L;
+        L.w = wp;
+        L.bias = bp;
+        e = conv_pack_dev_launch(weight, Cout, Cin, kh * kw, L.BN, transposed, wp, s);
+        ConvIO io{};
+        io.in0 = x;
+        io.B = B;
+        io.Hin = H;
+        io.Win = W;
+        io.out = out;
+        io.partial = P.aux ? aux : nullptr;
+        io.partial_cap = P.aux;
+        if (e == hipSuccess) e = conv_launch(L, io, s, 0);
+    }
+    if (e != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "eamm_op_conv_dev failed: %s", hipGetErrorString(e));
+    return EAMM_OK;
+}
+
 size_t eamm_op_conv_wgrad_workspace_floats(int Cin, int Cout, int kh, int kw) {
     if (Cin < 1 || Cout < 1 || kh < 1 || kw < 1) return 0;
     return conv_wgrad_workspace_floats(Cin, Cout, kh, kw);

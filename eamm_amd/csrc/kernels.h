@@ -221,4 +221,10 @@ size_t conv_wgrad_workspace_floats(int Cin, int Cout, int kh, int kw);
 hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int kh, int kw, float* dweight,
                              float* dbias, float* workspace, size_t workspace_floats, hipStream_t s);
 
+// conv_pack_dev.hip: the packings of conv_pack_host (register-staged kernel) and wino4_pack_host from a DEVICE OIHW tensor;
+// transposed = 1 reads the forward filter [Cin][Cout][kh][kw] transposed and flipped (the data gradient's filter)
+hipError_t conv_pack_dev_launch(const float* w, int Cout, int Cin, int T, int BN, int transposed, float* dst, hipStream_t s);
+hipError_t wino4_pack_dev_launch(const float* w, int Cout, int Cin, int BN, int transposed, float* dst, hipStream_t s);
+hipError_t bias_pad_dev_launch(const float* b, int Cout, int n, float* dst, hipStream_t s);
+
 }  // namespace eamm

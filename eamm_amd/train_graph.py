@@ -123,17 +123,44 @@ def _heatmaps(value: torch.Tensor, grid: torch.Tensor, variance: float) -> torch
     return torch.exp(-0.5 * (d * d).sum(-1) / variance)
 
 
+_RANK_ONE: Dict[tuple, bool] = {}
+
+
+def _band(taps: torch.Tensor, n_in: int, step: int) -> torch.Tensor:
+    """[n_in, n_out] matrix of a 1-D correlation with `taps`, zero padding len(taps) // 2, every step-th output kept."""
+    ka = taps.numel() // 2
+    n_out = (n_in + step - 1) // step
+    i = torch.arange(n_in, device=taps.device)[:, None]
+    o = torch.arange(n_out, device=taps.device)[None, :]
+    t = i - step * o + ka
+    ok = (t >= 0) & (t < taps.numel())
+    return torch.where(ok, taps[t.clamp(0, taps.numel() - 1)], torch.zeros((), dtype=taps.dtype, device=taps.device))
+
+
+def _antialias_down(x: torch.Tensor, weight: torch.Tensor, scale: float) -> torch.Tensor:
+    """AntiAliasInterpolation2d (util.py:1005-1052): zero-pad, depth-wise Gaussian, keep every (1/scale)-th row and column.
+    The Gaussian is an outer product (util.py:1024-1036), so the filter-and-subsample is two small dense matrix products
+    (rows, then columns) -- rocBLAS GEMMs with their own autograd instead of a 169-tap depth-wise convolution that computes
+    15/16 outputs only to drop them.  A buffer that is not rank one (never the reference's) takes the convolution."""
+    step = int(1 / scale)
+    k = weight[0, 0]
+    gy, gx = k.sum(dim=1), k.sum(dim=0)
+    key = (weight.data_ptr(), weight._version, weight.device)
+    if key not in _RANK_ONE:     # checked once per buffer (a host read)
+        _RANK_ONE.clear()
+        same = weight.shape[0] == 1 or bool(torch.equal(weight[0], weight[-1]))
+        _RANK_ONE[key] = same and float((torch.outer(gy, gx) - k).abs().max()) <= 1e-6 * float(k.abs().max())
+    if not _RANK_ONE[key]:
+        ka = weight.shape[-1] // 2
+        return F.conv2d(F.pad(x, (ka, ka, ka, ka)), weight, groups=x.shape[1])[:, :, ::step, ::step]
+    my, mx = _band(gy, x.shape[2], step), _band(gx, x.shape[3], step)
+    return torch.matmul(my.t(), torch.matmul(x, mx))
+
+
 def _dense_motion(g: _Graph, source_image, kp_driving, kp_source):
     """dense_motion.py:32-113."""
     dm = g.gen.dense_motion_network
-    if dm.scale_factor != 1:                                        # AntiAliasInterpolation2d, util.py:1044-1052
-        wgt = dm.down.weight
-        ka = wgt.shape[-1] // 2
-        src = F.conv2d(F.pad(source_image, (ka, ka, ka, ka)), wgt, groups=source_image.shape[1])
-        step = int(1 / dm.scale_factor)
-        src = src[:, :, ::step, ::step]
-    else:
-        src = source_image
+    src = _antialias_down(source_image, dm.down.weight, dm.scale_factor) if dm.scale_factor != 1 else source_image
     b, c, h, w = src.shape
     k = dm.num_kp
     grid = _grid(h, w, src)
@@ -141,8 +168,10 @@ def _dense_motion(g: _Graph, source_image, kp_driving, kp_source):
     heat = torch.cat([torch.zeros_like(heat[:, :1]), heat], dim=1)[:, :, None]            # [B,K+1,1,h,w]
     rel = grid[None, None] - kp_driving["value"][:, :, None, None, :]                      # dense_motion.py:47-67
     if "jacobian" in kp_driving:
-        jac = torch.matmul(kp_source["jacobian"], torch.inverse(kp_driving["jacobian"]))
-        rel = (jac[:, :, None, None] @ rel[..., None])[..., 0]
+        jac = torch.matmul(kp_source["jacobian"], torch.inverse(kp_driving["jacobian"]))   # [B,K,2,2]
+        j = jac[:, :, None, None]                                                           # 2x2 times a vector, element-wise
+        rel = torch.stack([j[..., 0, 0] * rel[..., 0] + j[..., 0, 1] * rel[..., 1],
+                           j[..., 1, 0] * rel[..., 0] + j[..., 1, 1] * rel[..., 1]], dim=-1)
     moved = rel + kp_source["value"][:, :, None, None, :]
     motions = torch.cat([grid[None, None].expand(b, 1, h, w, 2), moved], dim=1)            # [B,K+1,h,w,2]
     rep = src[:, None].expand(b, k + 1, c, h, w).reshape(b * (k + 1), c, h, w)             # dense_motion.py:69-79

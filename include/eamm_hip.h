@@ -362,6 +362,17 @@ int eamm_op_warp_backward(int device, const float* feat, const float* deformatio
  * (eamm_op_conv_wgrad_workspace_floats floats) and summed in a fixed order: deterministic.  Cin, Cout multiples of 4; kh, kw
  * odd and at most 7.  The DATA gradient of such a convolution is eamm_op_conv on grad_out with the filter transposed and
  * flipped (weight.permute(1,0,2,3).flip(2,3)), which eamm_amd/autograd_ops.py does. */
+/* Stride-1 "same" 3x3 / 7x7 convolution with DEVICE parameters (the training path: they change every optimiser step):
+ * x NHWC [B,H,W,Cin], weight OIHW [Cout,Cin,kh,kw] and bias [Cout] (or NULL) in device memory, out NHWC [B,H,W,Cout].  The filter
+ * is packed on the device into `workspace` (eamm_op_conv_dev_workspace_floats floats, 16-byte aligned) and the evaluation
+ * path's kernels run on it: F(4x4,3x3) Winograd where the bottleneck's kernel applies (3x3, Cin % 64 == 0, H and W multiples of
+ * 4, >= 2048 tiles), else the register-staged implicit GEMM.  transposed = 1 computes the DATA GRADIENT of such a convolution:
+ * x is then grad_out [B,H,W,Cin = the forward's Cout], weight the FORWARD filter [Cin,Cout,kh,kw], read transposed over
+ * (out, in) and flipped over (y, x) while packing.  Asynchronous on `stream`; Cin a multiple of 32, Cout of 4. */
+size_t eamm_op_conv_dev_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw);
+int eamm_op_conv_dev(int device, const float* x, int B, int H, int W, int Cin, const float* weight, const float* bias, int Cout, int kh,
+                     int kw, int transposed, float* out, float* workspace, size_t workspace_floats, void* stream);
+
 size_t eamm_op_conv_wgrad_workspace_floats(int Cin, int Cout, int kh, int kw);
 int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                        float* grad_weight, float* grad_bias, float* workspace, size_t workspace_floats, void* stream);

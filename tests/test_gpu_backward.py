@@ -102,6 +102,9 @@ CONV_CASES = {
     "row_3x3_w64":   dict(B=3, H=5, W=64, cin=128, cout=64, k=3, bias=True),
     "row_7x7_w32":   dict(B=1, H=6, W=32, cin=32, cout=32, k=7, bias=True),           # taller filter than some maps' margin
     "row_7x7_w96":   dict(B=2, H=10, W=96, cin=64, cout=32, k=7, bias=False),
+    # >= 2048 4x4 tiles: forward and data gradient on the F(4x4,3x3) Winograd kernels, filter transformed on the device
+    "wino4_64_64":   dict(B=2, H=128, W=128, cin=64, cout=64, k=3, bias=True),
+    "wino4_128_64":  dict(B=8, H=64, W=64, cin=128, cout=64, k=3, bias=True),          # transposed filter is not square
 }
 
 
