@@ -146,6 +146,29 @@ class _Conv2dSameFunction(torch.autograd.Function):
         return gx, gw, gb
 
 
+def conv2d_same_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``conv2d_same`` on the kernels' own layout: x NHWC [B,H,W,Cin] -> NHWC [B,H,W,Cout] (no layout copies)."""
+    _need_gpu(x, "conv2d_same_nhwc")
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) not in ((3, 3), (7, 7)) or x.shape[3] != cin or cin % _CONV_BK or cout % _CONV_BK:
+        raise ValueError(f"conv2d_same_nhwc: weight {tuple(weight.shape)} / input {tuple(x.shape)} unsupported "
+                         f"(3x3 or 7x7, channels multiples of {_CONV_BK})")
+    if weight.device != x.device or (bias is not None and bias.device != x.device):
+        raise RuntimeError("conv2d_same_nhwc: parameters and input are on different devices")
+    return _Conv2dSameFunction.apply(x.contiguous(), weight, bias)
+
+
+def warp_nhwc(features: torch.Tensor, deformation: torch.Tensor, occlusion: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``warp`` on NHWC features [n|1,h,w,C] (C a multiple of 8), flow [n,h,w,2], occlusion [n,h,w] or None -> NHWC [n,h,w,C]."""
+    _need_gpu(features, "warp_nhwc")
+    n, h, w, two = deformation.shape
+    if two != 2 or features.shape[1:3] != (h, w) or features.shape[0] not in (1, n) or features.shape[3] % 8:
+        raise ValueError(f"warp_nhwc: features {tuple(features.shape)} / deformation {tuple(deformation.shape)} mismatch")
+    if occlusion is not None and tuple(occlusion.shape) != (n, h, w):
+        raise ValueError(f"warp_nhwc: occlusion must be [{n},{h},{w}], got {tuple(occlusion.shape)}")
+    return _WarpFunction.apply(features.contiguous(), deformation.contiguous(), None if occlusion is None else occlusion.contiguous())
+
+
 def conv2d_same(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``F.conv2d(x, weight, bias, padding=k // 2)`` for the path's square 3x3 / 7x7 filters (reference modules/util.py:858-938),
     differentiable in x, weight and bias.  x NCHW [B,Cin,H,W], weight [Cout,Cin,k,k] on the GPU; Cin and Cout multiples of 32

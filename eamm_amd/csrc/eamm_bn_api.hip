@@ -82,4 +82,40 @@ int eamm_bn_backward_apply(const float* x, const float* dy, const float* mean, c
     return bn_check(bn_bwd_apply_launch(x, dy, mean, coef, N, C, HW, dx, reinterpret_cast<hipStream_t>(stream)), "bn_backward_apply");
 }
 
+// ---- the same module on NHWC activations, fused with the block's ReLU and DownBlock2d's 2x2 average (batchnorm_nhwc.hip) ----
+size_t eamm_bn_nhwc_workspace_floats(long long M, int C) {
+    if (M < 1 || C < 4 || (C & 3)) return 0;
+    return bn_nhwc_workspace_floats(M, C);
+}
+
+int eamm_bn_nhwc_local_sums(const float* x, long long M, int C, float* sums, float* workspace, void* stream) {
+    if (!x || !sums || !workspace) return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (M < 1 || C < 4 || (C & 3) || C > 1024 || M >= (1ll << 36)) return bn_fail(EAMM_ERR_ARG, "bad shape [%lld,%d] (C a multiple of 4, at most 1024)", M, C);
+    return bn_check(bn_nhwc_sums_launch(x, M, C, sums, workspace, reinterpret_cast<hipStream_t>(stream)), "bn_nhwc_local_sums");
+}
+
+int eamm_bn_nhwc_apply(const float* x, const float* mean, const float* scale, const float* bias, int B, int H, int W, int C, int relu,
+                       int pool, float* y, void* stream) {
+    if (!x || !mean || !scale || !y) return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (B < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || (pool && ((H | W) & 1))) return bn_fail(EAMM_ERR_ARG, "bad shape [%d,%d,%d,%d]", B, H, W, C);
+    return bn_check(bn_nhwc_apply_launch(x, mean, scale, bias, B, H, W, C, relu, pool, y, reinterpret_cast<hipStream_t>(stream)), "bn_nhwc_apply");
+}
+
+int eamm_bn_nhwc_backward_sums(const float* x, const float* dy, const float* mean, const float* scale, const float* bias, int B, int H,
+                               int W, int C, int relu, int pool, float* sums, float* workspace, void* stream) {
+    if (!x || !dy || !mean || !scale || !sums || !workspace) return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (B < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || C > 1024 || (pool && ((H | W) & 1)))
+        return bn_fail(EAMM_ERR_ARG, "bad shape [%d,%d,%d,%d]", B, H, W, C);
+    return bn_check(bn_nhwc_bwd_sums_launch(x, dy, mean, scale, bias, B, H, W, C, relu, pool, sums, workspace,
+                                            reinterpret_cast<hipStream_t>(stream)), "bn_nhwc_backward_sums");
+}
+
+int eamm_bn_nhwc_backward_apply(const float* x, const float* dy, const float* mean, const float* scale, const float* bias,
+                                const float* coef, int B, int H, int W, int C, int relu, int pool, float* dx, void* stream) {
+    if (!x || !dy || !mean || !scale || !coef || !dx) return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (B < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || (pool && ((H | W) & 1))) return bn_fail(EAMM_ERR_ARG, "bad shape [%d,%d,%d,%d]", B, H, W, C);
+    return bn_check(bn_nhwc_bwd_apply_launch(x, dy, mean, scale, bias, coef, B, H, W, C, relu, pool, dx,
+                                             reinterpret_cast<hipStream_t>(stream)), "bn_nhwc_backward_apply");
+}
+
 }  // extern "C"

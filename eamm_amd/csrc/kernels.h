@@ -210,6 +210,12 @@ size_t bn_nhwc_workspace_floats(long long M, int C);
 hipError_t bn_nhwc_sums_launch(const float* x /*[M,C]*/, long long M, int C, float* sums /*[6C+2]*/, float* workspace, hipStream_t s);
 hipError_t bn_nhwc_apply_launch(const float* x /*[B,H,W,C]*/, const float* mean, const float* scale, const float* bias, int B, int H,
                                 int W, int C, int relu, int pool, float* y, hipStream_t s);
+// backward of the fused tail y = [avgpool2x2](act(BatchNorm(x))) on NHWC: packed sums like bn_bwd_sums_launch, then dx with
+// bn_bwd_finalize_launch's coefficients (the ReLU mask is recomputed from x)
+hipError_t bn_nhwc_bwd_sums_launch(const float* x, const float* dy, const float* mean, const float* scale, const float* bias, int B, int H,
+                                   int W, int C, int relu, int pool, float* sums, float* workspace, hipStream_t s);
+hipError_t bn_nhwc_bwd_apply_launch(const float* x, const float* dy, const float* mean, const float* scale, const float* bias,
+                                    const float* coef, int B, int H, int W, int C, int relu, int pool, float* dx, hipStream_t s);
 hipError_t to_u8_launch(const float* pred /*[n,3,H,W]*/, int n, int H, int W, uint8_t* out /*[n,H,W,3]*/,
                         hipStream_t s);
 

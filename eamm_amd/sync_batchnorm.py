@@ -163,6 +163,66 @@ class _BatchNormFunction(torch.autograd.Function):
         return dx, (dw if ctx.needs_input_grad[1] else None), (db if ctx.needs_input_grad[2] else None), None
 
 
+class _BatchNormNHWCFunction(torch.autograd.Function):
+    """The same module on an NHWC activation [B,H,W,C], fused with the tail of the reference's blocks (modules/util.py:858-938):
+    y = [avgpool2x2](relu(BatchNorm(x))) -- ``eamm_bn_nhwc_*``.  Training mode only (the differentiable generator forward of
+    ``train_graph``); statistics, running-statistics update, the replicas' two all-reduces and the parameter gradients are
+    ``_BatchNormFunction``'s.  Only x is kept for the backward: the ReLU mask is recomputed from it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mod, relu, pool):
+        L = _lib.lib()
+        b, h, w, c = x.shape
+        m = b * h * w
+        dev = x.device
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        world = mod._replicas()
+        parallel = world > 1 if mod.sync is None else bool(mod.sync)
+        sums = torch.empty(6 * c + 2, dtype=torch.float32, device=dev)
+        work = torch.empty(max(1, L.eamm_bn_nhwc_workspace_floats(m, c)), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _check(L.eamm_bn_nhwc_local_sums(ptr(x), m, c, ptr(sums), ptr(work), st))
+            if world > 1 and parallel:
+                mod._all_reduce(sums[:2 * c + 2])
+            mode = BN_SYNC if parallel else BN_SINGLE
+            mean, scale, inv_std = mod._ops.finalize(sums, mod, mode)
+            y = torch.empty((b, h // 2, w // 2, c) if pool else (b, h, w, c), dtype=torch.float32, device=dev)
+            _check(L.eamm_bn_nhwc_apply(ptr(x), ptr(mean), ptr(scale), ptr(bias), b, h, w, c, int(relu), int(pool), ptr(y), st))
+        ctx.mod, ctx.mode, ctx.relu, ctx.pool = mod, mode, bool(relu), bool(pool)
+        ctx.reduce = mode == BN_SYNC and world > 1
+        ctx.save_for_backward(x, mean, scale, inv_std, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, scale, inv_std, weight, bias = ctx.saved_tensors
+        mod = ctx.mod
+        L = _lib.lib()
+        b, h, w, c = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        local = torch.empty(6 * c + 2, dtype=torch.float32, device=dev)
+        work = torch.empty(max(1, L.eamm_bn_nhwc_workspace_floats(b * h * w, c)), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _check(L.eamm_bn_nhwc_backward_sums(ptr(x), ptr(dy), ptr(mean), ptr(scale), ptr(bias), b, h, w, c, int(ctx.relu),
+                                                int(ctx.pool), ptr(local), ptr(work), st))
+            reduced = local
+            if ctx.reduce:
+                reduced = local.clone()
+                mod._all_reduce(reduced[:2 * c + 2])
+            want_wb = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+            coef, dw, db = mod._ops.backward_finalize(local, reduced, inv_std, weight, mod.eps, ctx.mode, want_wb)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _check(L.eamm_bn_nhwc_backward_apply(ptr(x), ptr(dy), ptr(mean), ptr(scale), ptr(bias), ptr(coef), b, h, w, c,
+                                                     int(ctx.relu), int(ctx.pool), ptr(dx), st))
+        return dx, (dw if ctx.needs_input_grad[1] else None), (db if ctx.needs_input_grad[2] else None), None, None, None
+
+
 class SynchronizedBatchNorm2d(_BatchNorm):
     """MI355X-native stand-in for reference sync_batchnorm/batchnorm.py:SynchronizedBatchNorm2d (forward and backward).
 

@@ -6,13 +6,15 @@ The reference composes ``nn.Conv2d`` / ``SynchronizedBatchNorm2d`` / ``F.grid_sa
 them (modules/generator.py:59-97, dense_motion.py:32-113, util.py:858-1002).  Here the same composition is built from this
 package's operators, each a ``torch.autograd.Function`` whose forward AND backward are libeamm_hip.so kernels:
 
-* every convolution          ``autograd_ops.conv2d_same``   (fp32-MFMA forward / data gradient / weight gradient)
-* every BatchNorm            ``sync_batchnorm._BatchNormFunction``  (batch statistics, replicas' all-reduce, backward)
-* every bilinear warp        ``autograd_ops.warp``          (feature warp x occlusion, the K+1 sparse warps, ``deformed``)
+* every convolution          ``autograd_ops.conv2d_same_nhwc``  (fp32-MFMA forward / data gradient / weight gradient)
+* every BatchNorm + ReLU     ``sync_batchnorm._BatchNormNHWCFunction``  (batch statistics, replicas' all-reduce, the block's ReLU
+                             and DownBlock2d's 2x2 average fused; backward with the mask recomputed)
+* every bilinear warp        ``autograd_ops.warp_nhwc``     (feature warp x occlusion, the K+1 sparse warps, ``deformed``)
 
-The remaining steps are element-wise or a few hundred floats (ReLU, 2x2 average, nearest x2, softmax over the K+1 motions,
-sigmoid, heat-maps, 2x2 jacobian algebra, channel padding to the kernels' 32-channel granule) and stay torch-ROCm ops with
-their own autograd.  This is the OP-LEVEL composition: it exists so that the backward kernels are exercised and verified in
+Activations stay NHWC -- the kernels' layout -- from the source image to the prediction; the remaining steps are element-wise
+or a few hundred floats (nearest x2, residual add, softmax over the K+1 motions, sigmoid, heat-maps, 2x2 jacobian algebra,
+channel padding to the kernels' 32-channel granule, anti-aliasing as two banded GEMMs) and stay torch-ROCm ops with their
+own autograd.  This is the OP-LEVEL composition: it exists so that the backward kernels are exercised and verified in
 the generator's real data flow (tests/test_gpu_train_backward.py: gradients against the reference's autograd fixture); it
 re-packs filters per call and is not the tuned path -- the inference engine and the resumable training forward are.
 GPU only: no CPU fallback.
@@ -25,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import autograd_ops
-from .sync_batchnorm import SynchronizedBatchNorm2d, _BatchNormFunction
+from .sync_batchnorm import SynchronizedBatchNorm2d, _BatchNormNHWCFunction
 
 _G = 32   # channel granule of the convolution kernels
 
@@ -34,46 +36,57 @@ def _round_up(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
+def _pad_last(x: torch.Tensor, mult: int) -> torch.Tensor:
+    c = x.shape[-1]
+    return x if c % mult == 0 else F.pad(x, (0, _round_up(c, mult) - c))
+
+
 def conv(x: torch.Tensor, mod: torch.nn.Conv2d) -> torch.Tensor:
-    """``mod(x)`` for the path's stride-1 "same" 3x3 / 7x7 convolutions; channels zero-padded to the kernels' granule
-    (the padded filter rows / columns are zeros and receive no gradient through the slice)."""
+    """``mod(x)`` for the path's stride-1 "same" 3x3 / 7x7 convolutions on NHWC [B,H,W,Cin] -> NHWC [B,H,W,Cout]; channels
+    zero-padded to the kernels' granule (the padded filter rows / columns are zeros and the slice drops their gradient)."""
     w, b = mod.weight, mod.bias
     cout, cin = w.shape[:2]
     cin_p, cout_p = _round_up(cin, _G), _round_up(cout, _G)
     if cin_p != cin:
-        x = F.pad(x, (0, 0, 0, 0, 0, cin_p - cin))
+        x = _pad_last(x, _G)
         w = F.pad(w, (0, 0, 0, 0, 0, cin_p - cin))
     if cout_p != cout:
         w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_p - cout))
         b = F.pad(b, (0, cout_p - cout)) if b is not None else None
-    y = autograd_ops.conv2d_same(x, w, b)
-    return y[:, :cout] if cout_p != cout else y
+    y = autograd_ops.conv2d_same_nhwc(x, w, b)
+    return y[..., :cout] if cout_p != cout else y
 
 
 def warp(features: torch.Tensor, deformation: torch.Tensor, occlusion=None) -> torch.Tensor:
-    """generator.py:50-57 (+ :79-84 with an occlusion map): flow and occlusion resized bilinearly to the features first."""
-    h, w = features.shape[2:]
+    """generator.py:50-57 (+ :79-84 with an occlusion map) on NHWC features; flow [n,h',w',2] and occlusion [n,h',w'] are
+    resized bilinearly to the features first, as the reference does."""
+    h, w = features.shape[1:3]
     if deformation.shape[1:3] != (h, w):
         deformation = F.interpolate(deformation.permute(0, 3, 1, 2), size=(h, w), mode="bilinear",
                                     align_corners=False).permute(0, 2, 3, 1)
-    if occlusion is not None and occlusion.shape[2:] != (h, w):
-        occlusion = F.interpolate(occlusion, size=(h, w), mode="bilinear", align_corners=False)
-    c = features.shape[1]
-    cp = _round_up(c, 8)
-    if cp != c:
-        features = F.pad(features, (0, 0, 0, 0, 0, cp - c))
-    out = autograd_ops.warp(features, deformation.contiguous(), occlusion)
-    return out[:, :c] if cp != c else out
+    if occlusion is not None and occlusion.shape[1:3] != (h, w):
+        occlusion = F.interpolate(occlusion[:, None], size=(h, w), mode="bilinear", align_corners=False)[:, 0]
+    c = features.shape[3]
+    out = autograd_ops.warp_nhwc(_pad_last(features, 8), deformation, occlusion)
+    return out[..., :c] if c % 8 else out
+
+
+def _upsample2(x: torch.Tensor) -> torch.Tensor:
+    """F.interpolate(scale_factor=2), nearest (util.py:896), on NHWC: one broadcast copy."""
+    b, h, w, c = x.shape
+    return x[:, :, None, :, None, :].expand(b, h, 2, w, 2, c).reshape(b, 2 * h, 2 * w, c)
 
 
 class _Graph:
-    """One forward's bookkeeping: the generator (parameter holder), its BatchNorm adapters, the replicas' settings."""
+    """One forward's bookkeeping: the generator (parameter holder), its BatchNorm adapters, the replicas' settings.
+    Activations are NHWC [B,H,W,C] between the operators -- the convolution and warp kernels' own layout."""
 
     def __init__(self, gen):
         self.gen = gen
         self.adapters: Dict[int, SynchronizedBatchNorm2d] = gen.__dict__.setdefault("_bn_adapters", {})
 
-    def norm(self, x: torch.Tensor, holder: torch.nn.BatchNorm2d) -> torch.Tensor:
+    def norm_relu(self, x: torch.Tensor, holder: torch.nn.BatchNorm2d, pool: bool = False) -> torch.Tensor:
+        """[avgpool2x2](relu(BatchNorm(x))) in one fused operator (every BatchNorm of the generator is followed by a ReLU)."""
         # the holder owns the tensors (state_dict names of the reference); the adapter lends them to the Function
         a = self.adapters.get(id(holder))
         if a is None:
@@ -83,22 +96,26 @@ class _Graph:
         a._buffers["running_mean"], a._buffers["running_var"] = holder.running_mean, holder.running_var
         a.training = True
         a.process_group, a.sync = self.gen.process_group, self.gen.sync_batchnorm
-        a._check_device(x)
-        return _BatchNormFunction.apply(x.contiguous(), holder.weight, holder.bias, a)
+        if x.shape[3] != holder.num_features:
+            raise RuntimeError(f"expected {holder.num_features} channels, got {x.shape[3]}")
+        a._ops.check(x, a)
+        if a._replicas() == 1 and x.numel() // x.shape[3] <= 1:      # batchnorm.py:112
+            raise AssertionError("BatchNorm computes unbiased standard-deviation, which requires size > 1.")
+        return _BatchNormNHWCFunction.apply(x.contiguous(), holder.weight, holder.bias, a, True, pool)
 
     # ---- blocks: modules/util.py:858-938 --------------------------------------------------------------------------------
     def same_block(self, x, blk):
-        return F.relu(self.norm(conv(x, blk.conv), blk.norm))
+        return self.norm_relu(conv(x, blk.conv), blk.norm)
 
     def down_block(self, x, blk):
-        return F.avg_pool2d(self.same_block(x, blk), kernel_size=(2, 2))
+        return self.norm_relu(conv(x, blk.conv), blk.norm, pool=True)
 
     def up_block(self, x, blk):
-        return self.same_block(F.interpolate(x, scale_factor=2), blk)
+        return self.same_block(_upsample2(x), blk)
 
     def res_block(self, x, blk):
-        y = conv(F.relu(self.norm(x, blk.norm1)), blk.conv1)
-        y = conv(F.relu(self.norm(y, blk.norm2)), blk.conv2)
+        y = conv(self.norm_relu(x, blk.norm1), blk.conv1)
+        y = conv(self.norm_relu(y, blk.norm2), blk.conv2)
         return y + x
 
     def hourglass(self, x, hg):                                    # util.py:941-1002
@@ -107,7 +124,7 @@ class _Graph:
             skips.append(self.down_block(skips[-1], blk))
         out = skips.pop()
         for blk in hg.decoder.up_blocks:
-            out = torch.cat([self.up_block(out, blk), skips.pop()], dim=1)
+            out = torch.cat([self.up_block(out, blk), skips.pop()], dim=3)
         return out
 
 
@@ -158,14 +175,14 @@ def _antialias_down(x: torch.Tensor, weight: torch.Tensor, scale: float) -> torc
 
 
 def _dense_motion(g: _Graph, source_image, kp_driving, kp_source):
-    """dense_motion.py:32-113."""
+    """dense_motion.py:32-113.  source_image NCHW as the caller passed it."""
     dm = g.gen.dense_motion_network
     src = _antialias_down(source_image, dm.down.weight, dm.scale_factor) if dm.scale_factor != 1 else source_image
     b, c, h, w = src.shape
     k = dm.num_kp
     grid = _grid(h, w, src)
     heat = _heatmaps(kp_driving["value"], grid, dm.kp_variance) - _heatmaps(kp_source["value"], grid, dm.kp_variance)
-    heat = torch.cat([torch.zeros_like(heat[:, :1]), heat], dim=1)[:, :, None]            # [B,K+1,1,h,w]
+    heat = torch.cat([torch.zeros_like(heat[:, :1]), heat], dim=1)                         # [B,K+1,h,w]
     rel = grid[None, None] - kp_driving["value"][:, :, None, None, :]                      # dense_motion.py:47-67
     if "jacobian" in kp_driving:
         jac = torch.matmul(kp_source["jacobian"], torch.inverse(kp_driving["jacobian"]))   # [B,K,2,2]
@@ -174,37 +191,41 @@ def _dense_motion(g: _Graph, source_image, kp_driving, kp_source):
                            j[..., 1, 0] * rel[..., 0] + j[..., 1, 1] * rel[..., 1]], dim=-1)
     moved = rel + kp_source["value"][:, :, None, None, :]
     motions = torch.cat([grid[None, None].expand(b, 1, h, w, 2), moved], dim=1)            # [B,K+1,h,w,2]
-    rep = src[:, None].expand(b, k + 1, c, h, w).reshape(b * (k + 1), c, h, w)             # dense_motion.py:69-79
-    warped = warp(rep, motions.reshape(b * (k + 1), h, w, 2)).view(b, k + 1, c, h, w)
-    feat = g.hourglass(torch.cat([heat, warped], dim=2).view(b, (k + 1) * (c + 1), h, w), dm.hourglass)
-    mask = F.softmax(conv(feat, dm.mask), dim=1)                                           # dense_motion.py:98-99
-    deformation = (motions * mask[..., None]).sum(dim=1)                                   # :101-104
-    out = {"sparse_deformed": warped, "mask": mask, "deformation": deformation}
+    src_nhwc = src.permute(0, 2, 3, 1)                                                      # dense_motion.py:69-79
+    rep = src_nhwc[:, None].expand(b, k + 1, h, w, c).reshape(b * (k + 1), h, w, c)
+    warped = warp(rep, motions.reshape(b * (k + 1), h, w, 2)).view(b, k + 1, h, w, c)      # NHWC per (pair, motion)
+    # hourglass input: channel (k, j) with j = 0 the heat-map, 1..c the warped source (dense_motion.py:93-94)
+    hg_in = torch.cat([heat.permute(0, 2, 3, 1)[..., None], warped.permute(0, 2, 3, 1, 4)], dim=4).reshape(b, h, w, (k + 1) * (c + 1))
+    feat = g.hourglass(hg_in, dm.hourglass)
+    mask = F.softmax(conv(feat, dm.mask), dim=3)                                           # [B,h,w,K+1]  dense_motion.py:98-99
+    deformation = (motions * mask.permute(0, 3, 1, 2)[..., None]).sum(dim=1)               # [B,h,w,2]    :101-104
+    out = {"sparse_deformed": warped.permute(0, 1, 4, 2, 3), "mask": mask.permute(0, 3, 1, 2), "deformation": deformation}
     if dm.occlusion is not None:
-        out["occlusion_map"] = torch.sigmoid(conv(feat, dm.occlusion))
+        out["occlusion_map"] = torch.sigmoid(conv(feat, dm.occlusion))[..., 0]             # [B,h,w]
     return out
 
 
 def forward_train(gen, source_image: torch.Tensor, kp_driving, kp_source) -> Dict[str, torch.Tensor]:
-    """OcclusionAwareGenerator.forward in ``.train()`` mode WITH an autograd graph (generator.py:59-97)."""
+    """OcclusionAwareGenerator.forward in ``.train()`` mode WITH an autograd graph (generator.py:59-97); NCHW in and out."""
     if source_image.device.type != "cuda":
         raise RuntimeError("eamm_amd.OcclusionAwareGenerator runs only on a ROCm GPU (there is no CPU fallback for this path)")
     g = _Graph(gen)
-    out = g.same_block(source_image, gen.first)                                           # generator.py:61-63
+    src_nhwc = source_image.permute(0, 2, 3, 1)
+    out = g.same_block(src_nhwc, gen.first)                                               # generator.py:61-63
     for blk in gen.down_blocks:
         out = g.down_block(out, blk)
     result = {}
     if gen.dense_motion_network is not None:                                               # generator.py:64-86
         dmo = _dense_motion(g, source_image, kp_driving, kp_source)
-        result["mask"], result["sparse_deformed"] = dmo["mask"], dmo["sparse_deformed"]
+        result["mask"], result["sparse_deformed"] = dmo["mask"].contiguous(), dmo["sparse_deformed"].contiguous()
         occ = dmo.get("occlusion_map")
         if occ is not None:
-            result["occlusion_map"] = occ
+            result["occlusion_map"] = occ[:, None]
         out = warp(out, dmo["deformation"], occ)
-        result["deformed"] = warp(source_image, dmo["deformation"])
+        result["deformed"] = warp(src_nhwc, dmo["deformation"]).permute(0, 3, 1, 2).contiguous()
     for blk in gen.bottleneck:                                                             # generator.py:89-93
         out = g.res_block(out, blk)
     for blk in gen.up_blocks:
         out = g.up_block(out, blk)
-    result["prediction"] = torch.sigmoid(conv(out, gen.final))
+    result["prediction"] = torch.sigmoid(conv(out, gen.final)).permute(0, 3, 1, 2).contiguous()
     return result

@@ -253,6 +253,20 @@ int eamm_bn_backward_finalize(const float* local_sums, const float* reduced_sums
                               void* stream);
 int eamm_bn_backward_apply(const float* x, const float* dy, const float* mean, const float* coef, int N, int C, int HW, float* dx,
                            void* stream);
+
+/* The same BatchNorm on NHWC activations x [B,H,W,C] (= [M,C], M = B*H*W; what the path's convolutions produce), fused with the
+ * tail of the reference's blocks (modules/util.py:858-938): y = [avgpool2x2](act((x - mean) * scale + bias)), relu = 1 | 0,
+ * pool = 1 | 0 (DownBlock2d; H, W even; y is [B,H/2,W/2,C]).  Statistics / finalize / backward_finalize are the layout-free
+ * entries above (same packed `sums`).  Backward: grad_out has y's shape; the ReLU mask is recomputed from x, so x is all the
+ * forward keeps.  C a multiple of 4, at most 1024. */
+size_t eamm_bn_nhwc_workspace_floats(long long M, int C);
+int eamm_bn_nhwc_local_sums(const float* x, long long M, int C, float* sums, float* workspace, void* stream);
+int eamm_bn_nhwc_apply(const float* x, const float* mean, const float* scale, const float* bias, int B, int H, int W, int C, int relu,
+                       int pool, float* y, void* stream);
+int eamm_bn_nhwc_backward_sums(const float* x, const float* grad_out, const float* mean, const float* scale, const float* bias, int B,
+                               int H, int W, int C, int relu, int pool, float* sums, float* workspace, void* stream);
+int eamm_bn_nhwc_backward_apply(const float* x, const float* grad_out, const float* mean, const float* scale, const float* bias,
+                                const float* coef, int B, int H, int W, int C, int relu, int pool, float* grad_x, void* stream);
 int eamm_bn_apply(const float* x, const float* mean, const float* scale, const float* bias, int N, int C, int HW, float* y,
                   void* stream);
 const char* eamm_bn_last_error(void);

@@ -188,6 +188,48 @@ def test_conv_wgrad_7x1_filter(H, W):
     assert err <= 2e-5, err
 
 
+@pytest.mark.parametrize("relu,pool,sync", [(True, False, None), (True, True, None), (False, False, None), (True, True, True)])
+def test_fused_nhwc_batchnorm_matches_autograd(relu, pool, sync):
+    # [avgpool2x2](relu(BatchNorm(x))) on NHWC, training mode (reference modules/util.py:858-938 block tails): forward, running
+    # statistics and every gradient against torch autograd in double; sync=True: the replicas' clamp formula on one rank
+    from eamm_amd.sync_batchnorm import SynchronizedBatchNorm2d, _BatchNormNHWCFunction
+    B, H, W, C = 3, 10, 12, 40
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+    wt, bs = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    gout = torch.randn(B, C, H // 2 if pool else H, W // 2 if pool else W, generator=g)
+    xr, wr, br = x.double().requires_grad_(), wt.double().requires_grad_(), bs.double().requires_grad_()
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    if sync:    # sync_batchnorm/batchnorm.py:110-125: clamp(var, eps) ** -0.5, running_var from the unbiased variance
+        mean = xr.mean(dim=(0, 2, 3))
+        var = ((xr - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
+        y = (xr - mean[None, :, None, None]) * (var.clamp(1e-5) ** -0.5 * wr)[None, :, None, None] + br[None, :, None, None]
+        n = B * H * W
+        rm, rv = 0.9 * rm + 0.1 * mean.detach(), 0.9 * rv + 0.1 * var.detach() * n / (n - 1)
+    else:
+        y = F.batch_norm(xr, rm, rv, wr, br, True, 0.1, 1e-5)
+    y = F.relu(y) if relu else y
+    y = F.avg_pool2d(y, 2) if pool else y
+    y.backward(gout.double())
+
+    mod = SynchronizedBatchNorm2d(C, sync=sync).to(DEV).train()
+    with torch.no_grad():
+        mod.weight.copy_(wt)
+        mod.bias.copy_(bs)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_()
+    out = _BatchNormNHWCFunction.apply(xd, mod.weight, mod.bias, mod, relu, pool)
+    out.backward(gout.permute(0, 2, 3, 1).contiguous().to(DEV))
+    torch.cuda.synchronize()
+
+    def rel(got, want):
+        return float((got.detach().cpu().double() - want).abs().max()) / max(1.0, float(want.abs().max()))
+
+    errs = {"y": rel(out.permute(0, 3, 1, 2), y.detach()), "dx": rel(xd.grad.permute(0, 3, 1, 2), xr.grad),
+            "dw": rel(mod.weight.grad, wr.grad), "db": rel(mod.bias.grad, br.grad),
+            "rm": rel(mod.running_mean, rm), "rv": rel(mod.running_var, rv)}
+    assert all(v <= 5e-6 for v in errs.values()), errs
+
+
 def test_backward_entry_points_reject_bad_arguments():
     L = _lib.lib()
     t = torch.zeros(64, device=DEV)
