@@ -29,7 +29,8 @@ for size_tag in ("256_b16", "512_b8"):
         table.update({k: v for k, v in json.load(open(t)).items() if f"_{size}x{size}_" in k})
 r = os.path.join(G, f"{rnd}_{tag}")
 for src, dst in (("bench_256_b16.json", f"{rnd}_bench_256_b16.json"), ("bench_512_b8.json", f"{rnd}_bench_512_b8.json"),
-                 ("module_latency.txt", f"{rnd}_module_latency.txt"), ("bn_bench.txt", f"{rnd}_bn_bench.txt")):
+                 ("module_latency.txt", f"{rnd}_module_latency.txt"), ("bn_bench.txt", f"{rnd}_bn_bench.txt"),
+                 ("backward_bench.txt", f"{rnd}_backward_bench.txt"), ("train_step.txt", f"{rnd}_train_step.txt")):
     if os.path.exists(os.path.join(r, src)):
         shutil.copy(os.path.join(r, src), os.path.join(P, dst))
 json.dump(table, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
