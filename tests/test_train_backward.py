@@ -173,3 +173,117 @@ def test_only_the_key_points_need_a_gradient():
         diff = (kd[k].grad.cpu().double() - want).abs().reshape(-1)
         bar = max(4 * float(z["floor/" + name]), FP32_MIN_REL) * float(z["scale/" + name])
         assert float(diff.median()) <= bar and float(diff.max()) <= 20 * bar, (name, float(diff.max()), bar)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# replicas and constructor variants: the oracle's training branch, differentiated in double, is the reference here
+def _oracle_gradients(cfg, sd, src, kp_s, kp_d, weights, parallel):
+    leaf = lambda k, v: v.is_floating_point() and "running" not in k and "down.weight" not in k
+    sdd = {k: (v.double().requires_grad_() if leaf(k, v) else v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    ks = {k: v.double().requires_grad_() for k, v in kp_s.items()}
+    kd = {k: v.double().requires_grad_() for k, v in kp_d.items()}
+    out, _ = orc.generator_forward_train(sdd, cfg, src.double(), kd, ks, parallel=parallel)
+    sum((out[k] * weights[k].double()).sum() for k in weights).backward()
+    grads = {"param/" + k: v.grad for k, v in sdd.items() if v.requires_grad}
+    grads.update({"kp_source/" + k: v.grad for k, v in ks.items()})
+    grads.update({"kp_driving/" + k: v.grad for k, v in kd.items()})
+    return grads
+
+
+def _close(got, want, what):
+    """fp32 run against the double gradients, without per-tensor floors: the reference's own fp32 run sits up to 9.3e-3 of a
+    tensor's largest entry away from its double run on this network (fixture: up_blocks.0.conv.weight; 7.9e-3
+    down_blocks.1.norm.weight, ...), so the bar is 2e-2 -- 95 % of a tensor's entries within it, none beyond 10 x (a wrong
+    kernel is off by the gradient's own size)."""
+    gmax = max(float(v.abs().max()) for v in want.values())
+    for k, w in want.items():
+        diff = (got[k].detach().cpu().double() - w).abs().reshape(-1)
+        scale = float(w.abs().max())
+        bar = 2e-2 * (scale if scale >= 1e-9 * gmax else gmax)
+        q = float(torch.quantile(diff, 0.95)) if diff.numel() >= 40 else float(diff.max())
+        assert q <= bar and float(diff.max()) <= 10 * bar, (what, k, q, float(diff.max()), bar)
+
+
+def _ddp_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    z = fixture()
+    n, split = int(z["n"]), 3
+    sl = slice(0, split) if rank == 0 else slice(split, n)
+    src, kp_s, kp_d = inputs(n)
+    gen = _make(tiny_config(), int(z["weight_seed"])).train()      # replicas because world > 1 (sync_batchnorm None)
+    gen.requires_grad_(True)
+    ks = {k: v[sl].to(DEV).requires_grad_() for k, v in kp_s.items()}
+    kd = {k: v[sl].to(DEV).requires_grad_() for k, v in kp_d.items()}
+    out = gen(src[sl].to(DEV), kp_driving=kd, kp_source=ks)
+    loss = sum((out[k] * torch.from_numpy(z["w/" + k])[sl].to(DEV)).sum() for k in KEYS)
+    loss.backward()
+    torch.cuda.synchronize()
+    blob = {"param/" + k: p.grad.cpu().numpy() for k, p in gen.named_parameters()}
+    blob.update({"kp_source/" + k: v.grad.cpu().numpy() for k, v in ks.items()})
+    blob.update({"kp_driving/" + k: v.grad.cpu().numpy() for k, v in kd.items()})
+    np.savez(os.path.join(tmp, f"grad{rank}.npz"), **blob)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_replicas_gradients_add_up_to_the_whole_batch(tmp_path):
+    """Two processes sharing GPU 0 under gloo, shards of 3 and 1 pairs, loss.backward() on each: the BatchNorm statistics AND
+    the backward's (sum dy, sum dy * xhat) are all-reduced per site, so the replicas' parameter gradients must ADD UP to --
+    and their key-point gradients BE the slices of -- the gradient of the whole batch under the replicas' formula
+    (what the reference's DataParallel master accumulates, sync_batchnorm/batchnorm.py:55-125)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    z = fixture()
+    n, split = int(z["n"]), 3
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=int(z["weight_seed"]))
+    src, kp_s, kp_d = inputs(n)
+    want = _oracle_gradients(cfg, sd, src, kp_s, kp_d, {k: torch.from_numpy(z["w/" + k]) for k in KEYS}, parallel=True)
+    r = [np.load(tmp_path / f"grad{i}.npz") for i in (0, 1)]
+    got = {}
+    for k in want:
+        if k.startswith("param/"):
+            got[k] = torch.from_numpy(r[0][k]) + torch.from_numpy(r[1][k])
+        else:
+            got[k] = torch.cat([torch.from_numpy(r[0][k]), torch.from_numpy(r[1][k])])
+    _close(got, want, "two replicas")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["no_jacobian", "no_motion_network"])
+def test_generator_backward_variants_against_oracle_autograd(variant):
+    """Branches of the differentiable forward: key points without jacobians (dense_motion.py:55) and a generator built
+    without a motion network (generator.py:22-23)."""
+    cfg = tiny_config()
+    if variant == "no_motion_network":
+        cfg = dict(cfg, dense_motion_params=None, estimate_occlusion_map=False)
+    n = 3
+    sd = synthetic_state_dict(cfg, seed=77)
+    src = synthetic_source(64, seed=3, batch=n)
+    kp_s = synthetic_keypoints(n, 10, seed=4, jacobian=variant != "no_jacobian")
+    kp_d = synthetic_keypoints(n, 10, seed=5, jacobian=variant != "no_jacobian")
+    gen = _make(cfg, 77).train()
+    gen.requires_grad_(True)
+    ks = {k: v.to(DEV).requires_grad_() for k, v in kp_s.items()}
+    kd = {k: v.to(DEV).requires_grad_() for k, v in kp_d.items()}
+    out = gen(src.to(DEV), kp_driving=kd, kp_source=ks)
+    g = torch.Generator().manual_seed(9)
+    weights = {k: torch.randn(out[k].shape, generator=g) for k in out}
+    sum((out[k] * weights[k].to(DEV)).sum() for k in out).backward()
+    want = _oracle_gradients(cfg, sd, src, kp_s, kp_d, weights, parallel=False)
+    got = {"param/" + k: p.grad for k, p in gen.named_parameters()}
+    if variant == "no_motion_network":     # the key points are never looked at (generator.py:64)
+        assert all(v.grad is None for v in list(ks.values()) + list(kd.values()))
+        want = {k: v for k, v in want.items() if k.startswith("param/") and v is not None}
+    else:
+        got.update({"kp_source/" + k: v.grad for k, v in ks.items()})
+        got.update({"kp_driving/" + k: v.grad for k, v in kd.items()})
+    _close(got, want, variant)
