@@ -138,7 +138,7 @@ class _Conv2dSameFunction(torch.autograd.Function):
             L = _lib.lib()
             gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
             gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            nwork = L.eamm_op_conv_wgrad_workspace_floats(cin, cout, kh, kw)
+            nwork = L.eamm_op_conv_wgrad_workspace_floats(b, h, w, cin, cout, kh, kw)
             work = torch.empty(max(1, nwork), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
                 _lib.check(L.eamm_op_conv_wgrad(x.device.index, _ptr(x), _ptr(grad_out), b, h, w, cin, cout, kh, kw, _ptr(gw), _ptr(gb),

@@ -134,7 +134,9 @@ struct WgradArgs {
     long long P;         // B*H*W
     long long per_split; // pixels per split (multiple of 64)
     int splits, mt, nt;  // pixel splits, Cout tiles, Cin tiles (64 each)
-    float* partial;      // [splits][kh*kw][mt*64][nt*64]
+    float* partial;      // [splits][planes*kh*kw][mt*64][nt*64]
+    int planes;          // independent GEMMs stacked along the grid (the 36 transform points of the Winograd form; else 1)
+    long long a_plane, b_plane;   // their strides in dy / x (floats)
 };
 
 // block (tile pair, tap, split): D[64 co][64 ci] += sum over the split's pixels; 4 waves of 32 x 32, v_mfma_f32_32x32x2_f32.
@@ -153,9 +155,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     const int mti = L % p.mt; L /= p.mt;
     const int taps = p.kh * p.kw;
     const int tap = L % taps; L /= taps;
+    const int plane = L % p.planes; L /= p.planes;
     const int split = L;
     const int dyo = tap / p.kw - p.kh / 2, dxo = tap % p.kw - p.kw / 2;
     const int p0 = (int)((long long)split * p.per_split), p1 = (int)std::min<long long>(p.P, (long long)p0 + p.per_split);
+    const float* const pdy = p.dy + plane * p.a_plane;
+    const float* const px_ = p.x + plane * p.b_plane;
     f32x16 acc;
     static_for<16>([&](auto rc) { acc[decltype(rc)::value] = 0.f; });
     // loader: thread -> (rows lr + 16 j of the chunk, 16-byte group lq of the 64 channels)
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         px[h2] = (int)(pp % (unsigned)p.W);
         py[h2] = (int)((pp / (unsigned)p.W) % (unsigned)p.H);
     }
-    const float* ap = p.dy + (size_t)(p0 + lr) * p.Cout + co;                                   // row lr of the current chunk
-    const float* bp = p.x + ((long long)(p0 + lr) + (long long)dyo * p.W + dxo) * p.Cin + ci;   // the tap's shifted pixel
+    const float* ap = pdy + (size_t)(p0 + lr) * p.Cout + co;                                   // row lr of the current chunk
+    const float* bp = px_ + ((long long)(p0 + lr) + (long long)dyo * p.W + dxo) * p.Cin + ci;   // the tap's shifted pixel
     const size_t a16 = (size_t)16 * p.Cout, b16 = (size_t)16 * p.Cin;
     f32x4 ra[RPT], rb[RPT];
     auto fetch = [&](int pc) {
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         }
     }
     // D layout of the 32x32 MFMA: lane -> column n = lane % 32; register r -> row m = (r % 4) + 8 * (r / 4) + 4 * (lane / 32)
-    float* out = p.partial + (((size_t)split * taps + tap) * (p.mt * TM) + mti * TM + wm * 32) * (size_t)(p.nt * TN) + nti * TN + wn * 32;
+    float* out = p.partial + (((size_t)split * taps * p.planes + (size_t)plane * taps + tap) * (p.mt * TM) + mti * TM + wm * 32) * (size_t)(p.nt * TN) + nti * TN + wn * 32;
     static_for<16>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -319,6 +324,95 @@ __global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs p) 
     });
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 weight gradient in Winograd form F(3x3, 4x4): the filter gradient of a 4x4 output tile is itself a minimal-filtering
+// problem -- dW[k][l] = sum_{a,b<4} dY[a][b] d[a+k][b+l] over the tile's 6x6 input patch d, the same correlation as the forward
+// with the roles of filter and output exchanged -- so with the forward's points {0, +-1, +-2, inf}
+//     dW = sum_tiles  A'^T [ (G' g G'^T) (.) (B^T d B) ] A',    g = the tile of dY,
+//     G' (6x4) rows p^k / N_p: [1/4 0 0 0; -1/6 -1/6 -1/6 -1/6; -1/6 1/6 -1/6 1/6; 1/24 1/12 1/6 1/3; 1/24 -1/12 1/6 -1/3; 0 0 0 1],
+//     A'^T (3x6) = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 1],
+// and B^T d B is exactly the forward's V (wino4_input_transform_kernel).  36 multiplies per (tile, cin, cout) instead of 144:
+// the sum over tiles is 36 independent GEMMs  M_xi[co][ci] = sum_q Yhat_xi[q][co] V_xi[q][ci]  (K = tiles, both operands K-major)
+// on the per-tap GEMM kernel above with the transform points as its `planes`, then one 36 -> 9 output transform per (co, ci).
+// (Identity checked in float64 in tests/test_transform_identities.py.)
+template <typename T> __device__ __forceinline__ void gp4(const T g0, const T g1, const T g2, const T g3, T* r) {
+    const T e = g0 + g2, o = g1 + g3;
+    r[0] = 0.25f * g0;
+    r[1] = (-1.f / 6.f) * (e + o);
+    r[2] = (-1.f / 6.f) * (e - o);
+    const T e2 = (1.f / 24.f) * g0 + (1.f / 6.f) * g2, o2 = (1.f / 12.f) * g1 + (1.f / 3.f) * g3;
+    r[3] = e2 + o2;
+    r[4] = e2 - o2;
+    r[5] = g3;
+}
+
+// one thread per (tile, 4 channels): 16 loads, 36 stores; Yhat[xi][q][c], q = (b, qy, qx) as the forward's V
+__global__ __launch_bounds__(256) void wino4_dy_transform_kernel(const float* __restrict__ dy, int B, int H, int W, int C,
+                                                                 float* __restrict__ Yh) {
+    const int c4n = C >> 2, Hq = H >> 2, Wq = W >> 2;
+    const size_t Mq = (size_t)B * Hq * Wq, total = Mq * c4n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const size_t q = idx / c4n;
+        const int qx = (int)(q % Wq), qy = (int)((q / Wq) % Hq);
+        const size_t b = q / ((size_t)Wq * Hq);
+        const f32x4* img = reinterpret_cast<const f32x4*>(dy) + ((b * H + 4 * qy) * W + 4 * qx) * c4n + c4;
+        f32x4 g[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) g[a][bb] = img[((size_t)a * W + bb) * c4n];
+        f32x4 t[6][4];   // G' g (columns)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            f32x4 r[6];
+            gp4(g[0][bb], g[1][bb], g[2][bb], g[3][bb], r);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][bb] = r[i];
+        }
+        f32x4* out = reinterpret_cast<f32x4*>(Yh) + q * c4n + c4;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            f32x4 r[6];
+            gp4(t[i][0], t[i][1], t[i][2], t[i][3], r);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) out[(size_t)(i * 6 + j) * Mq * c4n] = r[j];
+        }
+    }
+}
+
+// dW[co][ci][3][3] = A'^T (sum over the splits of M[36][co][ci]) A', in a fixed order
+__global__ void wino4_wgrad_output_kernel(const float* __restrict__ partial, int splits, int Mpad, int Npad, int Cout, int Cin,
+                                          float* __restrict__ dw) {
+    const size_t total = (size_t)Cout * Cin;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin), co = (int)(i / Cin);
+        float m[6][6];
+#pragma unroll
+        for (int xi = 0; xi < 36; ++xi) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += partial[(((size_t)k * 36 + xi) * Mpad + co) * Npad + ci];
+            m[xi / 6][xi % 6] = s;
+        }
+        float t[3][6];   // A'^T m
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float s12 = m[1][j] + m[2][j], d12 = m[1][j] - m[2][j], s34 = m[3][j] + m[4][j], d34 = m[3][j] - m[4][j];
+            t[0][j] = m[0][j] + s12 + s34;
+            t[1][j] = d12 + 2.f * d34;
+            t[2][j] = s12 + 4.f * s34 + m[5][j];
+        }
+        float* o = dw + i * 9;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float s12 = t[k][1] + t[k][2], d12 = t[k][1] - t[k][2], s34 = t[k][3] + t[k][4], d34 = t[k][3] - t[k][4];
+            o[k * 3 + 0] = t[k][0] + s12 + s34;
+            o[k * 3 + 1] = d12 + 2.f * d34;
+            o[k * 3 + 2] = s12 + 4.f * s34 + t[k][5];
+        }
+    }
+}
+
 // dW[co][ci][tap] (OIHW) = sum over the splits, in a fixed order
 __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int taps, int Mpad, int Npad, int Cout, int Cin,
                                          float* __restrict__ dw) {
@@ -364,51 +458,108 @@ __global__ __launch_bounds__(256) void conv_bias_grad_final_kernel(const float* 
     if (r == 0 && c < Cout) db[c] = (float)((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 
+size_t conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw);
+
+namespace {
+// F(3x3,4x4) form: 3x3, map sides multiples of 4, enough tiles for the GEMMs' K (EAMM_WGRAD_WINO4 = 0 turns it off)
+bool wgrad_wino4_applies(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
+    static const int off = [] { const char* e = getenv("EAMM_WGRAD_WINO4"); return e ? atoi(e) == 0 : 0; }();
+    static const long long min_tiles = [] { const char* e = getenv("EAMM_WGRAD_WINO4_MIN_TILES"); return e ? atoll(e) : 512ll; }();
+    return !off && kh == 3 && kw == 3 && !(H & 3) && !(W & 3) && !(Cin & 3) && !(Cout & 3) &&
+           (long long)B * (H / 4) * (W / 4) >= min_tiles;
+}
+long long wgrad_splits(long long tiles, long long K, long long min_k) {
+    return std::max<long long>(1, std::min<long long>(1024 / std::max<long long>(1, tiles) + 1, K / min_k));
+}
+size_t round64(size_t n) { return (n + 63) / 64 * 64; }
+}  // namespace
+
 hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int kh, int kw, float* dweight,
                              float* dbias, float* workspace, size_t workspace_floats, hipStream_t s) {
     if ((Cin & 3) || (Cout & 3) || Cout > 1024 || !(kh & 1) || !(kw & 1) || B < 1 || (long long)B * H * W >= (1ll << 30)) return hipErrorInvalidValue;
+    if (workspace_floats < conv_wgrad_workspace_floats(B, H, W, Cin, Cout, kh, kw)) return hipErrorInvalidValue;
     const size_t bias_floats = (size_t)BIAS_PARTS * Cout;   // the tail of the workspace
-    if (workspace_floats < bias_floats) return hipErrorInvalidValue;
     workspace_floats -= bias_floats;
     float* bias_part = workspace + workspace_floats;
     WgradArgs a{};
-    a.x = x;
-    a.dy = dy;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.kh = kh; a.kw = kw;
     a.P = (long long)B * H * W;
     a.mt = (Cout + 63) / 64;
     a.nt = (Cin + 63) / 64;
+    a.planes = 1;
     const int taps = kh * kw;
-    static const int row_off = [] { const char* e = getenv("EAMM_WGRAD_ROW"); return e ? atoi(e) == 0 : 0; }();
-    const bool row = !row_off && W % 32 == 0 && (kw == 1 || kw == 3 || kw == 7);   // one block per filter row (else: per tap)
-    const long long tiles = (long long)a.mt * a.nt * (row ? kh : taps);
-    long long splits = std::max<long long>(1, std::min<long long>(1024 / std::max<long long>(1, tiles) + 1, a.P / 256));
-    const size_t per = (size_t)taps * a.mt * 64 * a.nt * 64;
-    while (splits > 1 && (size_t)splits * per > workspace_floats) --splits;
-    if ((size_t)splits * per > workspace_floats) return hipErrorInvalidValue;
-    a.per_split = ((a.P + splits - 1) / splits + 63) / 64 * 64;
-    a.splits = (int)((a.P + a.per_split - 1) / a.per_split);
-    a.partial = workspace;
-    const dim3 grid((unsigned)(tiles * a.splits));
-    if (row && kw == 1) hipLaunchKernelGGL(conv_wgrad_row_kernel<1>, grid, dim3(256), 0, s, a);
-    else if (row && kw == 3) hipLaunchKernelGGL(conv_wgrad_row_kernel<3>, grid, dim3(256), 0, s, a);
-    else if (row) hipLaunchKernelGGL(conv_wgrad_row_kernel<7>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<32>, grid, dim3(256), 0, s, a);
-    const size_t total = (size_t)Cout * Cin * taps;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, s, workspace,
-                       a.splits, taps, a.mt * 64, a.nt * 64, Cout, Cin, dweight);
+    if (wgrad_wino4_applies(B, H, W, Cin, Cout, kh, kw)) {
+        const long long Mq = (long long)B * (H / 4) * (W / 4);
+        float* V = workspace;
+        float* Yh = V + round64((size_t)36 * Mq * Cin);
+        float* partial = Yh + round64((size_t)36 * Mq * Cout);
+        hipError_t e = wino4_transform_launch(x, nullptr, nullptr, B, H, W, Cin, V, s);
+        if (e != hipSuccess) return e;
+        const size_t ty = (size_t)Mq * (Cout / 4);
+        hipLaunchKernelGGL(wino4_dy_transform_kernel, dim3((unsigned)std::min<size_t>((ty + 255) / 256, (size_t)1 << 20)), dim3(256), 0, s, dy,
+                           B, H, W, Cout, Yh);
+        // the 36 GEMMs as planes of the per-tap kernel: a "1x1 filter" over Mq "pixels" in one row
+        a.x = V;
+        a.dy = Yh;
+        a.kh = a.kw = 1;
+        a.H = 1;
+        a.W = (int)Mq;
+        a.P = Mq;
+        a.planes = 36;
+        a.a_plane = Mq * Cout;
+        a.b_plane = Mq * Cin;
+        // (a 128 x 128 block tile for these GEMMs -- twice the flop per operand byte -- measured slower: 0.446 vs 0.398 ms at
+        //  256 -> 256 @ 64 x 64 x 16; many small blocks hide the f32 MFMA's issue stalls better than few large ones)
+        const long long tiles = (long long)a.mt * a.nt * 36;
+        const long long splits = wgrad_splits(tiles, Mq, 128);
+        a.per_split = ((Mq + splits - 1) / splits + 63) / 64 * 64;
+        a.splits = (int)((Mq + a.per_split - 1) / a.per_split);
+        a.partial = partial;
+        hipLaunchKernelGGL(conv_wgrad_kernel<32>, dim3((unsigned)(tiles * a.splits)), dim3(256), 0, s, a);
+        const size_t pairs = (size_t)Cout * Cin;
+        hipLaunchKernelGGL(wino4_wgrad_output_kernel, dim3((unsigned)std::min<size_t>((pairs + 255) / 256, 65535)), dim3(256), 0, s, partial,
+                           a.splits, a.mt * 64, a.nt * 64, Cout, Cin, dweight);
+    } else {
+        a.x = x;
+        a.dy = dy;
+        static const int row_off = [] { const char* e = getenv("EAMM_WGRAD_ROW"); return e ? atoi(e) == 0 : 0; }();
+        const bool row = !row_off && W % 32 == 0 && (kw == 1 || kw == 3 || kw == 7);   // one block per filter row (else: per tap)
+        const long long tiles = (long long)a.mt * a.nt * (row ? kh : taps);
+        const long long splits = wgrad_splits(tiles, a.P, 256);
+        a.per_split = ((a.P + splits - 1) / splits + 63) / 64 * 64;
+        a.splits = (int)((a.P + a.per_split - 1) / a.per_split);
+        a.partial = workspace;
+        const dim3 grid((unsigned)(tiles * a.splits));
+        if (row && kw == 1) hipLaunchKernelGGL(conv_wgrad_row_kernel<1>, grid, dim3(256), 0, s, a);
+        else if (row && kw == 3) hipLaunchKernelGGL(conv_wgrad_row_kernel<3>, grid, dim3(256), 0, s, a);
+        else if (row) hipLaunchKernelGGL(conv_wgrad_row_kernel<7>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv_wgrad_kernel<32>, grid, dim3(256), 0, s, a);
+        const size_t total = (size_t)Cout * Cin * taps;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, s, workspace,
+                           a.splits, taps, a.mt * 64, a.nt * 64, Cout, Cin, dweight);
+    }
     if (dbias != nullptr) {
-        const int parts = (int)std::min<long long>(BIAS_PARTS, (a.P + 63) / 64);
-        hipLaunchKernelGGL(conv_bias_grad_partial_kernel, dim3(parts), dim3(256), 0, s, dy, a.P, Cout, bias_part);
+        const long long P = (long long)B * H * W;
+        const int parts = (int)std::min<long long>(BIAS_PARTS, (P + 63) / 64);
+        hipLaunchKernelGGL(conv_bias_grad_partial_kernel, dim3(parts), dim3(256), 0, s, dy, P, Cout, bias_part);
         hipLaunchKernelGGL(conv_bias_grad_final_kernel, dim3((Cout + 63) / 64), dim3(256), 0, s, bias_part, parts, Cout, dbias);
     }
     return hipGetLastError();
 }
 
-size_t conv_wgrad_workspace_floats(int Cin, int Cout, int kh, int kw) {
-    const size_t per = (size_t)kh * kw * ((Cout + 63) / 64) * 64 * ((Cin + 63) / 64) * 64;
-    const long long tiles = (long long)((Cout + 63) / 64) * ((Cin + 63) / 64) * kh;   // the row kernel's count (the per-tap kernel has kw x more)
-    return per * (size_t)(1024 / std::max<long long>(1, tiles) + 1) + (size_t)BIAS_PARTS * Cout;
+size_t conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
+    const size_t per_tap = (size_t)((Cout + 63) / 64) * 64 * ((Cin + 63) / 64) * 64;
+    const long long mn = (long long)((Cout + 63) / 64) * ((Cin + 63) / 64);
+    size_t need;
+    if (wgrad_wino4_applies(B, H, W, Cin, Cout, kh, kw)) {
+        const long long Mq = (long long)B * (H / 4) * (W / 4);
+        const size_t part = per_tap * 36 * (size_t)wgrad_splits(mn * 36, Mq, 128);
+        need = round64((size_t)36 * Mq * Cin) + round64((size_t)36 * Mq * Cout) + part;
+    } else {
+        // the row kernel's block count (the per-tap kernel has kw x more tiles, hence fewer splits)
+        need = per_tap * kh * kw * (size_t)wgrad_splits(mn * kh, (long long)B * H * W, 256);
+    }
+    return round64(need) + (size_t)BIAS_PARTS * Cout;
 }
 
 }  // namespace eamm

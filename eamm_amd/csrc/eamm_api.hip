@@ -1577,9 +1577,9 @@ int eamm_op_conv_dev(int device, const float* x, int B, int H, int W, int Cin, c
     return EAMM_OK;
 }
 
-size_t eamm_op_conv_wgrad_workspace_floats(int Cin, int Cout, int kh, int kw) {
-    if (Cin < 1 || Cout < 1 || kh < 1 || kw < 1) return 0;
-    return conv_wgrad_workspace_floats(Cin, Cout, kh, kw);
+size_t eamm_op_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1) return 0;
+    return conv_wgrad_workspace_floats(B, H, W, Cin, Cout, kh, kw);
 }
 
 int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B, int H, int W, int Cin, int Cout, int kh, int kw,

@@ -223,7 +223,7 @@ hipError_t to_u8_launch(const float* pred /*[n,3,H,W]*/, int n, int H, int W, ui
 // convolution's weights and bias (NHWC activations, OIHW gradient)
 hipError_t warp_features_backward_launch(const float* feat, const float* defo, const float* occ, const float* dout, int n, int ns,
                                          int hf, int wf, int C, float* dfeat, float* ddefo, float* docc, hipStream_t s);
-size_t conv_wgrad_workspace_floats(int Cin, int Cout, int kh, int kw);
+size_t conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw);
 hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int kh, int kw, float* dweight,
                              float* dbias, float* workspace, size_t workspace_floats, hipStream_t s);
 

@@ -372,9 +372,11 @@ int eamm_op_warp_backward(int device, const float* feat, const float* deformatio
 
 /* Weight and bias gradient of a stride-1 "same" KHxKW convolution (every Conv2d of modules/util.py:858-938): x NHWC
  * [B,H,W,Cin], grad_out NHWC [B,H,W,Cout] -> grad_weight OIHW [Cout,Cin,kh,kw] (device), grad_bias [Cout] (device, or NULL).
- * One fp32-MFMA GEMM per filter tap, K = the B*H*W pixels split over workgroups, partial sums in `workspace`
- * (eamm_op_conv_wgrad_workspace_floats floats) and summed in a fixed order: deterministic.  Cin, Cout multiples of 4; kh, kw
- * odd and at most 7.  The DATA gradient of such a convolution is eamm_op_conv on grad_out with the filter transposed and
+ * fp32-MFMA GEMMs with K = the B*H*W pixels split over workgroups, partial sums in `workspace`
+ * (eamm_op_conv_wgrad_workspace_floats floats for this shape) and summed in a fixed order: deterministic.  Forms: Winograd
+ * F(3x3,4x4) for 3x3 filters on maps with sides multiples of 4 and at least 512 tiles (36 GEMMs over the tiles on the forward's
+ * transformed input: a quarter of the multiplies), one GEMM per filter ROW for maps with W % 32 == 0, else one per tap.
+ * Cin, Cout multiples of 4, Cout <= 1024; kh, kw odd and at most 7.  The DATA gradient of such a convolution is eamm_op_conv on grad_out with the filter transposed and
  * flipped (weight.permute(1,0,2,3).flip(2,3)), which eamm_amd/autograd_ops.py does. */
 /* Stride-1 "same" 3x3 / 7x7 convolution with DEVICE parameters (the training path: they change every optimiser step):
  * x NHWC [B,H,W,Cin], weight OIHW [Cout,Cin,kh,kw] and bias [Cout] (or NULL) in device memory, out NHWC [B,H,W,Cout].  The filter
@@ -387,7 +389,7 @@ size_t eamm_op_conv_dev_workspace_floats(int B, int H, int W, int Cin, int Cout,
 int eamm_op_conv_dev(int device, const float* x, int B, int H, int W, int Cin, const float* weight, const float* bias, int Cout, int kh,
                      int kw, int transposed, float* out, float* workspace, size_t workspace_floats, void* stream);
 
-size_t eamm_op_conv_wgrad_workspace_floats(int Cin, int Cout, int kh, int kw);
+size_t eamm_op_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw);
 int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                        float* grad_weight, float* grad_bias, float* workspace, size_t workspace_floats, void* stream);
 

@@ -148,7 +148,7 @@ def test_conv_wgrad_is_deterministic_and_linear():
     g1 = torch.randn(B, H, W, cout, generator=g).to(DEV)
     g2 = torch.randn(B, H, W, cout, generator=g).to(DEV)
     L = _lib.lib()
-    nwork = L.eamm_op_conv_wgrad_workspace_floats(cin, cout, k, k)
+    nwork = L.eamm_op_conv_wgrad_workspace_floats(B, H, W, cin, cout, k, k)
     work = torch.empty(nwork, device=DEV)
 
     def wgrad(go):
@@ -179,7 +179,7 @@ def test_conv_wgrad_7x1_filter(H, W):
     L = _lib.lib()
     xd, gd = x.permute(0, 2, 3, 1).contiguous().to(DEV), gout.permute(0, 2, 3, 1).contiguous().to(DEV)
     dw = torch.full((cout, cin, 7, 1), float("nan"), device=DEV)
-    nwork = L.eamm_op_conv_wgrad_workspace_floats(cin, cout, 7, 1)
+    nwork = L.eamm_op_conv_wgrad_workspace_floats(B, H, W, cin, cout, 7, 1)
     work = torch.empty(nwork, device=DEV)
     _lib.check(L.eamm_op_conv_wgrad(0, xd.data_ptr(), gd.data_ptr(), B, H, W, cin, cout, 7, 1, dw.data_ptr(), None, work.data_ptr(),
                                     nwork, torch.cuda.current_stream().cuda_stream), None)

@@ -104,3 +104,35 @@ def test_first_block_reduction_order_covers_every_tap_and_colour_once():
             assert 4 * tap + c == 2 * s + half
             seen.add((tap, c))
     assert seen == {(t, c) for t in range(49) for c in range(4)}
+
+
+# Winograd F(3x3,4x4) for the WEIGHT gradient (csrc/backward.hip): the filter gradient of a 4x4 output tile is the same
+# correlation with filter and output exchanged; same points, so B^T d B is the forward's transformed input
+GW4 = np.array([[1 / 4, 0, 0, 0], [-1 / 6, -1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6, 1 / 6], [1 / 24, 1 / 12, 1 / 6, 1 / 3],
+                [1 / 24, -1 / 12, 1 / 6, -1 / 3], [0, 0, 0, 1]], dtype=np.float64)
+AT3 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 1]], dtype=np.float64)
+
+
+def test_winograd_f3x3_4x4_gives_the_weight_gradient_of_a_same_convolution():
+    """dW[co][ci] = sum over 4x4 tiles of A'^T [(G' dY_tile G'^T) (.) (B^T patch B)] A' equals the gradient autograd derives for
+    F.conv2d(x, w, padding=1) (reference modules/util.py:858-938), zero padding included (patches clipped at the borders)."""
+    rng = np.random.default_rng(5)
+    H, W, C, Co = 8, 12, 3, 2
+    x = rng.standard_normal((H, W, C))
+    dy = rng.standard_normal((H, W, Co))
+    xp = np.pad(x, ((1, 1), (1, 1), (0, 0)))
+    want = np.zeros((Co, C, 3, 3))
+    for k in range(3):
+        for l in range(3):
+            want[:, :, k, l] = np.einsum("hwo,hwc->oc", dy, xp[k:k + H, l:l + W, :])
+    got = np.zeros((Co, C, 3, 3))
+    m = np.zeros((6, 6, Co, C))
+    for qy in range(H // 4):
+        for qx in range(W // 4):
+            d = xp[4 * qy:4 * qy + 6, 4 * qx:4 * qx + 6, :]                      # patch origin (4qy - 1, 4qx - 1) of the unpadded map
+            g = dy[4 * qy:4 * qy + 4, 4 * qx:4 * qx + 4, :]
+            V = np.einsum("ia,abc,jb->ijc", BT, d, BT)
+            Yh = np.einsum("ia,abo,jb->ijo", GW4, g, GW4)
+            m += np.einsum("ijo,ijc->ijoc", Yh, V)                                # the 36 GEMMs' K step
+    got = np.einsum("ki,ijoc,lj->ockl", AT3, m, AT3)
+    assert np.abs(got - want).max() < 1e-11

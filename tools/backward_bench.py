@@ -50,7 +50,7 @@ def main():
         dy = torch.randn(B, H, W, cout, generator=g).to(dev)
         dw = torch.empty(cout, cin, k, k, device=dev)
         db = torch.empty(cout, device=dev)
-        nwork = L.eamm_op_conv_wgrad_workspace_floats(cin, cout, k, k)
+        nwork = L.eamm_op_conv_wgrad_workspace_floats(B, H, W, cin, cout, k, k)
         work = torch.empty(nwork, device=dev)
         ms_w = timed(lambda: _lib.check(L.eamm_op_conv_wgrad(0, x.data_ptr(), dy.data_ptr(), B, H, W, cin, cout, k, k, dw.data_ptr(),
                                                              db.data_ptr(), work.data_ptr(), nwork, st), None))
