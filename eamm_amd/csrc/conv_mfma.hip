@@ -188,16 +188,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs p, in
         const int r = (int)(rem / p.Cout);
         const float bias = p.bias[n];
         if (p.pool) {
-            float v = 0.f;
-            for (int e = 0; e < 4; ++e) {
-                float s = 0.f;
-                for (int sp = 0; sp < splits; ++sp)
-                    s += partial[(size_t)(sp * p.nphase + phase) * slab + (size_t)(4 * r + e) * p.Npad + n];
-                v += apply_act(s + bias, p.act);
+            // the four pixels of the window as four independent sums (sixteen loads in flight per thread); each keeps its order
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int sp = 0; sp < splits; ++sp) {
+                const float* q = partial + (size_t)(sp * p.nphase + phase) * slab + (size_t)(4 * r) * p.Npad + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s4[e] += q[(size_t)e * p.Npad];
             }
+            float v = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v += apply_act(s4[e] + bias, p.act);
             p.out[(size_t)r * p.Cout + n] = 0.25f * v;
         } else {
             float s = 0.f;
+#pragma unroll 16   // independent loads in flight; the additions keep their order
             for (int sp = 0; sp < splits; ++sp)
                 s += partial[(size_t)(sp * p.nphase + phase) * slab + (size_t)r * p.Npad + n];
             int b, y, x;
