@@ -17,6 +17,7 @@ encoder (the reference recomputes it per frame, generator.py:61-63 inside demo.p
 """
 from __future__ import annotations
 
+import operator
 from typing import Dict, Iterable, Optional
 
 import torch
@@ -24,6 +25,9 @@ from torch import nn
 
 from .engine import Engine
 from .weights import antialias_kernel, generator_channels, hourglass_channels
+
+
+_VERSION_OF = operator.attrgetter("_version")
 
 
 class _ConvNorm(nn.Module):
@@ -146,7 +150,8 @@ class OcclusionAwareGenerator(nn.Module):
 
     def _weights_version(self):
         # identity AND version: a replaced tensor may carry the same version counter as the one it replaces
-        return tuple((id(store[key]), store[key]._version) for store, key, _ in self._tensor_slots())
+        ts = [store[key] for store, key, _ in self._tensor_slots()]
+        return tuple(map(id, ts)) + tuple(map(_VERSION_OF, ts))
 
     def _ensure_engine(self, height: int, width: int, frames: int, sources: int) -> Engine:
         dev = next(self.parameters()).device
