@@ -49,7 +49,8 @@ struct CtxBase {
     std::map<std::string, HostTensor> sd;
     bool finalized = false;
     std::vector<void*> owned;   // every device allocation, freed by free_owned()
-    int dma_min_m = 1024;       // smallest per-phase M for which an LDS-DMA tile is preferred
+    int dma_min_m = 4608;       // smallest per-phase M for which an LDS-DMA tile is preferred (1024 until round 3: the 512x64 tile left the
+                                // last hourglass decoder level at 8-32 workgroups for calls of 1-4 frames; one frame 1044 -> 1076 frames/s)
     int big_min_m = 49152;      // ... and for which Cout % 256 == 0 layers use the 256x256 tile (>= 192 M tiles)
     int dma_cfg_n256 = 2, dma_cfg_n128 = 2, dma_cfg_n64 = 3;
     int patch_poly = 1;         // up blocks on the patch kernel in the polyphase minimal-filtering form (EAMM_PATCH_POLY; 0: collapsed-phase form)
