@@ -387,12 +387,13 @@ __global__ void wino4_wgrad_output_kernel(const float* __restrict__ partial, int
     const size_t total = (size_t)Cout * Cin;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int ci = (int)(i % Cin), co = (int)(i / Cin);
-        float m[6][6];
+        float m[6][6];   // splits outer, the 36 points inner: 36 independent loads in flight per step, each point's order fixed
 #pragma unroll
-        for (int xi = 0; xi < 36; ++xi) {
-            float s = 0.f;
-            for (int k = 0; k < splits; ++k) s += partial[(((size_t)k * 36 + xi) * Mpad + co) * Npad + ci];
-            m[xi / 6][xi % 6] = s;
+        for (int xi = 0; xi < 36; ++xi) m[xi / 6][xi % 6] = 0.f;
+        for (int k = 0; k < splits; ++k) {
+            const float* q = partial + ((size_t)k * 36 * Mpad + co) * Npad + ci;
+#pragma unroll
+            for (int xi = 0; xi < 36; ++xi) m[xi / 6][xi % 6] += q[(size_t)xi * Mpad * Npad];
         }
         float t[3][6];   // A'^T m
 #pragma unroll
