@@ -423,6 +423,7 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int 
         const int ci = (int)((i / taps) % Cin);
         const int co = (int)(i / ((size_t)taps * Cin));
         float s = 0.f;
+#pragma unroll 8   // independent loads in flight; the additions keep their order
         for (int k = 0; k < splits; ++k) s += partial[(((size_t)k * taps + tap) * Mpad + co) * Npad + ci];
         dw[i] = s;
     }
@@ -438,8 +439,10 @@ __global__ __launch_bounds__(256) void conv_bias_grad_partial_kernel(const float
     const int rows = 256 / c4n, c4 = threadIdx.x % c4n, r = threadIdx.x / c4n;
     const long long per = (P + gridDim.x - 1) / gridDim.x, p0 = (long long)blockIdx.x * per, p1 = std::min<long long>(P, p0 + per);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (r < rows)
+    if (r < rows) {
+#pragma unroll 8
         for (long long pp = p0 + r; pp < p1; pp += rows) s += reinterpret_cast<const f32x4*>(dy)[pp * c4n + c4];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (r == 0) {

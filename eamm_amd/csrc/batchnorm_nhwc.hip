@@ -23,6 +23,7 @@ __global__ __launch_bounds__(NB_THREADS) void bn_nhwc_partial_kernel(const float
     const int c4 = threadIdx.x % C4, lane_r = threadIdx.x / C4, lanes = NB_THREADS / C4;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (lane_r < lanes) {
+#pragma unroll 4
         for (long long m = (long long)blockIdx.x * lanes + lane_r; m < M; m += (long long)R * lanes) {
             const float4 v = x[m * C4 + c4];
             s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(NB_THREADS) void bn_nhwc_bwd_partial_kernel(const f
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (lane_r < lanes) {
         const float4 m = mean[c4], sc = scale[c4], b = bias ? bias[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
         for (long long r = (long long)blockIdx.x * lanes + lane_r; r < M; r += (long long)R * lanes) {
             const float4 v = x[r * C4 + c4];
             const float4 g = bn_nhwc_upstream<POOL>(dy, v, m, sc, b, relu, r, c4, C4, H, W);
@@ -171,10 +173,11 @@ __global__ __launch_bounds__(NB_THREADS) void bn_nhwc_bwd_apply_kernel(const flo
     }
 }
 
-// slices of the row range: enough blocks to fill the chip, each with >= ~64 rows per row lane
+// slices of the row range: enough blocks to fill the chip, each with >= ~16 rows per row lane (64 until the combine kernel
+// stopped walking the slices serially: 256 channels x 32768 rows were 128 workgroups, 1.6 TB/s)
 static int nhwc_slices(long long M, int C4) {
     const int lanes = std::max(1, NB_THREADS / C4);
-    const long long want = std::max<long long>(1, M / ((long long)lanes * 64));
+    const long long want = std::max<long long>(1, M / ((long long)lanes * 16));
     return (int)std::min<long long>(1024, want);
 }
 
