@@ -1577,6 +1577,36 @@ int eamm_op_conv_dev(int device, const float* x, int B, int H, int W, int Cin, c
     return EAMM_OK;
 }
 
+// ---- the 7x7 layers with three channels on one side (conv7_thin.hip)
+size_t eamm_op_conv7_thin_workspace_floats(int B, int H, int W, int N) {
+    if (B < 1 || H < 1 || W < 1 || (N != 32 && N != 64)) return 0;
+    return conv7_thin_workspace_floats(B, H, W, N);
+}
+
+int eamm_op_conv7_thin(int device, const float* thin, const float* weight, const float* bias, int B, int H, int W, int N, int transposed,
+                       float* out, float* workspace, size_t workspace_floats, void* stream_) {
+    if (!thin || !weight || !out || !workspace || B < 1 || H < 1 || W < 1 || (N != 32 && N != 64) ||
+        workspace_floats < conv7_thin_workspace_floats(B, H, W, N) || (long long)B * H * W * 64 >= (1ll << 31))
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv7_thin: bad argument (N = 32 | 64, workspace of eamm_op_conv7_thin_workspace_floats)");
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
+    hipError_t e = conv7_thin_in_launch(thin, weight, bias, B, H, W, N, transposed, out, workspace, reinterpret_cast<hipStream_t>(stream_));
+    if (e != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "eamm_op_conv7_thin failed: %s", hipGetErrorString(e));
+    return EAMM_OK;
+}
+
+int eamm_op_conv7_thin_wgrad(int device, const float* thin, const float* wide, int B, int H, int W, int N, int thin_is_input,
+                             float* grad_weight, float* workspace, size_t workspace_floats, void* stream_) {
+    if (!thin || !wide || !grad_weight || !workspace || B < 1 || H < 1 || W < 1 || (N != 32 && N != 64) ||
+        workspace_floats < conv7_thin_workspace_floats(B, H, W, N) || (long long)B * H * W * 64 >= (1ll << 31))
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv7_thin_wgrad: bad argument");
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
+    hipError_t e = conv7_thin_wgrad_launch(thin, wide, B, H, W, N, thin_is_input, grad_weight, workspace, reinterpret_cast<hipStream_t>(stream_));
+    if (e != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "eamm_op_conv7_thin_wgrad failed: %s", hipGetErrorString(e));
+    return EAMM_OK;
+}
+
 size_t eamm_op_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1) return 0;
     return conv_wgrad_workspace_floats(B, H, W, Cin, Cout, kh, kw);

@@ -233,4 +233,11 @@ hipError_t conv_pack_dev_launch(const float* w, int Cout, int Cin, int T, int BN
 hipError_t wino4_pack_dev_launch(const float* w, int Cout, int Cin, int BN, int transposed, float* dst, hipStream_t s);
 hipError_t bias_pad_dev_launch(const float* b, int Cout, int n, float* dst, hipStream_t s);
 
+// conv7_thin.hip: the 7x7 layers with three channels on one side (training path); thin tensors are [B,H,W,4] (4th channel 0)
+size_t conv7_thin_workspace_floats(int B, int H, int W, int N);
+hipError_t conv7_thin_in_launch(const float* thin, const float* w, const float* bias, int B, int H, int W, int N, int transposed,
+                                float* out, float* workspace, hipStream_t s);
+hipError_t conv7_thin_wgrad_launch(const float* thin, const float* wide, int B, int H, int W, int N, int thin_is_input, float* dw,
+                                   float* workspace, hipStream_t s);
+
 }  // namespace eamm

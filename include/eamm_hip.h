@@ -389,6 +389,22 @@ size_t eamm_op_conv_dev_workspace_floats(int B, int H, int W, int Cin, int Cout,
 int eamm_op_conv_dev(int device, const float* x, int B, int H, int W, int Cin, const float* weight, const float* bias, int Cout, int kh,
                      int kw, int transposed, float* out, float* workspace, size_t workspace_floats, void* stream);
 
+/* The generator's two 7x7 layers with THREE channels on one side (`first` 3 -> N, `final` N -> 3: reference
+ * modules/generator.py:26, 48), training path, without padding the thin side to 32 channels.  Thin tensors are NHWC with FOUR
+ * floats per pixel, [B,H,W,4], the fourth zero; N = 32 | 64; device pointers; `workspace` of eamm_op_conv7_thin_workspace_floats.
+ *   eamm_op_conv7_thin        transposed = 0: out [B,H,W,N] = conv7x7_same(thin, weight [N,3,7,7]) + bias   (forward of `first`)
+ *                             transposed = 1: out [B,H,W,N] = data gradient of y3 = conv7x7_same(x [.,N], weight [3,N,7,7]) from
+ *                                             thin = d y3                                                  (backward of `final`)
+ *   eamm_op_conv7_thin_wgrad  thin_is_input = 1: grad_weight [N,3,7,7] from thin = the layer's input, wide = d out [B,H,W,N]
+ *                             thin_is_input = 0: grad_weight [3,N,7,7] from thin = d y3, wide = the layer's input [B,H,W,N]
+ * (the forward of `final` is the evaluation path's column-patch kernel: eamm_op_conv tile 4002; bias gradients: eamm_op_conv_wgrad's
+ * or a plain sum). */
+size_t eamm_op_conv7_thin_workspace_floats(int B, int H, int W, int N);
+int eamm_op_conv7_thin(int device, const float* thin, const float* weight, const float* bias, int B, int H, int W, int N, int transposed,
+                       float* out, float* workspace, size_t workspace_floats, void* stream);
+int eamm_op_conv7_thin_wgrad(int device, const float* thin, const float* wide, int B, int H, int W, int N, int thin_is_input,
+                             float* grad_weight, float* workspace, size_t workspace_floats, void* stream);
+
 size_t eamm_op_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw);
 int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                        float* grad_weight, float* grad_bias, float* workspace, size_t workspace_floats, void* stream);

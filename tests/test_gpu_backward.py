@@ -239,3 +239,58 @@ def test_backward_entry_points_reject_bad_arguments():
     assert L.eamm_op_conv_wgrad(0, t.data_ptr(), t.data_ptr(), 1, 2, 2, 4, 4, 3, 3, t.data_ptr(), None, t.data_ptr(), 1, None) != 0   # workspace too small
     with pytest.raises(RuntimeError):
         autograd_ops.warp(torch.zeros(1, 8, 4, 4), torch.zeros(1, 4, 4, 2))   # CPU tensors: no fallback
+
+
+# ---- the 7x7 layers with three channels on one side (reference modules/generator.py:26, 48), csrc/conv7_thin.hip ------------
+def _thin4(t_nchw3):
+    """[B,3,H,W] -> NHWC with four floats per pixel (fourth zero), on the GPU."""
+    return F.pad(t_nchw3.permute(0, 2, 3, 1), (0, 1)).contiguous().to(DEV)
+
+
+@pytest.mark.parametrize("B,H,W,N", [(2, 16, 16, 64), (1, 21, 37, 32), (2, 64, 64, 64)])
+def test_thin_7x7_layers_match_autograd(B, H, W, N):
+    g = torch.Generator().manual_seed(31 + H)
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    nwork = L.eamm_op_conv7_thin_workspace_floats(B, H, W, N)
+    work = torch.empty(nwork, device=DEV)
+
+    def rel(got, want):
+        return float((got.detach().cpu().double() - want).abs().max()) / max(1.0, float(want.abs().max()))
+
+    # `first`: y = conv(x3, w [N,3,7,7]) + b: forward and weight gradient
+    x3 = torch.randn(B, 3, H, W, generator=g)
+    w1 = torch.randn(N, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5
+    b1 = 0.1 * torch.randn(N, generator=g)
+    gy = torch.randn(B, N, H, W, generator=g)
+    wr = w1.double().requires_grad_()
+    yr = F.conv2d(x3.double(), wr, b1.double(), padding=3)
+    yr.backward(gy.double())
+    x4 = _thin4(x3)
+    y = torch.full((B, H, W, N), float("nan"), device=DEV)
+    w1_d, b1_d = w1.to(DEV), b1.to(DEV)
+    _lib.check(L.eamm_op_conv7_thin(0, x4.data_ptr(), w1_d.data_ptr(), b1_d.data_ptr(), B, H, W, N, 0, y.data_ptr(),
+                                    work.data_ptr(), nwork, st), None)
+    dw = torch.full((N, 3, 7, 7), float("nan"), device=DEV)
+    gy_d = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    _lib.check(L.eamm_op_conv7_thin_wgrad(0, x4.data_ptr(), gy_d.data_ptr(), B, H, W, N, 1, dw.data_ptr(), work.data_ptr(), nwork, st), None)
+    torch.cuda.synchronize()
+    errs = {"first_fwd": rel(y.permute(0, 3, 1, 2), yr.detach()), "first_dw": rel(dw, wr.grad)}
+
+    # `final`: y3 = conv(x [.,N], w [3,N,7,7]): data gradient and weight gradient from d y3
+    x = torch.randn(B, N, H, W, generator=g)
+    w2 = torch.randn(3, N, 7, 7, generator=g) * (2.0 / (49 * N)) ** 0.5
+    g3 = torch.randn(B, 3, H, W, generator=g)
+    xr, wr2 = x.double().requires_grad_(), w2.double().requires_grad_()
+    F.conv2d(xr, wr2, None, padding=3).backward(g3.double())
+    g4 = _thin4(g3)
+    dx = torch.full((B, H, W, N), float("nan"), device=DEV)
+    w2_d = w2.to(DEV)
+    _lib.check(L.eamm_op_conv7_thin(0, g4.data_ptr(), w2_d.data_ptr(), None, B, H, W, N, 1, dx.data_ptr(), work.data_ptr(), nwork, st), None)
+    dw2 = torch.full((3, N, 7, 7), float("nan"), device=DEV)
+    x_d = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    _lib.check(L.eamm_op_conv7_thin_wgrad(0, g4.data_ptr(), x_d.data_ptr(), B, H, W, N, 0, dw2.data_ptr(), work.data_ptr(), nwork, st), None)
+    torch.cuda.synchronize()
+    errs.update({"final_dx": rel(dx.permute(0, 3, 1, 2), xr.grad), "final_dw": rel(dw2, wr2.grad)})
+    print(f"thin 7x7 {B}x{H}x{W}x{N}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert all(v <= 2e-5 for v in errs.values()), errs
