@@ -139,6 +139,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "eamm_op_conv7_thin_wgrad": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "eamm_op_final_conv_sigmoid": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p]),
     "eamm_op_conv_wgrad_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "eamm_op_conv_wgrad": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

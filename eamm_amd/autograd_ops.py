@@ -146,6 +146,111 @@ class _Conv2dSameFunction(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _FirstConv7Function(torch.autograd.Function):
+    """The generator's first layer (reference modules/generator.py:26: 7x7, 3 -> N): x4 NHWC [B,H,W,4] (three channels + a zero),
+    weight [N,3,7,7], bias [N] -> NHWC [B,H,W,N].  eamm_op_conv7_thin / _wgrad: the three channels are part of the GEMM's K
+    index instead of being padded to 32."""
+
+    @staticmethod
+    def forward(ctx, x4, weight, bias):
+        b, h, w, _ = x4.shape
+        n = weight.shape[0]
+        L = _lib.lib()
+        out = torch.empty(b, h, w, n, dtype=torch.float32, device=x4.device)
+        nwork = L.eamm_op_conv7_thin_workspace_floats(b, h, w, n)
+        work = torch.empty(nwork, dtype=torch.float32, device=x4.device)
+        wt, bt = weight.detach().contiguous(), bias.detach().contiguous()
+        with torch.cuda.device(x4.device):
+            _lib.check(L.eamm_op_conv7_thin(x4.device.index, _ptr(x4), _ptr(wt), _ptr(bt), b, h, w, n, 0, _ptr(out), _ptr(work), nwork,
+                                            _stream(x4.device)), None)
+        ctx.save_for_backward(x4, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x4, weight = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        b, h, w, _ = x4.shape
+        n = weight.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:   # the source image rarely needs a gradient: the general kernels on the padded filter
+            wp = torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, _CONV_BK - 3))              # [N,32,7,7]
+            gx = _Conv2dSameFunction._conv(grad_out, wp, None, transposed=True)[..., :4].contiguous()
+            gx[..., 3] = 0
+        if ctx.needs_input_grad[1]:
+            L = _lib.lib()
+            gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            nwork = L.eamm_op_conv7_thin_workspace_floats(b, h, w, n)
+            work = torch.empty(nwork, dtype=torch.float32, device=x4.device)
+            with torch.cuda.device(x4.device):
+                _lib.check(L.eamm_op_conv7_thin_wgrad(x4.device.index, _ptr(x4), _ptr(grad_out), b, h, w, n, 1, _ptr(gw), _ptr(work), nwork,
+                                                      _stream(x4.device)), None)
+        if ctx.needs_input_grad[2]:
+            gb = grad_out.sum(dim=(0, 1, 2))
+        return gx, gw, gb
+
+
+class _FinalConvSigmoidFunction(torch.autograd.Function):
+    """The generator's last layer (reference modules/generator.py:92-93): sigmoid(conv7x7(x NHWC [B,H,W,N], weight [3,N,7,7]) + bias)
+    -> NCHW [B,3,H,W].  Forward: the evaluation path's fused column-patch kernel on a device-packed filter
+    (eamm_op_final_conv_sigmoid); backward: eamm_op_conv7_thin (data gradient) and eamm_op_conv7_thin_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        b, h, w, n = x.shape
+        L = _lib.lib()
+        y = torch.empty(b, 3, h, w, dtype=torch.float32, device=x.device)
+        nwork = 7 * n * 32
+        work = torch.empty(nwork, dtype=torch.float32, device=x.device)
+        wt, bt = weight.detach().contiguous(), bias.detach().contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(L.eamm_op_final_conv_sigmoid(x.device.index, _ptr(x), _ptr(wt), _ptr(bt), b, h, w, n, _ptr(y), _ptr(work), nwork,
+                                                    _stream(x.device)), None)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, weight, y = ctx.saved_tensors
+        b, h, w, n = x.shape
+        g = grad_y * y * (1.0 - y)                                                          # through the sigmoid, NCHW [B,3,H,W]
+        g4 = torch.nn.functional.pad(g.permute(0, 2, 3, 1), (0, 1)).contiguous()             # NHWC, four floats per pixel
+        L = _lib.lib()
+        nwork = L.eamm_op_conv7_thin_workspace_floats(b, h, w, n)
+        work = torch.empty(nwork, dtype=torch.float32, device=x.device)
+        gx = gw = gb = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                wt = weight.detach().contiguous()
+                _lib.check(L.eamm_op_conv7_thin(x.device.index, _ptr(g4), _ptr(wt), None, b, h, w, n, 1, _ptr(gx), _ptr(work), nwork,
+                                                _stream(x.device)), None)
+            if ctx.needs_input_grad[1]:
+                gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+                work2 = torch.empty(nwork, dtype=torch.float32, device=x.device)
+                _lib.check(L.eamm_op_conv7_thin_wgrad(x.device.index, _ptr(g4), _ptr(x), b, h, w, n, 0, _ptr(gw), _ptr(work2), nwork,
+                                                      _stream(x.device)), None)
+        if ctx.needs_input_grad[2]:
+            gb = g.sum(dim=(0, 2, 3))
+        return gx, gw, gb
+
+
+def first_conv7(x4: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """7x7 "same" convolution of a three-channel image (NHWC [B,H,W,4], fourth channel zero) to N = 32 | 64 channels."""
+    _need_gpu(x4, "first_conv7")
+    if x4.shape[3] != 4 or tuple(weight.shape[1:]) != (3, 7, 7) or weight.shape[0] not in (32, 64) or bias is None:
+        raise ValueError(f"first_conv7: input {tuple(x4.shape)} / weight {tuple(weight.shape)} unsupported")
+    return _FirstConv7Function.apply(x4.contiguous(), weight, bias)
+
+
+def final_conv7_sigmoid(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """sigmoid(7x7 "same" convolution of NHWC [B,H,W,N], N = 32 | 64, to three channels + bias) -> NCHW [B,3,H,W]."""
+    _need_gpu(x, "final_conv7_sigmoid")
+    if tuple(weight.shape) != (3, x.shape[3], 7, 7) or x.shape[3] not in (32, 64) or bias is None:
+        raise ValueError(f"final_conv7_sigmoid: input {tuple(x.shape)} / weight {tuple(weight.shape)} unsupported")
+    return _FinalConvSigmoidFunction.apply(x.contiguous(), weight, bias)
+
+
 def conv2d_same_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``conv2d_same`` on the kernels' own layout: x NHWC [B,H,W,Cin] -> NHWC [B,H,W,Cout] (no layout copies)."""
     _need_gpu(x, "conv2d_same_nhwc")

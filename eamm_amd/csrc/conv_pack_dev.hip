@@ -64,6 +64,20 @@ __global__ __launch_bounds__(256) void wino4_pack_dev_kernel(const float* __rest
     }
 }
 
+// the final layer's column-patch filter (conv_col7.hip; eamm_op_conv tile 4002 packs the same on the host): the 7x7, Cout = 3
+// filter as a 7x1 filter with N = (dx, co) = 21 of 32 columns, w'[dx*3+co][c][dy] = w[co][c][dy][dx], LDS-DMA (swizzled) layout
+__global__ __launch_bounds__(256) void col7_pack_dev_kernel(const float* __restrict__ w, int C, float* __restrict__ dst) {
+    const int total = 7 * (C / CONV_BK) * 32 * CONV_BK;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int kl = idx % CONV_BK, nl = (idx / CONV_BK) % 32, ci = idx / (CONV_BK * 32);
+        const int cc = ci / 7, dy = ci % 7, c = cc * CONV_BK + kl;
+        float v = 0.f;
+        if (nl < 21) v = w[(((size_t)(nl % 3) * C + c) * 7 + dy) * 7 + nl / 3];
+        const int kk = ((((kl >> 2) ^ ((nl >> 1) & 7)) << 2) | (kl & 3));
+        dst[((size_t)ci * 32 + nl) * CONV_BK + kk] = v;
+    }
+}
+
 __global__ void bias_pad_dev_kernel(const float* __restrict__ b, int Cout, int n, float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (b != nullptr && i < Cout) ? b[i] : 0.f;
@@ -83,6 +97,12 @@ hipError_t wino4_pack_dev_launch(const float* w, int Cout, int Cin, int BN, int 
     const size_t total = (size_t)ntiles * BN * Cin;
     hipLaunchKernelGGL(wino4_pack_dev_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 16)), dim3(256), 0, s, w, Cout, Cin, BN,
                        ntiles, transposed, dst);
+    return hipGetLastError();
+}
+
+hipError_t col7_pack_dev_launch(const float* w, int C, float* dst, hipStream_t s) {
+    if (C % CONV_BK) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(col7_pack_dev_kernel, dim3((7 * C * 32 + 255) / 256), dim3(256), 0, s, w, C, dst);
     return hipGetLastError();
 }
 

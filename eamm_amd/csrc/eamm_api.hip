@@ -1607,6 +1607,20 @@ int eamm_op_conv7_thin_wgrad(int device, const float* thin, const float* wide, i
     return EAMM_OK;
 }
 
+int eamm_op_final_conv_sigmoid(int device, const float* x, const float* weight, const float* bias, int B, int H, int W, int C,
+                               float* out_nchw, float* workspace, size_t workspace_floats, void* stream_) {
+    if (!x || !weight || !bias || !out_nchw || !workspace || B < 1 || H < 1 || W < 1 || (C != 32 && C != 64) ||
+        workspace_floats < (size_t)7 * C * 32 || (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_final_conv_sigmoid: bad argument (C = 32 | 64, workspace of 7 * C * 32 floats)");
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    hipError_t e = col7_pack_dev_launch(weight, C, workspace, s);
+    if (e == hipSuccess) e = conv_col7_fused_launch(x, C, B, H, W, workspace, bias, out_nchw, s);
+    if (e != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "eamm_op_final_conv_sigmoid failed: %s", hipGetErrorString(e));
+    return EAMM_OK;
+}
+
 size_t eamm_op_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || kh < 1 || kw < 1) return 0;
     return conv_wgrad_workspace_floats(B, H, W, Cin, Cout, kh, kw);

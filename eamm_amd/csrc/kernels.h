@@ -232,6 +232,7 @@ hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int 
 hipError_t conv_pack_dev_launch(const float* w, int Cout, int Cin, int T, int BN, int transposed, float* dst, hipStream_t s);
 hipError_t wino4_pack_dev_launch(const float* w, int Cout, int Cin, int BN, int transposed, float* dst, hipStream_t s);
 hipError_t bias_pad_dev_launch(const float* b, int Cout, int n, float* dst, hipStream_t s);
+hipError_t col7_pack_dev_launch(const float* w_3c77, int C, float* dst /*[7*C/32][32][32]*/, hipStream_t s);
 
 // conv7_thin.hip: the 7x7 layers with three channels on one side (training path); thin tensors are [B,H,W,4] (4th channel 0)
 size_t conv7_thin_workspace_floats(int B, int H, int W, int N);

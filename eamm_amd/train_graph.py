@@ -6,7 +6,9 @@ The reference composes ``nn.Conv2d`` / ``SynchronizedBatchNorm2d`` / ``F.grid_sa
 them (modules/generator.py:59-97, dense_motion.py:32-113, util.py:858-1002).  Here the same composition is built from this
 package's operators, each a ``torch.autograd.Function`` whose forward AND backward are libeamm_hip.so kernels:
 
-* every convolution          ``autograd_ops.conv2d_same_nhwc``  (fp32-MFMA forward / data gradient / weight gradient)
+* every convolution          ``autograd_ops.conv2d_same_nhwc``  (fp32-MFMA forward / data gradient / weight gradient); the two 7x7
+                             layers with three channels on one side ``first_conv7`` / ``final_conv7_sigmoid`` (no padding of
+                             the three channels to 32)
 * every BatchNorm + ReLU     ``sync_batchnorm._BatchNormNHWCFunction``  (batch statistics, replicas' all-reduce, the block's ReLU
                              and DownBlock2d's 2x2 average fused; backward with the mask recomputed)
 * every bilinear warp        ``autograd_ops.warp_nhwc``     (feature warp x occlusion, the K+1 sparse warps, ``deformed``)
@@ -211,7 +213,11 @@ def forward_train(gen, source_image: torch.Tensor, kp_driving, kp_source) -> Dic
         raise RuntimeError("eamm_amd.OcclusionAwareGenerator runs only on a ROCm GPU (there is no CPU fallback for this path)")
     g = _Graph(gen)
     src_nhwc = source_image.permute(0, 2, 3, 1)
-    out = g.same_block(src_nhwc, gen.first)                                               # generator.py:61-63
+    fc = gen.first.conv                                                                    # generator.py:61-63
+    if fc.weight.shape[1] == 3 and fc.weight.shape[0] in (32, 64) and fc.bias is not None:
+        out = g.norm_relu(autograd_ops.first_conv7(F.pad(src_nhwc, (0, 1)), fc.weight, fc.bias), gen.first.norm)
+    else:
+        out = g.same_block(src_nhwc, gen.first)
     for blk in gen.down_blocks:
         out = g.down_block(out, blk)
     result = {}
@@ -227,5 +233,9 @@ def forward_train(gen, source_image: torch.Tensor, kp_driving, kp_source) -> Dic
         out = g.res_block(out, blk)
     for blk in gen.up_blocks:
         out = g.up_block(out, blk)
-    result["prediction"] = torch.sigmoid(conv(out, gen.final)).permute(0, 3, 1, 2).contiguous()
+    fin = gen.final
+    if fin.weight.shape[0] == 3 and out.shape[3] in (32, 64) and fin.bias is not None:
+        result["prediction"] = autograd_ops.final_conv7_sigmoid(out, fin.weight, fin.bias)
+    else:
+        result["prediction"] = torch.sigmoid(conv(out, fin)).permute(0, 3, 1, 2).contiguous()
     return result

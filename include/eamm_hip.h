@@ -405,6 +405,12 @@ int eamm_op_conv7_thin(int device, const float* thin, const float* weight, const
 int eamm_op_conv7_thin_wgrad(int device, const float* thin, const float* wide, int B, int H, int W, int N, int thin_is_input,
                              float* grad_weight, float* workspace, size_t workspace_floats, void* stream);
 
+/* The generator's last layer whole with DEVICE parameters (training path): out NCHW [B,3,H,W] = sigmoid(conv7x7_same(x [B,H,W,C],
+ * weight [3,C,7,7]) + bias [3]) -- reference modules/generator.py:92-93 -- on the evaluation path's fused column-patch kernel;
+ * the filter is packed on the device into `workspace` (7 * C * 32 floats, 16-byte aligned).  C = 32 | 64. */
+int eamm_op_final_conv_sigmoid(int device, const float* x, const float* weight, const float* bias, int B, int H, int W, int C,
+                               float* out_nchw, float* workspace, size_t workspace_floats, void* stream);
+
 size_t eamm_op_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw);
 int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                        float* grad_weight, float* grad_bias, float* workspace, size_t workspace_floats, void* stream);

@@ -292,5 +292,14 @@ def test_thin_7x7_layers_match_autograd(B, H, W, N):
     _lib.check(L.eamm_op_conv7_thin_wgrad(0, g4.data_ptr(), x_d.data_ptr(), B, H, W, N, 0, dw2.data_ptr(), work.data_ptr(), nwork, st), None)
     torch.cuda.synchronize()
     errs.update({"final_dx": rel(dx.permute(0, 3, 1, 2), xr.grad), "final_dw": rel(dw2, wr2.grad)})
+    # `final` forward with device parameters: sigmoid(conv + bias) -> NCHW, on the fused column-patch kernel
+    b2 = 0.1 * torch.randn(3, generator=g)
+    b2_d = b2.to(DEV)
+    y3 = torch.full((B, 3, H, W), float("nan"), device=DEV)
+    pw = torch.empty(7 * N * 32, device=DEV)
+    _lib.check(L.eamm_op_final_conv_sigmoid(0, x_d.data_ptr(), w2_d.data_ptr(), b2_d.data_ptr(), B, H, W, N, y3.data_ptr(), pw.data_ptr(),
+                                            pw.numel(), st), None)
+    torch.cuda.synchronize()
+    errs["final_fwd"] = rel(y3, torch.sigmoid(F.conv2d(x.double(), w2.double(), b2.double(), padding=3)))
     print(f"thin 7x7 {B}x{H}x{W}x{N}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     assert all(v <= 2e-5 for v in errs.values()), errs
