@@ -192,19 +192,6 @@ __global__ void conv7_thin_wgrad_reduce_kernel(const float* __restrict__ partial
 
 namespace {
 int thin7_blocks(int nstrips) { return std::min(nstrips, 1024); }
-template <typename K>
-hipError_t set_lds(K kern, size_t lds, lds_once_mask& configured) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(configured.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured.fetch_or(bit, std::memory_order_release);
-    }
-    return hipSuccess;
-}
 }  // namespace
 
 size_t conv7_thin_workspace_floats(int B, int H, int W, int N) {
@@ -232,11 +219,11 @@ hipError_t conv7_thin_in_launch(const float* thin, const float* w, const float* 
     hipError_t e;
     if (N == 64) {
         static lds_once_mask configured{0};
-        if ((e = set_lds(conv7_thin_in_kernel<2>, lds, configured)) != hipSuccess) return e;
+        if ((e = ensure_dynamic_lds(conv7_thin_in_kernel<2>, lds, &configured)) != hipSuccess) return e;
         hipLaunchKernelGGL(conv7_thin_in_kernel<2>, dim3(blocks), dim3(256), lds, s, a);
     } else {
         static lds_once_mask configured{0};
-        if ((e = set_lds(conv7_thin_in_kernel<1>, lds, configured)) != hipSuccess) return e;
+        if ((e = ensure_dynamic_lds(conv7_thin_in_kernel<1>, lds, &configured)) != hipSuccess) return e;
         hipLaunchKernelGGL(conv7_thin_in_kernel<1>, dim3(blocks), dim3(256), lds, s, a);
     }
     return hipGetLastError();
