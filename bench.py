@@ -25,7 +25,9 @@ Prints ONE JSON line with the contract keys plus
   clip         -- BASELINE.json configs[3]: a `--clip-frames` (2048) frame clip through eamm_amd.animate_clip,
                   frames sharded contiguously over the ranks, timed from the un-encoded source on rank 0 to the
                   last frame on every rank: encode + RCCL broadcast of the source cache and key points + compute
-                  (+ gather of uint8 frames to rank 0 with --clip-gather); frames/s = frames / max-over-ranks time.
+                  (+ gather of uint8 frames to rank 0 with --clip-gather); frames/s = frames / max-over-ranks time;
+  train_step   -- SURVEY.md 8f row N4, N = 1 only, never part of `value`: one fine-tuning step (`--train-pairs` = 8 pairs;
+                  .train() forward with an autograd graph + loss.backward() on the HIP operators of eamm_amd/train_graph.py).
 """
 from __future__ import annotations
 
@@ -119,6 +121,44 @@ def cpu_baseline(cfg, sd, size, frames, passes=5):
                       f"{ncpu} logical CPUs, {dt:.1f} s"}
 
 
+def train_step_leg(cfg, sd, size, pairs, steps=4):
+    """SURVEY.md 8f row N4 (not part of `value`): one fine-tuning step of the generator -- .train() forward with an autograd
+    graph (eamm_amd/train_graph.py: HIP convolution / BatchNorm / warp operators) + loss.backward() -- `pairs` (source, driving)
+    pairs per step, wall clock with the stream drained, best of `steps` after one warm-up step."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gen = OcclusionAwareGenerator(**cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(dev).train()
+    gen.requires_grad_(True)
+    src = synthetic_source(size, seed=1, batch=pairs).to(dev)
+    kp_s = {k: v.to(dev) for k, v in synthetic_keypoints(pairs, cfg["num_kp"], seed=0).items()}
+    kp_d = {k: v.to(dev).requires_grad_() for k, v in synthetic_keypoints(pairs, cfg["num_kp"], seed=2).items()}
+    target = torch.rand(pairs, 3, size, size, device=dev)
+    fwd, bwd = [], []
+    for it in range(steps + 1):
+        for p in gen.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = (gen(src, kp_driving=kp_d, kp_source=kp_s)["prediction"] - target).abs().mean()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        loss.backward()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if it:
+            fwd.append((t1 - t0) * 1e3)
+            bwd.append((t2 - t1) * 1e3)
+    best = min(f + b for f, b in zip(fwd, bwd))
+    finite = all(bool(torch.isfinite(p.grad).all()) for p in gen.parameters())
+    del gen
+    torch.cuda.empty_cache()
+    return {"pairs": pairs, "size": size, "step_ms": round(best, 3), "forward_ms": round(min(fwd), 3), "backward_ms": round(min(bwd), 3),
+            "pairs_per_s": round(pairs / best * 1e3, 1), "gradients_finite": finite,
+            "note": "generator .train() forward with autograd graph + loss.backward() (L1 to a random target), HIP operators of "
+                    "eamm_amd/train_graph.py; batch-statistics BatchNorm; not part of `value`"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +169,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--clip-frames", type=int, default=2048, help="frames of the configs[3] clip leg (0 = skip)")
     ap.add_argument("--clip-gather", action="store_true", help="clip leg: gather uint8 frames on rank 0 inside the timed region")
+    ap.add_argument("--train-pairs", type=int, default=8, help="pairs per step of the training-step leg (N = 1 only; 0 = skip)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 16 if args.size <= 256 else 8
@@ -425,6 +466,11 @@ def main():
             line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)
         else:
             line["cpu_baseline"] = None
+        if world == 1 and args.train_pairs > 0:
+            try:
+                line["train_step"] = train_step_leg(cfg, sd, S, args.train_pairs if S <= 256 else max(1, args.train_pairs // 4))
+            except Exception as exc:   # never at the expense of the contract line
+                line["train_step"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

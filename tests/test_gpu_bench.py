@@ -68,6 +68,11 @@ def test_bench_single_gpu_line():
     assert k["frames"] == 2048 and k["n_gpus"] == 1 and abs(k["frames_per_s"] - 2048 / k["seconds"]) < 1.0
     assert 0.9 * d["value"] <= k["frames_per_s"] <= 1.05 * d["value"], (k["frames_per_s"], d["value"])
     assert {"encode_ms", "compute_ms"} <= set(k["phases_ms_rank0"])
+    # N4 leg (not part of `value`): one fine-tuning step of 8 pairs, forward with autograd graph + loss.backward()
+    t = d["train_step"]
+    assert "error" not in t, t
+    assert t["pairs"] == 8 and t["gradients_finite"] is True and t["step_ms"] > 0
+    assert abs(t["pairs_per_s"] - 8 / t["step_ms"] * 1e3) / t["pairs_per_s"] < 0.01 and t["step_ms"] <= t["forward_ms"] + t["backward_ms"] + 5
 
 
 def test_bench_512_batch8_line():
