@@ -44,3 +44,33 @@ def test_nhwc_helpers():
     assert train_graph._pad_last(x, 5) is x
     g = train_graph._grid(4, 6, x)
     assert g.shape == (4, 6, 2) and float(g[0, 0, 0]) == -1.0 and float(g[-1, -1, 1]) == 1.0 and float(g[0, -1, 0]) == 1.0
+
+
+def test_differentiable_operators_have_no_cpu_fallback_and_validate_shapes():
+    """The op-level wrappers (eamm_amd/autograd_ops.py) refuse CPU tensors (the product path never falls back) and reject
+    shapes the kernels do not cover before touching the library."""
+    from eamm_amd import autograd_ops as ops
+    x = torch.zeros(1, 8, 8, 32)
+    w3 = torch.zeros(32, 32, 3, 3)
+    for call in (lambda: ops.conv2d_same_nhwc(x, w3), lambda: ops.conv2d_same(x.permute(0, 3, 1, 2), w3),
+                 lambda: ops.warp_nhwc(x, torch.zeros(1, 8, 8, 2)), lambda: ops.warp(x.permute(0, 3, 1, 2), torch.zeros(1, 8, 8, 2)),
+                 lambda: ops.first_conv7(torch.zeros(1, 8, 8, 4), torch.zeros(32, 3, 7, 7), torch.zeros(32)),
+                 lambda: ops.final_conv7_sigmoid(x, torch.zeros(3, 32, 7, 7), torch.zeros(3))):
+        with pytest.raises(RuntimeError, match="ROCm GPU"):
+            call()
+
+
+def test_generator_picks_the_graph_path_only_when_something_needs_a_gradient():
+    from eamm_amd import OcclusionAwareGenerator, tiny_config
+    gen = OcclusionAwareGenerator(**tiny_config()).train()
+    src = torch.zeros(2, 3, 64, 64)
+    kp = {"value": torch.zeros(2, 10, 2), "jacobian": torch.eye(2).expand(2, 10, 2, 2).clone()}
+    assert not gen._wants_graph(src, kp, kp)                         # inference-style module: parameters frozen by default
+    kpg = {k: v.clone().requires_grad_() for k, v in kp.items()}
+    assert gen._wants_graph(src, kpg, kp)                            # the audio-to-key-point stage trains through the generator
+    with torch.no_grad():
+        assert not gen._wants_graph(src, kpg, kp)
+    gen.requires_grad_(True)
+    assert gen._wants_graph(src, kp, kp)                             # fine-tuning opts in
+    with pytest.raises(RuntimeError, match="ROCm GPU"):             # ... and still has no CPU fallback
+        gen(src, kp_driving=kp, kp_source=kp)
