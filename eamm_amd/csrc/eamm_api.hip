@@ -1488,6 +1488,8 @@ int eamm_op_warp_backward(int device, const float* feat, const float* deformatio
 namespace {
 struct ConvDevPlan {
     bool wino4 = false;
+    int groups = 1;         // F(4x4): rows of transform points split over this many workgroups per tile (few tiles), as the engine does
+    size_t zbuf = 0;        // floats of the split form's x-folded products
     int BN = 0, ntiles = 0;
     size_t packed = 0, bias = 0, aux = 0;   // floats: packed filter, padded bias, Winograd V or split-K partials
     ConvLayer L;
@@ -1506,6 +1508,15 @@ bool conv_dev_plan(int B, int H, int W, int Cin, int Cout, int kh, int kw, ConvD
         P->ntiles = (Cout + 63) / 64;
         P->packed = wino4_packed_elems(Cout, Cin, 64);
         P->aux = (size_t)36 * Mq * Cin;
+        // a single launch of <= 128 64-tile workgroups leaves half the chip idle (the engine runs two chains there): split
+        // the transform-point rows over 2 / 3 / 6 workgroups per tile, as the engine's one-chain calls do
+        const long long nb = ((Mq + 63) / 64) * P->ntiles;
+        for (int gsel : {6, 3, 2})
+            if (nb * gsel <= 256) {
+                P->groups = gsel;
+                break;
+            }
+        if (P->groups > 1) P->zbuf = (size_t)24 * Mq * Cout;
     } else {
         ConvLayer& L = P->L;
         L.kh = kh;
@@ -1525,13 +1536,14 @@ bool conv_dev_plan(int B, int H, int W, int Cin, int Cout, int kh, int kw, ConvD
     P->packed = up(P->packed);
     P->bias = up(P->bias);
     P->aux = up(P->aux);
+    P->zbuf = up(P->zbuf);
     return true;
 }
 }  // namespace
 
 size_t eamm_op_conv_dev_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
     ConvDevPlan P;
-    return conv_dev_plan(B, H, W, Cin, Cout, kh, kw, &P) ? P.packed + P.bias + P.aux : 0;
+    return conv_dev_plan(B, H, W, Cin, Cout, kh, kw, &P) ? P.packed + P.bias + P.aux + P.zbuf : 0;
 }
 
 int eamm_op_conv_dev(int device, const float* x, int B, int H, int W, int Cin, const float* weight, const float* bias, int Cout, int kh,
@@ -1539,8 +1551,8 @@ int eamm_op_conv_dev(int device, const float* x, int B, int H, int W, int Cin, c
     ConvDevPlan P;
     if (!x || !weight || !out || !workspace || !conv_dev_plan(B, H, W, Cin, Cout, kh, kw, &P))
         return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv_dev: bad argument (3x3 or 7x7, Cin a multiple of 32, Cout of 4)");
-    if (workspace_floats < P.packed + P.bias + P.aux || (reinterpret_cast<uintptr_t>(workspace) & 15))
-        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv_dev: workspace too small or misaligned (%zu floats needed)", P.packed + P.bias + P.aux);
+    if (workspace_floats < P.packed + P.bias + P.aux + P.zbuf || (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv_dev: workspace too small or misaligned (%zu floats needed)", P.packed + P.bias + P.aux + P.zbuf);
     DeviceGuard guard(device);
     if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
@@ -1557,7 +1569,9 @@ int eamm_op_conv_dev(int device, const float* x, int B, int H, int W, int Cin, c
         WL.bias = bp;
         e = wino4_pack_dev_launch(weight, Cout, Cin, 64, transposed, wp, s);
         if (e == hipSuccess) e = wino4_transform_launch(x, nullptr, nullptr, B, H, W, Cin, aux, s);
-        if (e == hipSuccess) e = wino4_gemm_launch(WL, aux, B, H, W, ACT_NONE, nullptr, out, s, 3, 1, nullptr, 0);
+        if (e == hipSuccess)
+            e = wino4_gemm_launch(WL, aux, B, H, W, ACT_NONE, nullptr, out, s, P.groups > 1 ? 0 : 3, P.groups,
+                                  P.groups > 1 ? aux + P.aux : nullptr, 0);
     } else if (e == hipSuccess) {
         ConvLayer& L = P.L;
         L.w = wp;
