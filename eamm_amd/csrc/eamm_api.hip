@@ -1500,7 +1500,8 @@ bool conv_dev_plan(int B, int H, int W, int Cin, int Cout, int kh, int kw, ConvD
     const long long Mq = (long long)B * (H / 4) * (W / 4);
     // F(4x4,3x3) where the bottleneck's kernel applies and the tile count fills the chip; else the register-staged implicit GEMM
     static const int wino_off = [] { const char* e = getenv("EAMM_CONV_DEV_WINO4"); return e ? atoi(e) == 0 : 0; }();
-    P->wino4 = !wino_off && kh == 3 && kw == 3 && Cin % (2 * CONV_BK) == 0 && !(H & 3) && !(W & 3) && Mq >= 2048 &&
+    static const long long wino_min_tiles = [] { const char* e = getenv("EAMM_CONV_DEV_WINO4_MIN_TILES"); return e ? atoll(e) : 2048ll; }();
+    P->wino4 = !wino_off && kh == 3 && kw == 3 && Cin % (2 * CONV_BK) == 0 && !(H & 3) && !(W & 3) && Mq >= wino_min_tiles &&
                (unsigned long long)36 * Mq * Cin * sizeof(float) < 0xFFFFF000ull &&
                wino4_packed_elems(Cout, Cin, 64) * sizeof(float) < 0xFFFFF000ull;
     if (P->wino4) {
