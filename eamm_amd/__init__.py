@@ -11,7 +11,8 @@ from .keypoints import apply_emotion_offsets, normalize_kp, one_euro_smooth, smo
 from .keypoint_detector import KPDetector, KPDetector_a  # noqa: F401
 from .deconv_tail import DeconvTail  # noqa: F401
 from .sync_batchnorm import SynchronizedBatchNorm2d  # noqa: F401
+from .data_parallel import all_reduce_gradients  # noqa: F401
 from .config import kp_detector_config, kp_detector_a_config, tiny_kp_config  # noqa: F401
 
 __all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "driving_keypoints", "shard_bounds", "normalize_kp", "apply_emotion_offsets", "smooth_keypoints", "one_euro_smooth", "KPDetector", "KPDetector_a", "DeconvTail", "SynchronizedBatchNorm2d",
-           "hot_path_config", "tiny_config"]
+           "all_reduce_gradients", "hot_path_config", "tiny_config"]

@@ -224,6 +224,12 @@ def _ddp_worker(rank, world, port, tmp):
     blob = {"param/" + k: p.grad.cpu().numpy() for k, p in gen.named_parameters()}
     blob.update({"kp_source/" + k: v.grad.cpu().numpy() for k, v in ks.items()})
     blob.update({"kp_driving/" + k: v.grad.cpu().numpy() for k, v in kd.items()})
+    # ... and eamm_amd.all_reduce_gradients leaves the SUM of the replicas' parameter gradients on every rank (the reference's
+    # ReduceAddCoalesced on the DataParallel master), in flat buckets
+    from eamm_amd import all_reduce_gradients
+    assert all_reduce_gradients(gen.parameters(), bucket_mb=1.0) >= 2
+    torch.cuda.synchronize()
+    blob.update({"sum/" + k: p.grad.cpu().numpy() for k, p in gen.named_parameters()})
     np.savez(os.path.join(tmp, f"grad{rank}.npz"), **blob)
     dist.barrier()
     dist.destroy_process_group()
@@ -255,6 +261,11 @@ def test_two_replicas_gradients_add_up_to_the_whole_batch(tmp_path):
         else:
             got[k] = torch.cat([torch.from_numpy(r[0][k]), torch.from_numpy(r[1][k])])
     _close(got, want, "two replicas")
+    for k in want:                                                    # the bucketed all-reduce: exactly the sum, on both ranks
+        if k.startswith("param/"):
+            name = "sum/" + k[len("param/"):]
+            for i in (0, 1):
+                assert np.abs(r[i][name] - got[k].numpy()).max() <= 1e-6 * max(1.0, float(np.abs(got[k].numpy()).max())), (i, k)
 
 
 @pytest.mark.gpu
