@@ -119,9 +119,10 @@ class _Conv2dSameFunction(torch.autograd.Function):
         return out
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, bias_grad_is_zero=False):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_grad_is_zero = bool(bias_grad_is_zero)
         return _Conv2dSameFunction._conv(x, weight, bias)
 
     @staticmethod
@@ -137,13 +138,18 @@ class _Conv2dSameFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             L = _lib.lib()
             gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-            gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            # a bias that feeds a batch-statistics BatchNorm directly has a gradient of exactly zero (the mean is subtracted
+            # again): the caller says so and the sum over the pixels is not computed (autograd's own value there is rounding noise)
+            zero_gb = ctx.has_bias and ctx.bias_grad_is_zero
+            gb = torch.empty(cout, dtype=torch.float32, device=x.device) if (ctx.has_bias and not zero_gb) else None
             nwork = L.eamm_op_conv_wgrad_workspace_floats(b, h, w, cin, cout, kh, kw)
             work = torch.empty(max(1, nwork), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
                 _lib.check(L.eamm_op_conv_wgrad(x.device.index, _ptr(x), _ptr(grad_out), b, h, w, cin, cout, kh, kw, _ptr(gw), _ptr(gb),
                                                 _ptr(work), nwork, _stream(x.device)), None)
-        return gx, gw, gb
+            if zero_gb:
+                gb = torch.zeros(cout, dtype=torch.float32, device=x.device)
+        return gx, gw, gb, None
 
 
 class _FirstConv7Function(torch.autograd.Function):
@@ -152,7 +158,8 @@ class _FirstConv7Function(torch.autograd.Function):
     index instead of being padded to 32."""
 
     @staticmethod
-    def forward(ctx, x4, weight, bias):
+    def forward(ctx, x4, weight, bias, bias_grad_is_zero=False):
+        ctx.bias_grad_is_zero = bool(bias_grad_is_zero)
         b, h, w, _ = x4.shape
         n = weight.shape[0]
         L = _lib.lib()
@@ -186,8 +193,8 @@ class _FirstConv7Function(torch.autograd.Function):
                 _lib.check(L.eamm_op_conv7_thin_wgrad(x4.device.index, _ptr(x4), _ptr(grad_out), b, h, w, n, 1, _ptr(gw), _ptr(work), nwork,
                                                       _stream(x4.device)), None)
         if ctx.needs_input_grad[2]:
-            gb = grad_out.sum(dim=(0, 1, 2))
-        return gx, gw, gb
+            gb = torch.zeros_like(weight[:, 0, 0, 0]) if ctx.bias_grad_is_zero else grad_out.sum(dim=(0, 1, 2))
+        return gx, gw, gb, None
 
 
 class _FinalConvSigmoidFunction(torch.autograd.Function):
@@ -235,12 +242,12 @@ class _FinalConvSigmoidFunction(torch.autograd.Function):
         return gx, gw, gb
 
 
-def first_conv7(x4: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+def first_conv7(x4: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, bias_grad_is_zero: bool = False) -> torch.Tensor:
     """7x7 "same" convolution of a three-channel image (NHWC [B,H,W,4], fourth channel zero) to N = 32 | 64 channels."""
     _need_gpu(x4, "first_conv7")
     if x4.shape[3] != 4 or tuple(weight.shape[1:]) != (3, 7, 7) or weight.shape[0] not in (32, 64) or bias is None:
         raise ValueError(f"first_conv7: input {tuple(x4.shape)} / weight {tuple(weight.shape)} unsupported")
-    return _FirstConv7Function.apply(x4.contiguous(), weight, bias)
+    return _FirstConv7Function.apply(x4.contiguous(), weight, bias, bias_grad_is_zero)
 
 
 def final_conv7_sigmoid(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
@@ -251,8 +258,11 @@ def final_conv7_sigmoid(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tenso
     return _FinalConvSigmoidFunction.apply(x.contiguous(), weight, bias)
 
 
-def conv2d_same_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``conv2d_same`` on the kernels' own layout: x NHWC [B,H,W,Cin] -> NHWC [B,H,W,Cout] (no layout copies)."""
+def conv2d_same_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                     bias_grad_is_zero: bool = False) -> torch.Tensor:
+    """``conv2d_same`` on the kernels' own layout: x NHWC [B,H,W,Cin] -> NHWC [B,H,W,Cout] (no layout copies).
+    ``bias_grad_is_zero``: the output feeds a batch-statistics BatchNorm directly, so the bias gradient is exactly zero and is
+    returned as zeros without being computed."""
     _need_gpu(x, "conv2d_same_nhwc")
     cout, cin, kh, kw = weight.shape
     if (kh, kw) not in ((3, 3), (7, 7)) or x.shape[3] != cin or cin % _CONV_BK or cout % _CONV_BK:
@@ -260,7 +270,7 @@ def conv2d_same_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
                          f"(3x3 or 7x7, channels multiples of {_CONV_BK})")
     if weight.device != x.device or (bias is not None and bias.device != x.device):
         raise RuntimeError("conv2d_same_nhwc: parameters and input are on different devices")
-    return _Conv2dSameFunction.apply(x.contiguous(), weight, bias)
+    return _Conv2dSameFunction.apply(x.contiguous(), weight, bias, bias_grad_is_zero)
 
 
 def warp_nhwc(features: torch.Tensor, deformation: torch.Tensor, occlusion: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -285,5 +295,5 @@ def conv2d_same(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
                          f"(3x3 or 7x7, channels multiples of {_CONV_BK})")
     if weight.device != x.device or (bias is not None and bias.device != x.device):
         raise RuntimeError("conv2d_same: parameters and input are on different devices")
-    out = _Conv2dSameFunction.apply(x.permute(0, 2, 3, 1).contiguous(), weight, bias)
+    out = _Conv2dSameFunction.apply(x.permute(0, 2, 3, 1).contiguous(), weight, bias, False)
     return out.permute(0, 3, 1, 2)

@@ -43,7 +43,7 @@ def _pad_last(x: torch.Tensor, mult: int) -> torch.Tensor:
     return x if c % mult == 0 else F.pad(x, (0, _round_up(c, mult) - c))
 
 
-def conv(x: torch.Tensor, mod: torch.nn.Conv2d) -> torch.Tensor:
+def conv(x: torch.Tensor, mod: torch.nn.Conv2d, feeds_norm: bool = False) -> torch.Tensor:
     """``mod(x)`` for the path's stride-1 "same" 3x3 / 7x7 convolutions on NHWC [B,H,W,Cin] -> NHWC [B,H,W,Cout]; channels
     zero-padded to the kernels' granule (the padded filter rows / columns are zeros and the slice drops their gradient)."""
     w, b = mod.weight, mod.bias
@@ -55,7 +55,8 @@ def conv(x: torch.Tensor, mod: torch.nn.Conv2d) -> torch.Tensor:
     if cout_p != cout:
         w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_p - cout))
         b = F.pad(b, (0, cout_p - cout)) if b is not None else None
-    y = autograd_ops.conv2d_same_nhwc(x, w, b)
+    # feeds_norm: the output goes straight into a batch-statistics BatchNorm -- the bias gradient is exactly zero
+    y = autograd_ops.conv2d_same_nhwc(x, w, b, bias_grad_is_zero=feeds_norm)
     return y[..., :cout] if cout_p != cout else y
 
 
@@ -107,16 +108,16 @@ class _Graph:
 
     # ---- blocks: modules/util.py:858-938 --------------------------------------------------------------------------------
     def same_block(self, x, blk):
-        return self.norm_relu(conv(x, blk.conv), blk.norm)
+        return self.norm_relu(conv(x, blk.conv, feeds_norm=True), blk.norm)
 
     def down_block(self, x, blk):
-        return self.norm_relu(conv(x, blk.conv), blk.norm, pool=True)
+        return self.norm_relu(conv(x, blk.conv, feeds_norm=True), blk.norm, pool=True)
 
     def up_block(self, x, blk):
         return self.same_block(_upsample2(x), blk)
 
     def res_block(self, x, blk):
-        y = conv(self.norm_relu(x, blk.norm1), blk.conv1)
+        y = conv(self.norm_relu(x, blk.norm1), blk.conv1, feeds_norm=True)      # conv1 -> norm2
         y = conv(self.norm_relu(y, blk.norm2), blk.conv2)
         return y + x
 
@@ -215,7 +216,7 @@ def forward_train(gen, source_image: torch.Tensor, kp_driving, kp_source) -> Dic
     src_nhwc = source_image.permute(0, 2, 3, 1)
     fc = gen.first.conv                                                                    # generator.py:61-63
     if fc.weight.shape[1] == 3 and fc.weight.shape[0] in (32, 64) and fc.bias is not None:
-        out = g.norm_relu(autograd_ops.first_conv7(F.pad(src_nhwc, (0, 1)), fc.weight, fc.bias), gen.first.norm)
+        out = g.norm_relu(autograd_ops.first_conv7(F.pad(src_nhwc, (0, 1)), fc.weight, fc.bias, bias_grad_is_zero=True), gen.first.norm)
     else:
         out = g.same_block(src_nhwc, gen.first)
     for blk in gen.down_blocks:
