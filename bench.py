@@ -121,6 +121,11 @@ def cpu_baseline(cfg, sd, size, frames, passes=5):
                       f"{ncpu} logical CPUs, {dt:.1f} s"}
 
 
+def train_step_target(pairs, size):
+    """The training-step leg's L1 target: seeded, so that the printed loss / gradient checksums can be re-derived."""
+    return torch.rand(pairs, 3, size, size, generator=torch.Generator().manual_seed(11))
+
+
 def train_step_leg(cfg, sd, size, pairs, steps=4):
     """SURVEY.md 8f row N4 (not part of `value`): one fine-tuning step of the generator -- .train() forward with an autograd
     graph (eamm_amd/train_graph.py: HIP convolution / BatchNorm / warp operators) + loss.backward() -- `pairs` (source, driving)
@@ -128,12 +133,11 @@ def train_step_leg(cfg, sd, size, pairs, steps=4):
     dev = torch.device("cuda", torch.cuda.current_device())
     gen = OcclusionAwareGenerator(**cfg)
     gen.load_state_dict(sd, strict=True)
-    gen = gen.to(dev).train()
-    gen.requires_grad_(True)
+    gen = gen.to(dev).train()       # parameters require grad by default, as the reference module's (train.py:136)
     src = synthetic_source(size, seed=1, batch=pairs).to(dev)
     kp_s = {k: v.to(dev) for k, v in synthetic_keypoints(pairs, cfg["num_kp"], seed=0).items()}
     kp_d = {k: v.to(dev).requires_grad_() for k, v in synthetic_keypoints(pairs, cfg["num_kp"], seed=2).items()}
-    target = torch.rand(pairs, 3, size, size, device=dev)
+    target = train_step_target(pairs, size).to(dev)
     fwd, bwd = [], []
     for it in range(steps + 1):
         for p in gen.parameters():
@@ -151,10 +155,16 @@ def train_step_leg(cfg, sd, size, pairs, steps=4):
             bwd.append((t2 - t1) * 1e3)
     best = min(f + b for f, b in zip(fwd, bwd))
     finite = all(bool(torch.isfinite(p.grad).all()) for p in gen.parameters())
+    # deterministic inputs (seeds above): the loss and three gradient checksums of the last step, checked against the oracle's
+    # autograd in double by tests/test_gpu_bench.py -- `gradients_finite` alone would pass a wrong kernel
+    checks = {"loss": float(loss.detach()),
+              "grad_l1/kp_driving.value": float(kp_d["value"].grad.abs().sum()),
+              "grad_l1/final.weight": float(gen.final.weight.grad.abs().sum()),
+              "grad_l1/bottleneck.r0.conv1.weight": float(gen.bottleneck.r0.conv1.weight.grad.abs().sum())}
     del gen
     torch.cuda.empty_cache()
     return {"pairs": pairs, "size": size, "step_ms": round(best, 3), "forward_ms": round(min(fwd), 3), "backward_ms": round(min(bwd), 3),
-            "pairs_per_s": round(pairs / best * 1e3, 1), "gradients_finite": finite,
+            "pairs_per_s": round(pairs / best * 1e3, 1), "gradients_finite": finite, "checks": checks,
             "note": "generator .train() forward with autograd graph + loss.backward() (L1 to a random target), HIP operators of "
                     "eamm_amd/train_graph.py; batch-statistics BatchNorm; not part of `value`"}
 
@@ -395,12 +405,27 @@ def main():
         stage_tflops = bneck_exec_gf_step / union_ms if union_ms > 0 else float("nan")
         algo = algo_flop_step / 1e9 / union_ms if union_ms > 0 else float("nan")
         ms_step = dt / args.steps * 1e3
-        total_ms = sum(pm.values())
         traffic, traffic_src = measured_traffic(form, S, B, chains)
         which = "configs[2]" if (S, B) == (256, 16) else ("configs[4]" if (S, B) == (512, 8) else "a non-BASELINE size")
         warp_bytes_frame = (2 * hf * hf * cb + 3 * (S // 4) * (S // 4)) * 4.0    # 8.438 MB at 256^2
         warp_frames = B // pchains                                              # frames of ONE in-pipeline launch
         warp_ms = pm["warp"] / calls
+
+        # per-stage fraction of the chip's fp32 matrix peak: executed matrix-core GFLOP of the stage (ALL chains, library-side
+        # count of what the grids issue) / the main stream's time in the stage -- the other chain runs the same stage beside it
+        # and takes the same time within a few per cent (compare bneck_union with bneck_windows / chains)
+        stage_gf = {k[3:]: pm.pop(k) / calls for k in list(pm) if k.startswith("gf_")}
+        stage_time = {"front": pm["front"], "hg_enc": pm["hg_enc"], "hg_dec": pm["hg_dec"], "head": pm["head"], "warp": pm["warp"],
+                      "bneck": pm["bneck_transform"] + pm["bneck_conv"], "up": pm["up"], "final": pm["final"]}
+        stage_roofline = {}
+        for k, gf in stage_gf.items():
+            ms = stage_time[k] / calls
+            if gf > 0 and ms > 0:
+                stage_roofline[k] = {"executed_gflop_per_step": round(gf, 2), "ms": round(ms, 4),
+                                     "tflops": round(gf / ms, 2), "frac_chip": round(gf / ms / FP32_MFMA_PEAK_TFLOPS, 4)}
+        stage_roofline["note"] = ("executed matrix-core GFLOP of all chains per step / the main stream's time in the stage / 157.3; "
+                                  "stages without matrix-core work (front, warp) are HBM-bound: see roofline_warp")
+        total_ms = sum(pm.values())
 
         def hbm(by, ms):
             return {"achieved": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -434,6 +459,7 @@ def main():
                                         "frac_chip": round(per_launch / FP32_MFMA_PEAK_TFLOPS, 4),
                                         "cu_share": round(cu_share, 4),
                                         "frac_of_occupied_cus": round(per_launch / (FP32_MFMA_PEAK_TFLOPS * cu_share), 4),
+                                        "stream": "chain 0 (the main stream; the other chains' launches carry no events)",
                                         "note": "one main-stream launch (HIP events around the kernel); with chains it covers "
                                                 "1/chains of the frames and the other chain's kernels run beside it: frac_chip is "
                                                 "against the whole chip, frac_of_occupied_cus against the CUs its grid can occupy"},
@@ -457,6 +483,7 @@ def main():
                                                        **hbm(B * warp_bytes_frame, warp_iso_ms))} if warp_iso_ms else {})),
             "stage_ms_per_step": {k: round(v / calls, 4) for k, v in pm.items()},
             "stage_sum_ms": round(total_ms / calls, 4),
+            "stage_roofline": stage_roofline,
         }
         if t_bcast_ms is not None:
             line["source_broadcast_ms"] = round(t_bcast_ms, 3)

@@ -125,6 +125,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     // chain count both derive from this value
     c->pass_chains = c->pass_chains < 0 ? 1 : std::min(c->pass_chains, 4);
     c->bneck_chains = std::max(1, std::min(c->bneck_chains, 16));
+    c->bneck_stagger = env_int("EAMM_BNECK_STAGGER", c->bneck_stagger);
     c->pass_chains_min_frames = env_int("EAMM_PASS_CHAINS_MIN_FRAMES", c->pass_chains_min_frames);
     c->pass_chains_min_blocks = env_int("EAMM_PASS_CHAINS_MIN_BLOCKS", c->pass_chains_min_blocks);
     c->head_col7_min_tiles = env_int("EAMM_HEAD_COL7_MIN_TILES", c->head_col7_min_tiles);
@@ -147,6 +148,7 @@ void eamm_destroy(eamm_ctx* c) {
     for (auto& e : c->prof_events) (void)hipEventDestroy(e);
     for (auto& e : c->prof_chain_ev) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_stagger) (void)hipEventDestroy(c->ev_stagger);
     for (auto& e : c->ev_join) (void)hipEventDestroy(e);
     for (auto& st : c->side_streams) (void)hipStreamDestroy(st);
     delete c;
@@ -445,6 +447,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
     const int max_chains = std::max(c->bneck_chains, c->pass_chains == 0 ? 2 : c->pass_chains);
     if (max_chains > 1) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming));
         for (int k = 1; k < max_chains; ++k) {
             hipStream_t st = nullptr;
             hipEvent_t ev = nullptr;
@@ -640,12 +643,21 @@ static int pass_chains(const eamm_ctx* c, int n) {
 }
 
 // One launch sequence over the frames of `v` on stream s.  `chained`: another sequence runs beside this one.
-static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent_t* ev, bool chained, hipEvent_t* cev = nullptr) {
+static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent_t* ev, bool chained, hipEvent_t* cev = nullptr,
+                        int chain_idx = 0) {
     const int n = v.n, ns = v.ns;
     const int h = c->h, w = c->w, hf = c->hf, wf = c->wf, K = c->K;
     const bool occ = c->cfg.estimate_occlusion_map != 0;
+    // executed matrix-core flops launched since the last mark belong to the stage interval that ends here
+    auto account = [&](int interval) {
+        const double f = take_mfma_flops();
+        c->call_flops += f;
+        c->call_stage_flops[interval] += f;
+        if (interval == 5) c->call_flops_bneck += f;
+    };
 #define STAGE_MARK(i)                                  \
     do {                                               \
+        if ((i) > 0) account((i) - 1);                 \
         if (ev) {                                      \
             HIP_TRY(c, hipEventRecord(ev[i], s));      \
             c->prof_marks.back() = (i) + 1;            \
@@ -764,7 +776,6 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
     // bottleneck                                                               generator.py:89
     float *x = v.xa, *xn = v.xb;
     if (cev) HIP_TRY(c, hipEventRecord(cev[0], s));
-    c->call_flops += take_mfma_flops();
     hipEvent_t* sub = (ev && wino && 4 * nr + 1 <= eamm_ctx::NSUB) ? ev + eamm_ctx::NMARK + 1 : nullptr;
     int nsub = 0;
 #define SUB_MARK()                                               \
@@ -811,7 +822,10 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         // conv1(relu(norm1(x))): the pre-activation rides on the input transform; norm2 + relu in the epilogue
         SUB_MARK();
         if (wino4) {
+            const bool stagger = chained && c->bneck_stagger && c->ev_stagger && i == 0;
+            if (stagger && chain_idx > 0) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_stagger, 0));
             HIP_TRY(c, wino4_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, v.wino_v, s));
+            if (stagger && chain_idx == 0) HIP_TRY(c, hipEventRecord(c->ev_stagger, s));
             SUB_MARK();
             HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], v.wino_v, n, hf, wf, ACT_RELU, nullptr, v.tmp, s, c->wino4_variant, w4g, v.wino_z));
             SUB_MARK();
@@ -863,11 +877,6 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
     }
     STAGE_MARK(6);
     if (cev) HIP_TRY(c, hipEventRecord(cev[1], s));
-    {
-        const double fb = take_mfma_flops();
-        c->call_flops += fb;
-        c->call_flops_bneck += fb;
-    }
     // up blocks                                                                generator.py:90-91
     const float* cur = x;
     for (int i = 0; i < c->nd; ++i) {
@@ -912,7 +921,7 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         }
     }
     if (v.out.frames_u8) HIP_TRY(c, to_u8_launch(v.out.prediction, n, c->H, c->W, v.out.frames_u8, s));
-    c->call_flops += take_mfma_flops();
+    account(7);
 #undef STAGE_MARK
     return EAMM_OK;   // (the caller records the last stage mark, after joining the chains)
 }
@@ -952,6 +961,7 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     }
     (void)take_mfma_flops();
     c->call_flops = c->call_flops_bneck = 0.0;
+    for (double& f : c->call_stage_flops) f = 0.0;
     if (chains == 1) {
         if (int rc = forward_view(c, make_view(c, 0, n, ns, 0, kd_val, kd_jac, ks_val, ks_jac, o), s, ev, false, cev)) return rc;
     } else {
@@ -962,7 +972,7 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
             const int nk = nbase + (k < nrem ? 1 : 0), f0 = k * nbase + std::min(k, nrem);
             const FrameView v = make_view(c, f0, nk, ns, k, kd_val, kd_jac, ks_val, ks_jac, o);
             if (int rc = forward_view(c, v, k ? c->side_streams[k - 1] : s, k ? nullptr : ev, true,
-                                      (cev && k < eamm_ctx::MAXCHAIN) ? cev + 2 * k : nullptr))
+                                      (cev && k < eamm_ctx::MAXCHAIN) ? cev + 2 * k : nullptr, k))
                 return rc;
         }
         for (int k = 1; k < chains; ++k) {
@@ -975,6 +985,8 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         c->prof_marks.back() = eamm_ctx::NMARK + 1;
         c->prof_flops.back() = c->call_flops;
         c->prof_flops_bneck.back() = c->call_flops_bneck;
+        for (int i = 0; i < eamm_ctx::NMARK; ++i)
+            c->prof_stage_flops[(size_t)(c->prof_used - 1) * eamm_ctx::NMARK + i] = c->call_stage_flops[i];
     }
     return EAMM_OK;
 }
@@ -988,6 +1000,7 @@ int eamm_profile_enable(eamm_ctx* c, int on) {
         for (auto& e : c->prof_events) HIP_TRY(c, hipEventCreate(&e));
         c->prof_chain_ev.resize((size_t)eamm_ctx::PROF_CALLS * eamm_ctx::MAXCHAIN * 2);
         for (auto& e : c->prof_chain_ev) HIP_TRY(c, hipEventCreate(&e));
+        c->prof_stage_flops.assign((size_t)eamm_ctx::PROF_CALLS * eamm_ctx::NMARK, 0.0);
     }
     c->profiling = on != 0;
     return EAMM_OK;
@@ -1055,6 +1068,7 @@ int eamm_profile_read(eamm_ctx* c, double* stage_ms, int nstage, int64_t* calls,
                 ms_set[11] = sum;
                 ms_set[12] = c->prof_flops[k] * 1e-9;
                 ms_set[13] = c->prof_flops_bneck[k] * 1e-9;
+                for (int i = 0; i < eamm_ctx::NMARK; ++i) ms_set[14 + i] = c->prof_stage_flops[(size_t)k * eamm_ctx::NMARK + i] * 1e-9;
             }
         }
         if (!ok) {
@@ -1458,7 +1472,9 @@ int eamm_op_warp(int device, const float* feat, const float* deformation, const 
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    // (no stream synchronisation outside the timing branch: like every other operator entry the work is only ENQUEUED on
+    // `stream` -- the differentiable forward calls this three times per pass and must stay capturable)
+    if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "eamm_op_warp failed: %s", hipGetErrorString(e));
     return EAMM_OK;
 }

@@ -43,6 +43,9 @@ struct eamm_ctx : eamm::CtxBase {
     int pass_chains_min_frames = 8;        // ... from this many frames per call (EAMM_PASS_CHAINS_MIN_FRAMES)
     std::vector<hipStream_t> side_streams; // the other chains' streams + fork / join events
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_stagger = nullptr;       // recorded by the first chain after its first bottleneck input transform
+    int bneck_stagger = 0;                 // EAMM_BNECK_STAGGER=1: the other whole-pass chains start their bottleneck stage behind that event, so the
+                                           // chains' HBM-bound input transforms run beside the other chain's GEMM instead of beside each other
     std::vector<hipEvent_t> ev_join;
     int wino_tile = 4;                     // preferred output tile (EAMM_WINO_TILE): 4 -> F(4x4) where it applies, 2 -> F(2x2)
     int wino4_variant = 3;                 // wino4_gemm_kernel pipeline variant (3: one DMA piece per 8 MFMAs; 2.062 -> 2.047 ms per step vs one per 4)
@@ -83,10 +86,11 @@ struct eamm_ctx : eamm::CtxBase {
     double flops_frame = 0, flops_encode = 0;
 
     // optional stage timing with HIP events on the caller's stream (bench.py roofline leg)
-    static constexpr int NSTAGE = 14;      // front, hg_enc, hg_dec, head, warp, bneck_transform, bneck_conv, up, final + bneck_gemm_kernel
+    static constexpr int NSTAGE = 22;      // front, hg_enc, hg_dec, head, warp, bneck_transform, bneck_conv, up, final + bneck_gemm_kernel
                                            // + bneck_union_ms (wall time during which ANY chain is in its bottleneck stage), bneck_windows_ms (sum of
                                            // the chains' bottleneck windows), exec_gflop / bneck_exec_gflop (executed MFMA GFLOP of the recorded
-                                           // calls, all chains: whole pass / bottleneck GEMMs)
+                                           // calls, all chains: whole pass / bottleneck GEMMs) + 14..21 executed MFMA GFLOP of each of the eight
+                                           // recorded stage intervals (front, hg_enc, hg_dec, head, warp, bottleneck, up, final), all chains
     static constexpr int MAXCHAIN = 4;     // chains whose bottleneck window is recorded per call
     static constexpr int NMARK = 8;        // stage boundaries recorded per call (bottleneck is split from sub-events)
     static constexpr int NSUB = 64;        // per-launch events inside the bottleneck (4 per res-block + 1)
@@ -97,6 +101,8 @@ struct eamm_ctx : eamm::CtxBase {
     std::vector<int> prof_nchain;          // chains recorded by each call
     std::vector<double> prof_flops, prof_flops_bneck;   // executed MFMA flops of each recorded call
     double call_flops = 0, call_flops_bneck = 0;         // ... of the call being enqueued
+    double call_stage_flops[8] = {0};                    // ... per stage interval (all chains)
+    std::vector<double> prof_stage_flops;                // PROF_CALLS * NMARK
     std::vector<int> prof_sub;             // sub-events used by each recorded call (0: direct form)
     std::vector<int> prof_marks;           // stage marks each recorded call completed (NMARK + 1 unless it failed midway)
     int prof_used = 0;

@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from .keypoint_detector import _refuse_silent_detach
 from .weights import DECONV_CHANNELS
 
 
@@ -86,9 +87,13 @@ class DeconvTail(nn.Sequential):
             _lib.check(L.eamm_deconv_finalize_weights(ctx), ctx, deconv=True)
         self._key = key
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: [B,C0,1,1] (the reference's call, util.py:603-607) or [B,C0]; returns [B,C_last,S,S]."""
+        _refuse_silent_detach(self, x)
+        with torch.no_grad():
+            return self._forward(x)
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() == 4 and x.shape[2:] == (1, 1):
             x = x.flatten(1)
         if x.dim() != 2 or x.shape[1] != self.channels[0] or x.dtype != torch.float32:

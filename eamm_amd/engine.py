@@ -264,7 +264,8 @@ class Engine:
 
     # -- stage timing (HIP events inside the library, on the stream the kernels run on) -----------------
     STAGES = ("front", "hg_enc", "hg_dec", "head", "warp", "bneck_transform", "bneck_conv", "up", "final", "bneck_gemm_kernel",
-              "bneck_union", "bneck_windows", "exec_gflop", "bneck_exec_gflop")   # the last four: chip-level accounting (eamm_hip.h)
+              "bneck_union", "bneck_windows", "exec_gflop", "bneck_exec_gflop",   # these four: chip-level accounting (eamm_hip.h)
+              "gf_front", "gf_hg_enc", "gf_hg_dec", "gf_head", "gf_warp", "gf_bneck", "gf_up", "gf_final")   # executed GFLOP per stage
 
     def profile(self, on: bool = True):
         _lib.check(self._L.eamm_profile_enable(self._ctx, int(on)), self._ctx)

@@ -7,9 +7,15 @@ set, so ``generator.load_state_dict(checkpoint['generator'])`` / ``.cuda()`` / `
 (demo.py:56-57, 91, 105) work unchanged.  The sub-modules below only HOLD parameters under the
 reference's names; they are never called.  All computation happens in the HIP library; there is no
 PyTorch/CPU fallback and ``forward`` raises when the module is not on a GPU.  ``.train()`` is supported (batch statistics in
-every BatchNorm, running statistics updated, replicas' statistics all-reduced -- SURVEY.md 8f row N4): graph-free through the
-resumable engine, and -- when something requires a gradient -- as a composition of differentiable HIP operators
-(``train_graph``), so ``loss.backward()`` reaches the parameters and the key points as in train.py:133.
+every BatchNorm, running statistics updated, replicas' statistics all-reduced -- SURVEY.md 8f row N4).
+
+Autograd semantics are the reference module's: parameters keep PyTorch's default ``requires_grad=True``, so
+``torch.optim.Adam(generator.parameters())`` + ``loss.backward()`` (train.py:133-136) works straight after construction.
+Whenever gradients are enabled and anything that reaches the output requires one -- a parameter, the key points, the source --
+``forward`` is the composition of differentiable HIP operators of ``train_graph`` (batch statistics in ``.train()``, running
+statistics in ``.eval()``) and its outputs carry the graph, exactly where the reference's would.  Under ``torch.no_grad()``
+(demo.py:195) it is the graph-free engine: the folded fast path in ``.eval()``, the resumable batch-statistics pass in
+``.train()``.  An output is never silently detached.
 
 Beyond the reference interface the module exposes the two halves of forward separately
 (``encode_source`` / ``forward_frames``) so that a clip can reuse the frame-invariant source
@@ -18,6 +24,7 @@ encoder (the reference recomputes it per frame, generator.py:61-63 inside demo.p
 from __future__ import annotations
 
 import operator
+import warnings
 from typing import Dict, Iterable, Optional
 
 import torch
@@ -28,6 +35,27 @@ from .weights import antialias_kernel, generator_channels, hourglass_channels
 
 
 _VERSION_OF = operator.attrgetter("_version")
+
+# Structure epoch: bumped whenever ANY module in the process registers a parameter, buffer or sub-module (attribute
+# assignment of a Parameter / Module, add_module, register_buffer, ModuleList / Sequential item assignment).  The
+# generator's cached list of tensor slots is rebuilt when the epoch has moved, so a replaced sub-module
+# (``gen.bottleneck[0] = ...``) or a tensor registered later is seen -- at the cost of one integer compare per forward.
+_STRUCTURE_EPOCH = [0]
+
+
+def _bump_epoch(*_args):
+    _STRUCTURE_EPOCH[0] += 1
+    return None
+
+
+def _install_registration_hooks():
+    from torch.nn.modules import module as _m
+    for name in ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook",
+                 "register_module_module_registration_hook"):
+        getattr(_m, name)(_bump_epoch)
+
+
+_install_registration_hooks()
 
 
 class _ConvNorm(nn.Module):
@@ -129,8 +157,7 @@ class OcclusionAwareGenerator(nn.Module):
         # replicas' formula on or off (sync_batchnorm/batchnorm.py:48-53 vs :55-125)
         self.process_group = None
         self.sync_batchnorm: Optional[bool] = None
-        for p in self.parameters():  # inference is the default use: fine-tuning opts in with .requires_grad_(True)
-            p.requires_grad_(False)
+        # (parameters keep requires_grad=True as in the reference: the optimiser of train.py:136 sees every one of them)
 
     # -- engine management ---------------------------------------------------------------------------
     def _tensor_slots(self):
@@ -138,19 +165,20 @@ class OcclusionAwareGenerator(nn.Module):
         sees replaced tensors (``.cuda()``, ``load_state_dict(assign=True)``, attribute assignment) without rebuilding a
         ``state_dict`` per forward (340 us for the 196 tensors of the shipped configuration -- a third of a one-frame call)."""
         slots = self.__dict__.get("_slots")
-        if slots is None:
+        if slots is None or self.__dict__.get("_slots_epoch") != _STRUCTURE_EPOCH[0]:
             slots = []
             for prefix, mod in self.named_modules():
-                for store in (mod._parameters, mod._buffers):
-                    for key, t in store.items():
-                        if t is not None and key not in mod._non_persistent_buffers_set:
+                for store, skip in ((mod._parameters, ()), (mod._buffers, mod._non_persistent_buffers_set)):
+                    for key in store:            # (a slot that holds None today is kept: it may be assigned later)
+                        if key not in skip:
                             slots.append((store, key, (prefix + "." if prefix else "") + key))
             self.__dict__["_slots"] = slots
+            self.__dict__["_slots_epoch"] = _STRUCTURE_EPOCH[0]
         return slots
 
     def _weights_version(self):
         # identity AND version: a replaced tensor may carry the same version counter as the one it replaces
-        ts = [store[key] for store, key, _ in self._tensor_slots()]
+        ts = [t for t in (store[key] for store, key, _ in self._tensor_slots()) if t is not None]
         return tuple(map(id, ts)) + tuple(map(_VERSION_OF, ts))
 
     def _ensure_engine(self, height: int, width: int, frames: int, sources: int) -> Engine:
@@ -179,7 +207,8 @@ class OcclusionAwareGenerator(nn.Module):
             raise RuntimeError("eamm_amd.OcclusionAwareGenerator runs only on a ROCm GPU: move the module with "
                                ".cuda() first (there is no CPU fallback for this path)")
         # convolution weights only: the BatchNorm tensors are read (and the running statistics written) in place
-        conv_version = tuple((id(store[key]), store[key]._version) for store, key, name in self._tensor_slots() if ".norm" not in name)
+        conv_version = tuple((id(store[key]), store[key]._version) for store, key, name in self._tensor_slots()
+                             if ".norm" not in name and store[key] is not None)
         e = self._train_engine
         key = (dev, height, width, conv_version)
         if e is None or self._train_key != key or e.max_frames < frames:
@@ -236,16 +265,23 @@ class OcclusionAwareGenerator(nn.Module):
     def forward(self, source_image, kp_driving, kp_source):
         """Reference generator.py:59-97: batch of independent (source, kp_source, kp_driving) triples.  In ``.train()`` mode
         every BatchNorm normalises with the statistics of the batch and updates its running statistics, as the reference's
-        blocks do (modules/util.py:858-938).  The outputs carry an autograd graph only in ``.train()`` mode with gradients
-        enabled and something to differentiate (a parameter after ``requires_grad_(True)``, or an input that requires grad):
-        then the forward is the composition of differentiable HIP operators of ``train_graph`` (train.py:133's
-        ``loss.backward()``); in every other case it is the graph-free engine."""
+        blocks do (modules/util.py:858-938).  The outputs carry an autograd graph exactly when the reference's would: gradients
+        enabled and a parameter (``requires_grad`` is PyTorch's default True) or an input that requires one -- then the forward
+        is the composition of differentiable HIP operators of ``train_graph`` (train.py:133's ``loss.backward()``), with batch
+        statistics in ``.train()`` and running statistics in ``.eval()``.  Under ``torch.no_grad()`` (demo.py:195) it is the
+        graph-free engine."""
         if source_image.dim() != 4:
             raise RuntimeError(f"source_image must be [B,3,H,W], got {tuple(source_image.shape)}")
-        if self.training and self._wants_graph(source_image, kp_driving, kp_source):
+        if self._wants_graph(source_image, kp_driving, kp_source):
             from . import train_graph
+            if not self.training and not self.__dict__.get("_warned_eval_graph"):
+                self.__dict__["_warned_eval_graph"] = True
+                warnings.warn("eamm_amd.OcclusionAwareGenerator: building an autograd graph in .eval() mode (gradients are enabled "
+                              "and a parameter or an input requires one) -- the differentiable operator composition, not the folded "
+                              "inference engine; wrap inference in torch.no_grad() as demo.py:195 does", stacklevel=2)
             out = train_graph.forward_train(self, source_image, kp_driving, kp_source)
-            self._bump_running_stats()
+            if self.training:
+                self._bump_running_stats()
             self._src_ref = None
             return {k: out[k] for k in ("mask", "sparse_deformed", "occlusion_map", "deformed", "prediction") if k in out}
         with torch.no_grad():

@@ -21,6 +21,18 @@ from .generator import _AntiAlias, _ConvNorm, _Stack
 from .weights import hourglass_channels
 
 
+
+def _refuse_silent_detach(mod: nn.Module, x: torch.Tensor):
+    """These modules are inference-only (no backward kernels: SURVEY.md 8f N1 / N3 are forward rows; their parameters are
+    frozen at construction).  If the caller nevertheless asks for a gradient -- gradients enabled and the input or a
+    re-enabled parameter requires one -- the reference would return a differentiable tensor; returning a detached one
+    would silently train nothing, so refuse instead."""
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mod.parameters())):
+        raise RuntimeError(f"eamm_amd.{type(mod).__name__} is inference-only (forward kernels, no backward): call it under "
+                           "torch.no_grad() / with frozen parameters and an input that does not require grad; it never "
+                           "returns a silently detached tensor")
+
+
 class _KPBase(nn.Module):
     _with_predictor = True
 
@@ -127,8 +139,12 @@ class KPDetector(_KPBase):
         super().__init__(block_expansion, num_kp, num_channels, max_features, num_blocks, temperature,
                          estimate_jacobian, scale_factor, single_jacobian_map, pad, None, max_batch)
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        _refuse_silent_detach(self, x)
+        with torch.no_grad():
+            return self._forward(x)
+
+    def _forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:
             raise RuntimeError(f"expected a float32 [B,3,H,W] image batch, got {tuple(x.shape)} {x.dtype}")
         b, _, hh, ww = x.shape
@@ -147,8 +163,12 @@ class KPDetector_a(_KPBase):
         super().__init__(block_expansion, num_kp, num_channels, max_features, num_blocks, temperature,
                          estimate_jacobian, scale_factor, single_jacobian_map, pad, num_channels_a, max_batch)
 
-    @torch.no_grad()
     def forward(self, feature_map: torch.Tensor) -> Dict[str, torch.Tensor]:
+        _refuse_silent_detach(self, feature_map)
+        with torch.no_grad():
+            return self._forward(feature_map)
+
+    def _forward(self, feature_map: torch.Tensor) -> Dict[str, torch.Tensor]:
         if feature_map.dim() != 4 or feature_map.shape[1] != self.out_filters or feature_map.dtype != torch.float32:
             raise RuntimeError(f"expected a float32 [B,{self.out_filters},h,w] feature map, got "
                                f"{tuple(feature_map.shape)} {feature_map.dtype}")

@@ -1,6 +1,8 @@
-"""Differentiable ``.train()`` forward of OcclusionAwareGenerator -- SURVEY.md section 8f row N4, the backward half: what
+"""Differentiable forward of OcclusionAwareGenerator -- SURVEY.md section 8f row N4, the backward half: what
 ``loss.backward()`` needs in the reference's fine-tuning loop (train.py:133; the generator stays in training mode there and the
-loss reaches both the generator's parameters and, through the flow, the audio-driven key points).
+loss reaches both the generator's parameters and, through the flow, the audio-driven key points).  ``.eval()`` with gradients
+enabled takes the same composition with every BatchNorm on its running statistics (sync_batchnorm/batchnorm.py:48-53), so the
+output is differentiable in evaluation mode as the reference module's is.
 
 The reference composes ``nn.Conv2d`` / ``SynchronizedBatchNorm2d`` / ``F.grid_sample`` modules and lets autograd differentiate
 them (modules/generator.py:59-97, dense_motion.py:32-113, util.py:858-1002).  Here the same composition is built from this
@@ -17,7 +19,8 @@ Activations stay NHWC -- the kernels' layout -- from the source image to the pre
 or a few hundred floats (nearest x2, residual add, softmax over the K+1 motions, sigmoid, heat-maps, 2x2 jacobian algebra,
 channel padding to the kernels' 32-channel granule, anti-aliasing as two banded GEMMs) and stay torch-ROCm ops with their
 own autograd.  This is the OP-LEVEL composition: it exists so that the backward kernels are exercised and verified in
-the generator's real data flow (tests/test_gpu_train_backward.py: gradients against the reference's autograd fixture); it
+the generator's real data flow (tests/test_train_backward.py: gradients against the reference's autograd fixtures; the
+operators one by one: tests/test_gpu_backward.py); it
 re-packs filters per call and is not the tuned path -- the inference engine and the resumable training forward are.
 GPU only: no CPU fallback.
 """
@@ -86,38 +89,50 @@ class _Graph:
 
     def __init__(self, gen):
         self.gen = gen
-        self.adapters: Dict[int, SynchronizedBatchNorm2d] = gen.__dict__.setdefault("_bn_adapters", {})
+        self.training = bool(gen.training)
 
     def norm_relu(self, x: torch.Tensor, holder: torch.nn.BatchNorm2d, pool: bool = False) -> torch.Tensor:
         """[avgpool2x2](relu(BatchNorm(x))) in one fused operator (every BatchNorm of the generator is followed by a ReLU)."""
-        # the holder owns the tensors (state_dict names of the reference); the adapter lends them to the Function
-        a = self.adapters.get(id(holder))
-        if a is None:
+        if x.shape[3] != holder.num_features:
+            raise RuntimeError(f"expected {holder.num_features} channels, got {x.shape[3]}")
+        if not self.training:
+            # evaluation mode (batchnorm.py:48-53): a per-channel affine map from the running statistics -- a few element-wise
+            # torch ops with their own autograd (differentiable in x, weight and bias; the statistics are buffers)
+            scale = holder.weight * torch.rsqrt(holder.running_var + holder.eps)
+            y = torch.relu(x * scale + (holder.bias - holder.running_mean * scale))
+            if pool:
+                b, h, w, c = y.shape
+                y = y.view(b, h // 2, 2, w // 2, 2, c).mean(dim=(2, 4))
+            return y
+        # the holder owns the tensors (state_dict names of the reference); the adapter lends them to the Function.  The
+        # adapter lives ON the holder (not in a table keyed by id(holder): ids go stale after deepcopy / are reused)
+        a = holder.__dict__.get("_eamm_adapter")
+        if a is None or a.num_features != holder.num_features:
             a = SynchronizedBatchNorm2d(holder.num_features, eps=holder.eps, momentum=holder.momentum)
-            self.adapters[id(holder)] = a
+            holder.__dict__["_eamm_adapter"] = a
+        a.eps, a.momentum = holder.eps, holder.momentum
         a._parameters["weight"], a._parameters["bias"] = holder.weight, holder.bias
         a._buffers["running_mean"], a._buffers["running_var"] = holder.running_mean, holder.running_var
         a.training = True
         a.process_group, a.sync = self.gen.process_group, self.gen.sync_batchnorm
-        if x.shape[3] != holder.num_features:
-            raise RuntimeError(f"expected {holder.num_features} channels, got {x.shape[3]}")
         a._ops.check(x, a)
         if a._replicas() == 1 and x.numel() // x.shape[3] <= 1:      # batchnorm.py:112
             raise AssertionError("BatchNorm computes unbiased standard-deviation, which requires size > 1.")
         return _BatchNormNHWCFunction.apply(x.contiguous(), holder.weight, holder.bias, a, True, pool)
 
     # ---- blocks: modules/util.py:858-938 --------------------------------------------------------------------------------
+    # (feeds_norm -- "the bias gradient is exactly zero" -- holds for BATCH statistics only: training mode)
     def same_block(self, x, blk):
-        return self.norm_relu(conv(x, blk.conv, feeds_norm=True), blk.norm)
+        return self.norm_relu(conv(x, blk.conv, feeds_norm=self.training), blk.norm)
 
     def down_block(self, x, blk):
-        return self.norm_relu(conv(x, blk.conv, feeds_norm=True), blk.norm, pool=True)
+        return self.norm_relu(conv(x, blk.conv, feeds_norm=self.training), blk.norm, pool=True)
 
     def up_block(self, x, blk):
         return self.same_block(_upsample2(x), blk)
 
     def res_block(self, x, blk):
-        y = conv(self.norm_relu(x, blk.norm1), blk.conv1, feeds_norm=True)      # conv1 -> norm2
+        y = conv(self.norm_relu(x, blk.norm1), blk.conv1, feeds_norm=self.training)      # conv1 -> norm2
         y = conv(self.norm_relu(y, blk.norm2), blk.conv2)
         return y + x
 
@@ -209,14 +224,15 @@ def _dense_motion(g: _Graph, source_image, kp_driving, kp_source):
 
 
 def forward_train(gen, source_image: torch.Tensor, kp_driving, kp_source) -> Dict[str, torch.Tensor]:
-    """OcclusionAwareGenerator.forward in ``.train()`` mode WITH an autograd graph (generator.py:59-97); NCHW in and out."""
+    """OcclusionAwareGenerator.forward WITH an autograd graph (generator.py:59-97); NCHW in and out.  ``gen.training`` picks
+    batch statistics (+ running-statistics update) or running statistics in every BatchNorm."""
     if source_image.device.type != "cuda":
         raise RuntimeError("eamm_amd.OcclusionAwareGenerator runs only on a ROCm GPU (there is no CPU fallback for this path)")
     g = _Graph(gen)
     src_nhwc = source_image.permute(0, 2, 3, 1)
     fc = gen.first.conv                                                                    # generator.py:61-63
     if fc.weight.shape[1] == 3 and fc.weight.shape[0] in (32, 64) and fc.bias is not None:
-        out = g.norm_relu(autograd_ops.first_conv7(F.pad(src_nhwc, (0, 1)), fc.weight, fc.bias, bias_grad_is_zero=True), gen.first.norm)
+        out = g.norm_relu(autograd_ops.first_conv7(F.pad(src_nhwc, (0, 1)), fc.weight, fc.bias, bias_grad_is_zero=g.training), gen.first.norm)
     else:
         out = g.same_block(src_nhwc, gen.first)
     for blk in gen.down_blocks:

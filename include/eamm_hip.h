@@ -323,9 +323,11 @@ int eamm_train_next(eamm_ctx* ctx, int* nfloats);
  * Chip-level accounting (all chains, not only the main stream): 10 the wall time during which ANY whole-pass chain is
  * inside its bottleneck stage (union of the chains' windows, events on every chain's stream), 11 the sum of those
  * windows, 12 executed matrix-core GFLOP of the recorded calls (what the grids really issue: padded tiles, Winograd /
- * polyphase point counts), 13 the bottleneck GEMMs' share of 12.  (12 and 13 are GFLOP, not milliseconds.)
+ * polyphase point counts), 13 the bottleneck GEMMs' share of 12, 14..21 the same count per stage interval (key points +
+ * front end, hourglass encoder, hourglass decoder, flow head, warp, bottleneck, up blocks, final layer) so that every stage's
+ * fraction of the matrix peak can be printed, not only the bottleneck's.  (12..21 are GFLOP, not milliseconds.)
  */
-#define EAMM_NSTAGE 14
+#define EAMM_NSTAGE 22
 int eamm_profile_enable(eamm_ctx* ctx, int on);
 int eamm_profile_read(eamm_ctx* ctx, double* stage_ms, int nstage, int64_t* calls, int64_t* frames, int reset);
 

@@ -524,25 +524,30 @@ def train_mode_case(OAG):
     print("tiny64_train: wrote", len(blob), "arrays;", len(norm_names), "BatchNorm sites")
 
 
-def train_backward_case(OAG):
-    """Fixture for the generator's BACKWARD in .train() mode (N4): the reference generator on one replica, a scalar loss that
+def train_backward_case(OAG, name="tiny64_train_backward", cfg=None, size=64, n=4, max_samples=8192, training=True):
+    """Fixture for the generator's BACKWARD (N4): the reference generator on one replica, a scalar loss that
     weighs every output with fixed random tensors, ``loss.backward()`` -- the gradients autograd derives for every parameter,
     the key points (value + jacobian of driving and source) and the source image.  Stored in fp32 as the reference computes
     them, with the fp32-vs-fp64 distance of each (the same computation in double) so that tests can scale their bars to the
-    algorithm's own noise floor.  The oracle's training branch must reproduce them."""
-    cfg = tiny_config()
+    algorithm's own noise floor.  The oracle must reproduce them.  ``tiny64_train_backward`` (.train(), 4 pairs at 64x64),
+    ``full256_train_backward`` (.train(), the shipped configuration, 2 pairs at 256x256 -- the size at which the Winograd
+    weight gradient, the thin 7x7 kernels on 64 channels and the split-group F(4x4) run inside the graph; round 4) and
+    ``tiny64_eval_backward`` / ``full256_eval_backward`` (.eval(): running statistics -- the reference module is differentiable
+    in evaluation mode too; without the batch statistics' cancellation the fp32 floor is 10-100x lower, so the 256x256 one is
+    the SHARP check of the convolution / warp backward kernels at the shapes they run at)."""
+    cfg = tiny_config() if cfg is None else cfg
     sd = synthetic_state_dict(cfg, seed=1234)
-    n = 4
-    source = synthetic_source(64, seed=1, batch=n)
+    source = synthetic_source(size, seed=1, batch=n)
     kp_s = synthetic_keypoints(n, cfg["num_kp"], seed=0)
     kp_d = synthetic_keypoints(n, cfg["num_kp"], seed=2)
     keys = ("prediction", "mask", "sparse_deformed", "occlusion_map", "deformed")
     gen = torch.Generator().manual_seed(77)
+    full_outputs = size <= 64
 
     def run(dtype):
         g = OAG(**cfg)
         g.load_state_dict(sd, strict=True)
-        g = g.to(dtype).train()
+        g = g.to(dtype).train(training)
         src = source.detach().clone().to(dtype).requires_grad_()
         ks = {k: v.detach().clone().to(dtype).requires_grad_() for k, v in kp_s.items()}
         kd = {k: v.detach().clone().to(dtype).requires_grad_() for k, v in kp_d.items()}
@@ -561,20 +566,26 @@ def train_backward_case(OAG):
     with torch.no_grad():
         g0 = OAG(**cfg)
         g0.load_state_dict(sd, strict=True)
-        shapes = {k: v.shape for k, v in g0.train()(source, kp_source=kp_s, kp_driving=kp_d).items() if k in keys}
+        shapes = {k: v.shape for k, v in g0.train(training)(source, kp_source=kp_s, kp_driving=kp_d).items() if k in keys}
     weights = {k: torch.randn(shapes[k], generator=gen) for k in keys}
     loss32, g32, out32 = run(torch.float32)
-    loss64, g64, _ = run(torch.float64)
-    blob = {"weight_seed": np.int64(1234), "n": np.int64(n), "loss": np.float64(loss32), "loss64": np.float64(loss64),
-            "names": np.array(sorted(g32))}
+    loss64, g64, out64 = run(torch.float64)
+    blob = {"weight_seed": np.int64(1234), "n": np.int64(n), "size": np.int64(size), "loss": np.float64(loss32),
+            "loss64": np.float64(loss64), "names": np.array(sorted(g32)), "weights_seed": np.int64(77)}
     for k in keys:
-        blob["w/" + k] = weights[k].numpy()
-        blob["out/" + k] = out32[k].numpy()
+        if full_outputs:
+            blob["w/" + k] = weights[k].numpy()
+            blob["out/" + k] = out32[k].numpy()
+        else:   # the loss weights are torch.randn(shape, generator=manual_seed(77)) in `keys` order: regenerated by the test
+            ostep = (out32[k].numel() // 16384) | 1
+            blob["ostep/" + k] = np.int64(ostep)
+            blob["out/" + k] = out32[k].reshape(-1)[::ostep].numpy()
+            blob["out64/" + k] = out64[k].reshape(-1)[::ostep].float().numpy()
     floor = {}
     gmax = max(float(v.abs().max()) for v in g64.values())
     for k in sorted(g32):
         # large tensors: every step-th element of the flattened gradient (step odd, so no fixed phase against the 3x3 taps)
-        step = 1 if g32[k].numel() <= 8192 else (g32[k].numel() // 8192) | 1
+        step = 1 if g32[k].numel() <= max_samples else (g32[k].numel() // max_samples) | 1
         blob["step/" + k] = np.int64(step)
         blob["grad/" + k] = g32[k].reshape(-1)[::step].numpy() if step > 1 else g32[k].numpy()
         g64s = g64[k].reshape(-1)[::step] if step > 1 else g64[k]
@@ -587,7 +598,7 @@ def train_backward_case(OAG):
         floor[k] = float((g32[k].double() - g64[k]).abs().max()) / (scale if scale >= 1e-9 * gmax else gmax)
         blob["floor/" + k] = np.float64(floor[k])
     nz = [k for k in floor if not blob["zero/" + k]]
-    print("train_backward: loss", float(loss32), "| largest gradient", f"{gmax:.3e}", "| fp32-vs-fp64 relative floor: worst",
+    print(name + ": loss", float(loss32), "| largest gradient", f"{gmax:.3e}", "| fp32-vs-fp64 relative floor: worst",
           max(nz, key=floor.get), f"{max(floor[k] for k in nz):.2e}", "median", f"{float(np.median([floor[k] for k in nz])):.2e}",
           "|", len(floor) - len(nz), "identically-zero gradients")
     # the oracle's training branch, differentiated by autograd, must give the same gradients (in double, against the double run)
@@ -596,7 +607,10 @@ def train_backward_case(OAG):
     src = source.detach().double().requires_grad_()
     ks = {k: v.detach().double().requires_grad_() for k, v in kp_s.items()}
     kd = {k: v.detach().double().requires_grad_() for k, v in kp_d.items()}
-    mine, _ = orc.generator_forward_train(sd64, cfg, src, kd, ks, parallel=False)
+    if training:
+        mine, _ = orc.generator_forward_train(sd64, cfg, src, kd, ks, parallel=False)
+    else:
+        mine = orc.generator_forward(sd64, cfg, src, kd, ks)
     sum((mine[k] * weights[k].double()).sum() for k in keys).backward()
     worst = 0.0
     for k in sorted(g64):
@@ -612,16 +626,27 @@ def train_backward_case(OAG):
         if rel > 1e-9:
             print('  oracle gradient differs:', k, rel, float(g64[k].abs().max()))
         worst = max(worst, rel)
-    print(f"train_backward: oracle autograd vs reference autograd (float64), worst relative |diff| {worst:.2e}")
+    print(f"{name}: oracle autograd vs reference autograd (float64), worst relative |diff| {worst:.2e}")
     assert worst < 1e-9, worst
-    np.savez_compressed(os.path.join(GOLDEN, "tiny64_train_backward.npz"), **blob)
-    print("tiny64_train_backward: wrote", len(blob), "arrays,", os.path.getsize(os.path.join(GOLDEN, "tiny64_train_backward.npz")) >> 10, "KiB")
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **blob)
+    print(name + ": wrote", len(blob), "arrays,", os.path.getsize(os.path.join(GOLDEN, name + ".npz")) >> 10, "KiB")
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "train_backward":
         os.makedirs(GOLDEN, exist_ok=True)
         train_backward_case(import_reference())
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "train_backward_256":
+        torch.set_num_threads(os.cpu_count() or 1)
+        train_backward_case(import_reference(), "full256_train_backward", hot_path_config(), 256, 2, max_samples=2048)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "eval_backward_256":
+        torch.set_num_threads(os.cpu_count() or 1)
+        train_backward_case(import_reference(), "full256_eval_backward", hot_path_config(), 256, 2, max_samples=2048, training=False)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "eval_backward":
+        train_backward_case(import_reference(), "tiny64_eval_backward", tiny_config(), 64, 2, training=False)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         os.makedirs(GOLDEN, exist_ok=True)
@@ -674,6 +699,9 @@ def main():
     batchnorm_case()
     train_mode_case(OAG)
     train_backward_case(OAG)
+    train_backward_case(OAG, "full256_train_backward", full, 256, 2, max_samples=2048)
+    train_backward_case(OAG, "tiny64_eval_backward", tiny, 64, 2, training=False)
+    train_backward_case(OAG, "full256_eval_backward", full, 256, 2, max_samples=2048, training=False)
     with open(os.path.join(GOLDEN, "summary.json"), "w") as f:
         json.dump({"torch": torch.__version__, "cases": summary}, f, indent=1, sort_keys=True)
     for name, rep in summary.items():

@@ -73,6 +73,46 @@ def test_bench_single_gpu_line():
     assert "error" not in t, t
     assert t["pairs"] == 8 and t["gradients_finite"] is True and t["step_ms"] > 0
     assert abs(t["pairs_per_s"] - 8 / t["step_ms"] * 1e3) / t["pairs_per_s"] < 0.01 and t["step_ms"] <= t["forward_ms"] + t["backward_ms"] + 5
+    # every stage's fraction of the chip's matrix peak is in the line, consistent with the headline
+    sr = d["stage_roofline"]
+    assert {"hg_enc", "hg_dec", "head", "bneck", "up", "final"} <= set(sr)
+    for k, v in sr.items():
+        if k != "note":
+            assert abs(v["tflops"] - v["executed_gflop_per_step"] / v["ms"]) / v["tflops"] < 0.01 and 0 < v["frac_chip"] <= 1.0, (k, v)
+    assert abs(sr["bneck"]["executed_gflop_per_step"] - r["bneck_executed_gflop_per_step"]) / r["bneck_executed_gflop_per_step"] < 1e-3
+    assert abs(sum(v["executed_gflop_per_step"] for k, v in sr.items() if k != "note") / 16 - wp["executed_gflop_per_frame"]) < 0.01
+    assert abs(sr["bneck"]["frac_chip"] - r["frac"]) < 0.05      # main-stream stage time vs the union of the chains' windows
+    _check_train_step_against_the_oracle(t)
+
+
+def _check_train_step_against_the_oracle(t):
+    """bench.py's training step prints its loss and gradient checksums; the same step (same seeds) through
+    the CPU oracle's training branch, differentiated by autograd in DOUBLE, must give the same numbers."""
+    import torch
+    from bench import train_step_target
+    from eamm_amd import hot_path_config
+    from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict
+    from oracle import eamm_oracle as orc
+    cfg, pairs, size = hot_path_config(), t["pairs"], t["size"]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sd = synthetic_state_dict(cfg, seed=1234)
+    leaf = lambda k, v: v.is_floating_point() and "running" not in k and "down.weight" not in k
+    sdd = {k: (v.double().requires_grad_() if leaf(k, v) else v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    src = synthetic_source(size, seed=1, batch=pairs).double()
+    kp_s = {k: v.double() for k, v in synthetic_keypoints(pairs, cfg["num_kp"], seed=0).items()}
+    kp_d = {k: v.double().requires_grad_() for k, v in synthetic_keypoints(pairs, cfg["num_kp"], seed=2).items()}
+    out, _ = orc.generator_forward_train(sdd, cfg, src, kp_d, kp_s, parallel=False)
+    loss = (out["prediction"] - train_step_target(pairs, size).double()).abs().mean()
+    loss.backward()
+    want = {"loss": float(loss.detach()),
+            "grad_l1/kp_driving.value": float(kp_d["value"].grad.abs().sum()),
+            "grad_l1/final.weight": float(sdd["final.weight"].grad.abs().sum()),
+            "grad_l1/bottleneck.r0.conv1.weight": float(sdd["bottleneck.r0.conv1.weight"].grad.abs().sum())}
+    got = t["checks"]
+    print("train_step checks: " + "  ".join(f"{k} {got[k]:.6g} (oracle64 {want[k]:.6g})" for k in want))
+    assert abs(got["loss"] - want["loss"]) <= 2e-4 * abs(want["loss"]), (got["loss"], want["loss"])
+    for k in want:   # L1 norms of whole gradient tensors: the per-element fp32 floor (a few 1e-3 at 8 pairs) averages out
+        assert abs(got[k] - want[k]) <= 2e-2 * abs(want[k]), (k, got[k], want[k])
 
 
 def test_bench_512_batch8_line():

@@ -17,6 +17,15 @@ from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_st
 from oracle import eamm_oracle as orc
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _called_as_demo_py_calls_it():
+    """Inference tests run under torch.no_grad(), as the reference's caller does (demo.py:195): with gradients enabled the
+    module -- like the reference's -- would build an autograd graph through the differentiable operators instead."""
+    with torch.no_grad():
+        yield
+
 DEV = "cuda:0"
 
 

@@ -17,6 +17,15 @@ KEYS = ("prediction", "mask", "sparse_deformed", "occlusion_map", "deformed")
 _GEN = {}
 
 
+@pytest.fixture(autouse=True)
+def _called_as_demo_py_calls_it():
+    """Inference tests run under torch.no_grad(), as the reference's caller does (demo.py:195): with gradients enabled the
+    module -- like the reference's -- would build an autograd graph through the differentiable operators instead."""
+    with torch.no_grad():
+        yield
+
+
+
 def generator(cfg_fn):
     """One module per config for the whole session (weights: seed 1234, like the fixtures)."""
     if cfg_fn not in _GEN:

@@ -1,0 +1,50 @@
+"""tools/rocpd_summary.py --bneck-timeline: the union of the chains' bottleneck windows re-derived from a rocprofv3 kernel
+trace (`roofline.frac` must reproduce from profiles/).  CPU test on a synthetic rocpd-shaped database:
+two chains on two streams, known offsets."""
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+from conftest import ROOT
+
+GEMM = "void eamm::wino4_gemm_kernel<2, 4, 2, 4, 2, 8, 0>(eamm::Wino4Args)"
+GEMM_HG = "void eamm::wino4_gemm_kernel<2, 4, 2, 4, 2, 4, 0>(eamm::Wino4Args)"
+TR = "void eamm::wino4_input_transform_kernel<4>(float const*, float const*, float const*, int, int, int, int, float*)"
+
+
+def test_bottleneck_timeline_union(tmp_path):
+    db = tmp_path / "kt_results.db"
+    con = sqlite3.connect(db)
+    con.execute("create table kernels (name text, start integer, end integer, duration integer, stream_id integer, queue_id integer, "
+                "vgpr_count integer, accum_vgpr_count integer, lds_size integer)")
+    rows = []
+    calls, nres, T, G = 5, 12, 30_000, 170_000          # ns
+    for call in range(calls):
+        base = call * 5_000_000
+        for lane, off in ((1, 0), (2, 40_000)):          # the second chain starts 40 us later
+            t = base + off
+            rows.append(("eamm::warp_features_kernel", t - 25_000, t - 5_000, 20_000, lane, lane))
+            rows.append((GEMM_HG, t - 600_000, t - 560_000, 40_000, lane, lane))   # an hourglass level: not the bottleneck
+            for _ in range(nres):
+                rows.append((TR, t, t + T, T, lane, lane))
+                rows.append((GEMM, t + T, t + T + G, G, lane, lane))
+                t += T + G
+    con.executemany("insert into kernels values (?,?,?,?,?,?,124,0,131072)", rows)
+    con.commit()
+    con.close()
+    window = nres * (T + G) / 1e6
+    line = {"steps": 3, "warmup": 1, "roofline": {"bneck_union_ms_per_step": window + 0.040, "frac": 0.59,
+                                                  "bneck_executed_gflop_per_step": 231.93}}
+    (tmp_path / "line.json").write_text(json.dumps(line))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), "--bneck-timeline",
+                          str(tmp_path / "line.json"), str(db)], capture_output=True, text=True, check=True).stdout
+    assert "wino4_gemm_kernel<2, 4, 2, 4, 2, 8, 0>" in out and "stream_id" in out and "5 forward calls" in out
+    avg = [l for l in out.splitlines() if l.startswith("average over the timed calls")][0]
+    assert f"union {window + 0.040:.4f} ms" in avg and f"sum of windows {2 * window:.4f} ms" in avg
+    assert "trace / events = 1.0000" in out
+    # the plain summary mode still works on the same database
+    out2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), str(db)], capture_output=True, text=True,
+                          check=True).stdout
+    assert "wino4_gemm_kernel<2, 4, 2, 4, 2, 8, 0>" in out2 and "total_ms" in out2

@@ -6,9 +6,14 @@ Fixture tests/golden/tiny64_train_backward.npz (oracle/make_golden.py::train_bac
 (`grad64`), and their distance (`floor`): the algorithm's own fp32 noise floor, up to 9e-3 of a tensor's largest gradient on
 this randomly-initialised network (batch-statistics BatchNorm backward cancels heavily), median 9e-4.
 
-CPU: the oracle's training branch differentiated by autograd against the fixture.
-GPU (-m gpu): eamm_amd.OcclusionAwareGenerator.train() with requires_grad_(True) -- the composition of differentiable HIP
-operators in eamm_amd/train_graph.py -- against the double gradients, each tensor within a few of ITS OWN fp32 floors."""
+Round 4 adds ``full256_train_backward.npz`` (the shipped configuration, 2 pairs at 256x256: the size at which the Winograd weight
+gradient, the thin 7x7 kernels on 64 channels and the split-group F(4x4) run inside the graph; strided samples) and
+``tiny64_eval_backward.npz`` (the reference generator differentiated in .eval(): running statistics).
+
+CPU: the oracle's training / evaluation branch differentiated by autograd against the fixtures.
+GPU (-m gpu): eamm_amd.OcclusionAwareGenerator -- the composition of differentiable HIP operators in eamm_amd/train_graph.py --
+against the double gradients, each tensor within a few of ITS OWN fp32 floors; ``Adam(gen.parameters())`` straight after
+construction as train.py:136 builds it."""
 import os
 
 import numpy as np
@@ -28,40 +33,70 @@ DEV = "cuda:0"
 FP32_MIN_REL = 5e-3
 
 
-def fixture():
-    return np.load(os.path.join(GOLDEN, "tiny64_train_backward.npz"))
+def fixture(name="tiny64_train_backward"):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
-def inputs(n):
-    return synthetic_source(64, seed=1, batch=n), synthetic_keypoints(n, 10, seed=0), synthetic_keypoints(n, 10, seed=2)
+def inputs(n, size=64):
+    return synthetic_source(size, seed=1, batch=n), synthetic_keypoints(n, 10, seed=0), synthetic_keypoints(n, 10, seed=2)
+
+
+def loss_weights(z, shapes=None):
+    """The fixed random tensors that weigh every output in the fixture's scalar loss: stored in full for the 64x64 fixtures,
+    regenerated from the recorded seed for the 256x256 one (torch.randn on the CPU generator, KEYS order, as make_golden.py)."""
+    if "w/prediction" in z:
+        return {k: torch.from_numpy(z["w/" + k]) for k in KEYS}
+    g = torch.Generator().manual_seed(int(z["weights_seed"]))
+    return {k: torch.randn(shapes[k], generator=g) for k in KEYS}
+
+
+# Tensors in front of which (towards the loss) no ReLU sits for the final layer, and the inputs whose gradient is a sum over
+# the whole frame (one flipped ReLU pixel is diluted in them): bar = 4 x the tensor's OWN fp32-vs-fp64 distance, no 5e-3 floor.
+def _tight(name):
+    return name.startswith(("kp_source/", "kp_driving/", "param/final.")) or name == "source_image"
+
+
+TIGHT_MIN_REL = 2e-5      # (the operator-level bar of tests/test_gpu_backward.py: two fp32 summation orders differ by this much)
 
 
 def sampled(t, step):
     return t.reshape(-1)[::step] if step > 1 else t
 
 
-def compare(z, grads, floors_allowed, min_rel):
+def compare(z, grads, floors_allowed, min_rel, report=False):
     """grads: {fixture name: tensor}.  Returns the worst ratio error / bar over all tensors (and asserts every one)."""
     names = [str(s) for s in z["names"]]
     assert sorted(grads) == sorted(names)
     gmax = max(float(z["scale/" + k]) for k in names)
     worst = (0.0, None)
+    rows = []
     for k in names:
         want = torch.from_numpy(z["grad64/" + k]).double().reshape(-1)
         got = sampled(grads[k].detach().cpu().double(), int(z["step/" + k])).reshape(-1)
         scale = gmax if bool(z["zero/" + k]) else float(z["scale/" + k])
-        bar = max(floors_allowed * float(z["floor/" + k]), min_rel) * scale
+        floor_k = float(z["floor/" + k])
+        rel_bar = max(floors_allowed * floor_k, min(min_rel, TIGHT_MIN_REL) if _tight(k) else min_rel)
+        bar = rel_bar * scale
         diff = (got - want).abs()
         # A few elements may sit far outside the rounding floor: an activation within an ulp of zero takes the other branch of
         # its ReLU in a run that rounds differently, and that one pixel's whole upstream gradient enters (or leaves) every sum
         # it feeds -- a weight gradient's Cin x taps entries of one output channel at once.  (Seen: replacing a batched 2x2
         # matmul by its element-wise form moved 8 sampled entries of up_blocks.1.conv.weight by up to 0.8 % of the tensor's
-        # largest gradient, everything else by ~1e-6.)  So: 95 % of a tensor's elements within the bar, none beyond 20 bars.
-        err = float(torch.quantile(diff, 0.95)) if diff.numel() >= 40 else float(diff.max())
-        assert err <= bar, (k, err, bar, float(z["floor/" + k]))
-        assert float(diff.max()) <= 20 * bar, (k, float(diff.max()), bar, float(z["floor/" + k]))
+        # largest gradient, everything else by ~1e-6.)  So (ADVICE r03: not "95 % within the bar" -- a systematic halo error of
+        # a weight-gradient kernel could hide in the other 5 %): at most 0.5 % of a tensor's sampled elements (and never more
+        # than 2 of a small one) beyond the bar, none beyond 20 bars.
+        allowed = max(2, diff.numel() // 200) if diff.numel() >= 40 else 0
+        beyond = int((diff > bar).sum())
+        err = float(torch.quantile(diff, 1.0 - allowed / diff.numel())) if allowed else float(diff.max())
+        rows.append((err / bar, k, err / scale, floor_k, beyond, diff.numel()))
+        assert beyond <= allowed, (k, beyond, allowed, err, bar, floor_k)
+        assert float(diff.max()) <= 20 * bar, (k, float(diff.max()), bar, floor_k)
         if err / bar > worst[0]:
             worst = (err / bar, k)
+    if report:   # per-tensor error against its own floor (VERDICT r03 item 3)
+        rows.sort(reverse=True)
+        for ratio, k, rel, fl, beyond, numel in rows[:12]:
+            print(f"  {k:58s} err/scale {rel:.2e}  own floor {fl:.2e}  err/bar {ratio:.2f}  beyond bar {beyond}/{numel}")
     return worst
 
 
@@ -87,6 +122,29 @@ def test_oracle_autograd_matches_reference_gradients():
         compare(z, grads, floors, min_rel)
 
 
+def test_oracle_autograd_matches_reference_gradients_in_eval_mode():
+    """The reference module is differentiable in .eval() (running statistics): the oracle's evaluation forward, differentiated
+    by autograd in double, against the reference's gradients (fixture tiny64_eval_backward)."""
+    z = fixture("tiny64_eval_backward")
+    cfg, n = tiny_config(), int(z["n"])
+    sd = synthetic_state_dict(cfg, seed=int(z["weight_seed"]))
+    src, kp_s, kp_d = inputs(n)
+    leaf = lambda k, v: v.is_floating_point() and "running" not in k and "down.weight" not in k
+    sdd = {k: (v.double().requires_grad_() if leaf(k, v) else v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    s = src.double().requires_grad_()
+    ks = {k: v.double().requires_grad_() for k, v in kp_s.items()}
+    kd = {k: v.double().requires_grad_() for k, v in kp_d.items()}
+    out = orc.generator_forward(sdd, cfg, s, kd, ks)
+    loss = sum((out[k] * torch.from_numpy(z["w/" + k]).double()).sum() for k in KEYS)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(z["loss64"])) <= 1e-9 * abs(float(z["loss64"]))
+    grads = {"source_image": s.grad}
+    grads.update({"kp_source/" + k: v.grad for k, v in ks.items()})
+    grads.update({"kp_driving/" + k: v.grad for k, v in kd.items()})
+    grads.update({"param/" + k: v.grad for k, v in sdd.items() if v.requires_grad})
+    compare(z, grads, 0.0, 1e-6)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def _make(cfg, seed):
     from eamm_amd import OcclusionAwareGenerator
@@ -95,13 +153,14 @@ def _make(cfg, seed):
     return gen.to(DEV)
 
 
-def _run_graph(gen, z, n):
-    src, kp_s, kp_d = inputs(n)
+def _run_graph(gen, z, n, size=64):
+    src, kp_s, kp_d = inputs(n, size)
     s = src.to(DEV).requires_grad_()
     ks = {k: v.to(DEV).requires_grad_() for k, v in kp_s.items()}
     kd = {k: v.to(DEV).requires_grad_() for k, v in kp_d.items()}
     out = gen(s, kp_driving=kd, kp_source=ks)
-    loss = sum((out[k] * torch.from_numpy(z["w/" + k]).to(DEV)).sum() for k in KEYS)
+    w = loss_weights(z, {k: out[k].shape for k in KEYS})
+    loss = sum((out[k] * w[k].to(DEV)).sum() for k in KEYS)
     loss.backward()
     torch.cuda.synchronize()
     grads = {"source_image": s.grad}
@@ -115,8 +174,7 @@ def _run_graph(gen, z, n):
 def test_generator_backward_matches_reference_gradients():
     z = fixture()
     n = int(z["n"])
-    gen = _make(tiny_config(), int(z["weight_seed"])).train()
-    gen.requires_grad_(True)                                   # fine-tuning opts in (inference is the default use)
+    gen = _make(tiny_config(), int(z["weight_seed"])).train()  # parameters require grad by default, as the reference's
     before = {k: v.clone() for k, v in gen.state_dict().items() if "running_var" in k}
     out, loss, grads = _run_graph(gen, z, n)
     for k in KEYS:                                             # the forward of the graph path is the reference's
@@ -124,11 +182,119 @@ def test_generator_backward_matches_reference_gradients():
         assert err <= (1e-4 if k == "deformed" else 2e-5), (k, err)
     assert abs(float(loss.detach()) - float(z["loss64"])) <= 5e-4 * abs(float(z["loss64"]))
     assert all(g is not None for g in grads.values())
-    worst = compare(z, grads, floors_allowed=4.0, min_rel=FP32_MIN_REL)
+    worst = compare(z, grads, floors_allowed=4.0, min_rel=FP32_MIN_REL, report=True)
     print(f"generator backward: worst error / bar = {worst[0]:.2f} at {worst[1]}")
     # the running statistics moved, as in every training-mode forward
     after = gen.state_dict()
     assert max(float((after[k] - v).abs().max()) for k, v in before.items()) > 1e-3
+
+
+@pytest.mark.gpu
+def test_generator_backward_matches_reference_gradients_at_256():
+    """the gradients at the size the path runs at -- the shipped configuration, 2 pairs at 256x256 (Winograd
+    weight gradient on >= 512 tiles, thin 7x7 kernels on 64 channels, split-group F(4x4) inside the graph) -- against the
+    REFERENCE's autograd in double (fixture: strided samples of all 71 gradient tensors + each tensor's own fp32 floor)."""
+    from eamm_amd import hot_path_config
+    z = fixture("full256_train_backward")
+    n, size = int(z["n"]), int(z["size"])
+    gen = _make(hot_path_config(), int(z["weight_seed"])).train()
+    out, loss, grads = _run_graph(gen, z, n, size)
+    for k in KEYS:   # forward of the graph path against the reference's (strided samples; bars of tests/test_train_mode.py at 256)
+        got = out[k].detach().cpu().reshape(-1)[::int(z["ostep/" + k])]
+        err = float((got - torch.from_numpy(z["out64/" + k])).abs().max())
+        ref_floor = float((torch.from_numpy(z["out/" + k]) - torch.from_numpy(z["out64/" + k])).abs().max())
+        print(f"256 train graph forward {k:16s} max|hip - ref64| = {err:.2e} (reference's own fp32 run: {ref_floor:.2e})")
+        assert err <= {"prediction": 4e-4, "deformed": 1e-3, "sparse_deformed": 5e-4}.get(k, 1e-4), (k, err)
+    assert abs(float(loss.detach()) - float(z["loss64"])) <= 5e-4 * abs(float(z["loss64"]))
+    assert all(g is not None for g in grads.values())
+    worst = compare(z, grads, floors_allowed=4.0, min_rel=FP32_MIN_REL, report=True)
+    print(f"generator backward at 256x256: worst error / bar = {worst[0]:.2f} at {worst[1]}")
+
+
+@pytest.mark.gpu
+def test_eval_mode_backward_matches_reference_gradients_at_256():
+    """The SHARP gradient check at the size the path runs at: the shipped configuration, 2 pairs at 256x256, in .eval() -- running
+    statistics, so the batch statistics' cancellation (which puts the reference's own fp32 run 1-4 % away from its double run
+    in .train() at two pairs) is absent and the decoder / bottleneck tensors' own floors are 1e-6 ... 1e-3: the Winograd
+    weight-gradient form, the thin 7x7 kernels on 64 channels and the F(4x4) data gradient inside the real graph, against
+    the REFERENCE's autograd in double."""
+    from eamm_amd import hot_path_config
+    z = fixture("full256_eval_backward")
+    n, size = int(z["n"]), int(z["size"])
+    gen = _make(hot_path_config(), int(z["weight_seed"])).eval()
+    with pytest.warns(UserWarning, match="autograd graph in .eval"):
+        out, loss, grads = _run_graph(gen, z, n, size)
+    for k in KEYS:
+        got = out[k].detach().cpu().reshape(-1)[::int(z["ostep/" + k])]
+        err = float((got - torch.from_numpy(z["out64/" + k])).abs().max())
+        print(f"256 eval graph forward {k:16s} max|hip - ref64| = {err:.2e}")
+        assert err <= {"prediction": 1e-4, "deformed": 5e-4, "sparse_deformed": 5e-4}.get(k, 1e-5), (k, err)
+    assert abs(float(loss.detach()) - float(z["loss64"])) <= 2e-4 * abs(float(z["loss64"]))
+    worst = compare(z, grads, floors_allowed=4.0, min_rel=FP32_MIN_REL, report=True)
+    print(f"eval-mode backward at 256x256: worst error / bar = {worst[0]:.2f} at {worst[1]}")
+
+
+@pytest.mark.gpu
+def test_adam_straight_after_construction_trains_every_parameter():
+    """VERDICT r03 item 9(i) / reference train.py:136: ``torch.optim.Adam(generator.parameters())`` built straight after
+    construction + load_state_dict, one ``loss.backward()`` + ``step()``: every parameter has a gradient and moves -- except
+    the convolution biases in front of a batch-statistics BatchNorm, whose gradient is mathematically zero (the mean is
+    subtracted again; the reference holds rounding noise there, this library returns exact zeros)."""
+    z = fixture()
+    n = int(z["n"])
+    gen = _make(tiny_config(), int(z["weight_seed"])).train()
+    opt = torch.optim.Adam(gen.parameters(), lr=1e-3)
+    assert sum(len(g["params"]) for g in opt.param_groups) == len(list(gen.parameters()))
+    before = {k: p.detach().clone() for k, p in gen.named_parameters()}
+    src, kp_s, kp_d = inputs(n)
+    cu = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    out = gen(src.to(DEV), kp_driving=cu(kp_d), kp_source=cu(kp_s))
+    assert out["prediction"].requires_grad and out["prediction"].grad_fn is not None
+    (out["prediction"] - 0.5).abs().mean().backward()
+    opt.step()
+    zero_by_construction = {str(k)[len("param/"):] for k in z["names"] if bool(z["zero/" + str(k)])}
+    moved, still = [], []
+    for k, p in gen.named_parameters():
+        assert p.grad is not None, k
+        (moved if float((p.detach() - before[k]).abs().max()) > 0 else still).append(k)
+    # outputs other than 'prediction' are not in this loss: the occlusion / mask heads still get gradients through the warp
+    assert set(still) <= zero_by_construction, sorted(set(still) - zero_by_construction)
+    assert len(moved) >= len(before) - len(zero_by_construction)
+
+
+@pytest.mark.gpu
+def test_eval_mode_forward_is_differentiable_like_the_reference():
+    """.eval() with gradients enabled is differentiable (running statistics in every BatchNorm), never
+    a silently detached tensor.  Values equal the folded inference engine's; gradients equal the REFERENCE's autograd in
+    evaluation mode (fixture tiny64_eval_backward: every parameter, the key points, the source)."""
+    z = fixture("tiny64_eval_backward")
+    n = int(z["n"])
+    gen = _make(tiny_config(), int(z["weight_seed"])).eval()
+    stats = {k: v.clone() for k, v in gen.state_dict().items() if "running" in k}
+    with pytest.warns(UserWarning, match="autograd graph in .eval"):
+        out, loss, grads = _run_graph(gen, z, n)
+    assert all(out[k].requires_grad for k in KEYS)
+    assert all(torch.equal(v, gen.state_dict()[k]) for k, v in stats.items())       # evaluation mode: statistics untouched
+    src, kp_s, kp_d = inputs(n)
+    cu = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    with torch.no_grad():
+        fast = gen(src.to(DEV), kp_driving=cu(kp_d), kp_source=cu(kp_s))             # the folded engine
+    assert not fast["prediction"].requires_grad
+    for k in KEYS:
+        ref = float((out[k].detach().cpu() - torch.from_numpy(z["out/" + k])).abs().max())
+        eng = float((out[k].detach() - fast[k]).abs().max())
+        print(f"eval graph {k:16s} vs reference {ref:.2e}   vs engine {eng:.2e}")
+        assert ref <= (1e-4 if k == "deformed" else 2e-5) and eng <= (2e-4 if k == "deformed" else 4e-5), (k, ref, eng)
+    assert abs(float(loss.detach()) - float(z["loss64"])) <= 5e-4 * abs(float(z["loss64"]))
+    worst = compare(z, grads, floors_allowed=4.0, min_rel=FP32_MIN_REL, report=True)
+    print(f"eval-mode backward: worst error / bar = {worst[0]:.2f} at {worst[1]}")
+    # a frozen generator in .eval() with an input that requires grad: the flow's backward alone, still a graph
+    gen.requires_grad_(False)
+    kd = {k: v.to(DEV).requires_grad_() for k, v in kp_d.items()}
+    o2 = gen(src.to(DEV), kp_driving=kd, kp_source=cu(kp_s))
+    assert o2["prediction"].requires_grad
+    o2["prediction"].sum().backward()
+    assert kd["value"].grad is not None and float(kd["value"].grad.abs().max()) > 0
 
 
 @pytest.mark.gpu
@@ -143,7 +309,6 @@ def test_graph_and_engine_training_forwards_agree():
     with torch.no_grad():
         o1 = g1(src.to(DEV), kp_driving=cu(kp_d), kp_source=cu(kp_s))
     g2 = _make(tiny_config(), 1234).train()
-    g2.requires_grad_(True)
     o2 = g2(src.to(DEV), kp_driving=cu(kp_d), kp_source=cu(kp_s))
     assert o2["prediction"].requires_grad and not o1["prediction"].requires_grad
     for k in KEYS:
@@ -160,7 +325,7 @@ def test_only_the_key_points_need_a_gradient():
     # gradients, driving key points with -- the flow's backward alone
     z = fixture()
     n = int(z["n"])
-    gen = _make(tiny_config(), 1234).train()
+    gen = _make(tiny_config(), 1234).train().requires_grad_(False)
     src, kp_s, kp_d = inputs(n)
     kd = {k: v.to(DEV).requires_grad_() for k, v in kp_d.items()}
     out = gen(src.to(DEV), kp_driving=kd, kp_source={k: v.to(DEV) for k, v in kp_s.items()})
@@ -214,7 +379,6 @@ def _ddp_worker(rank, world, port, tmp):
     sl = slice(0, split) if rank == 0 else slice(split, n)
     src, kp_s, kp_d = inputs(n)
     gen = _make(tiny_config(), int(z["weight_seed"])).train()      # replicas because world > 1 (sync_batchnorm None)
-    gen.requires_grad_(True)
     ks = {k: v[sl].to(DEV).requires_grad_() for k, v in kp_s.items()}
     kd = {k: v[sl].to(DEV).requires_grad_() for k, v in kp_d.items()}
     out = gen(src[sl].to(DEV), kp_driving=kd, kp_source=ks)
@@ -282,7 +446,6 @@ def test_generator_backward_variants_against_oracle_autograd(variant):
     kp_s = synthetic_keypoints(n, 10, seed=4, jacobian=variant != "no_jacobian")
     kp_d = synthetic_keypoints(n, 10, seed=5, jacobian=variant != "no_jacobian")
     gen = _make(cfg, 77).train()
-    gen.requires_grad_(True)
     ks = {k: v.to(DEV).requires_grad_() for k, v in kp_s.items()}
     kd = {k: v.to(DEV).requires_grad_() for k, v in kp_d.items()}
     out = gen(src.to(DEV), kp_driving=kd, kp_source=ks)

@@ -60,17 +60,49 @@ def test_differentiable_operators_have_no_cpu_fallback_and_validate_shapes():
             call()
 
 
-def test_generator_picks_the_graph_path_only_when_something_needs_a_gradient():
+def test_generator_picks_the_graph_path_exactly_when_the_reference_would_build_a_graph():
+    """Reference semantics (modules/generator.py:59-97 are plain differentiable torch ops; train.py:136 builds
+    ``Adam(generator.parameters())`` straight after construction): parameters require grad by default, so any forward with
+    gradients enabled is differentiable -- in .train() AND in .eval(); torch.no_grad() (demo.py:195) is the graph-free engine."""
     from eamm_amd import OcclusionAwareGenerator, tiny_config
-    gen = OcclusionAwareGenerator(**tiny_config()).train()
+    gen = OcclusionAwareGenerator(**tiny_config())
+    assert all(p.requires_grad for p in gen.parameters())            # PyTorch's default, as the reference module
+    assert len(torch.optim.Adam(gen.parameters()).param_groups[0]["params"]) == len(list(gen.parameters()))
     src = torch.zeros(2, 3, 64, 64)
     kp = {"value": torch.zeros(2, 10, 2), "jacobian": torch.eye(2).expand(2, 10, 2, 2).clone()}
-    assert not gen._wants_graph(src, kp, kp)                         # inference-style module: parameters frozen by default
     kpg = {k: v.clone().requires_grad_() for k, v in kp.items()}
+    for mode in (gen.train(), gen.eval()):
+        assert mode._wants_graph(src, kp, kp)
+        with torch.no_grad():
+            assert not mode._wants_graph(src, kpg, kp)
+    gen.requires_grad_(False)                                        # a frozen generator: only an input can ask for a graph
+    assert not gen._wants_graph(src, kp, kp)
     assert gen._wants_graph(src, kpg, kp)                            # the audio-to-key-point stage trains through the generator
-    with torch.no_grad():
-        assert not gen._wants_graph(src, kpg, kp)
+    assert gen._wants_graph(src.clone().requires_grad_(), kp, kp)
     gen.requires_grad_(True)
-    assert gen._wants_graph(src, kp, kp)                             # fine-tuning opts in
     with pytest.raises(RuntimeError, match="ROCm GPU"):             # ... and still has no CPU fallback
         gen(src, kp_driving=kp, kp_source=kp)
+
+
+def test_tensor_slots_follow_structural_changes():
+    """the cached slot list must see replaced sub-modules, late-assigned tensors and copies."""
+    import copy
+    from eamm_amd import OcclusionAwareGenerator, tiny_config
+    gen = OcclusionAwareGenerator(**tiny_config())
+    v0 = gen._weights_version()
+    assert gen._weights_version() == v0
+    gen.bottleneck[0] = type(gen.bottleneck[0])(128)                 # Sequential item assignment
+    v1 = gen._weights_version()
+    assert v1 != v0
+    gen.first = type(gen.first)(3, 32, 7)                            # attribute assignment of a sub-module
+    v2 = gen._weights_version()
+    assert v2 != v1
+    gen.final.bias = None                                            # a slot that holds None ...
+    v3 = gen._weights_version()
+    assert len(v3) == len(v2) - 2
+    gen.final.bias = torch.nn.Parameter(torch.zeros(3))              # ... and is assigned later
+    assert len(gen._weights_version()) == len(v2)
+    twin = copy.deepcopy(gen)
+    ids = set(twin._weights_version()[:len(v2) // 2])
+    assert ids <= {id(t) for t in list(twin.parameters()) + list(twin.buffers())}
+    assert not ids & set(gen._weights_version()[:len(v2) // 2])      # the copy reads ITS tensors, not the original's

@@ -26,6 +26,15 @@ TOL_STAT = 1e-5          # running statistics (values are O(0.1..1)); the refere
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _called_as_demo_py_calls_it():
+    """Inference tests run under torch.no_grad(), as the reference's caller does (demo.py:195): with gradients enabled the
+    module -- like the reference's -- would build an autograd graph through the differentiable operators instead."""
+    with torch.no_grad():
+        yield
+
+
+
 def fixture():
     z = np.load(os.path.join(GOLDEN, "tiny64_train.npz"))
     return z, [str(s) for s in z["norm_names"]], int(z["n"]), int(z["split"])
@@ -143,6 +152,7 @@ def _worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    torch.set_grad_enabled(False)     # the graph-free resumable pass (the differentiable one: test_train_backward.py)
     z, names, n, split = fixture()
     sl = slice(0, split) if rank == 0 else slice(split, n)
     src, kp_s, kp_d = inputs(n)

@@ -5,7 +5,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 SIZE=${1:-256}; BATCH=${2:-16}; TAG=${3:-${SIZE}_b${BATCH}}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
@@ -14,6 +14,8 @@ BENCH="python bench.py --size $SIZE --batch $BATCH --steps 10 --warmup 3 --cpu-f
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $BENCH > $O/kt_bench.log 2>&1
 python tools/rocpd_summary.py $O/kt/kt_results.db > $O/kernel_trace_stats.txt 2>&1
 grep '^{' $O/kt_bench.log > $O/bench_under_kernel_trace.json
+# the bottleneck stage's union window re-derived from the trace's kernel timestamps (vs bench.py's HIP events, same run)
+python tools/rocpd_summary.py --bneck-timeline $O/bench_under_kernel_trace.json $O/kt/kt_results.db > $O/bneck_timeline.txt 2>&1
 pmc() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o $name -- $BENCH > $O/$name.log 2>&1; python tools/rocpd_summary.py $O/$name/${name}_results.db | grep -v rocclr > $O/pmc_$name.txt; }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE

@@ -1,10 +1,10 @@
 #!/bin/bash
 # One gpurun call: GPU tests, default bench line, 512x512 bench line, module latency, profiles at both BASELINE sizes.
-#   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh <tag>'      (ROUND=r03 by default: output names carry it)
+#   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh <tag>'      (ROUND=r04 by default: output names carry it)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-a}
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 O=$R/gpurun_out/${ROUND}_$TAG
 mkdir -p $O
 cd $R

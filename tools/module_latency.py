@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eamm_amd import OcclusionAwareGenerator, hot_path_config
 from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict
 
+torch.set_grad_enabled(False)     # demo.py:195 runs the frame loop under torch.no_grad()
 cfg = hot_path_config()
 sd = synthetic_state_dict(cfg)
 for cache in (False, True):

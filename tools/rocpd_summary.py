@@ -1,9 +1,21 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 (rocpd SQLite) results as text: per-kernel duration statistics and, when the run
-collected PMC counters, per-kernel counter averages.  Usage: tools/rocpd_summary.py results.db [...]"""
+collected PMC counters, per-kernel counter averages.  Usage: tools/rocpd_summary.py results.db [...]
+
+    tools/rocpd_summary.py --bneck-timeline bench_line.json results.db
+
+prints instead the TIMELINE of the bottleneck stage from the kernel trace of a bench.py run: for every forward call the
+[start, end] interval of each chain's bottleneck stage (first Winograd input transform in front of the chain's first
+bottleneck GEMM ... end of its last bottleneck GEMM, per HIP stream / HSA queue), the union of the chains' intervals, and
+the average over the calls of bench.py's timed region -- the quantity `roofline.frac` divides by (bench.py measures it with
+HIP events on every chain's stream; VERDICT r03 item 1 asks that it reproduce from the trace).  `bench_line.json` is the JSON
+line the SAME run printed (steps, warmup, roofline.bneck_union_ms_per_step, roofline.bneck_executed_gflop_per_step)."""
+import json
 import re
 import sqlite3
 import sys
+
+FP32_MFMA_PEAK_TFLOPS = 157.3
 
 
 def short(name):
@@ -12,7 +24,104 @@ def short(name):
     return name if not m else f"{m.group(1)}<{m.group(2)}>"
 
 
+def union_ms(intervals):
+    """total length of the union of [start, end] intervals (ns) in ms"""
+    total, cur0, cur1 = 0, None, None
+    for a, b in sorted(intervals):
+        if cur1 is None or a > cur1:
+            if cur1 is not None:
+                total += cur1 - cur0
+            cur0, cur1 = a, b
+        else:
+            cur1 = max(cur1, b)
+    if cur1 is not None:
+        total += cur1 - cur0
+    return total / 1e6
+
+
+def bottleneck_timeline(con, nres=12):
+    """-> list over forward calls of {"chains": [(start, end), ...], "gemm": [(start, end), ...]} (ns), in time order.
+    The bottleneck GEMM is the wino4_gemm_kernel instantiation with the most dispatches (2 * num_bottleneck_blocks = `nres`
+    per chain and call); chains are told apart by the stream / queue column that takes more than one value."""
+    cols = [r[1] for r in con.execute("pragma table_info('kernels')")]
+    if not cols:   # a view: ask one row
+        cols = [d[0] for d in con.execute("select * from kernels limit 1").description]
+    t0c, t1c = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
+    lane_cols = [c for c in ("stream_id", "queue_id", "queue") if c in cols]
+    sel = ", ".join(["name", t0c, t1c] + lane_cols)
+    rows = con.execute(f"select {sel} from kernels order by {t0c}").fetchall()
+    gemm_names = {}
+    for r in rows:
+        if "wino4_gemm_kernel" in r[0]:
+            gemm_names[r[0]] = gemm_names.get(r[0], 0) + 1
+    if not gemm_names:
+        raise SystemExit("no wino4_gemm_kernel dispatch in the trace (the bottleneck did not run in F(4x4) form)")
+    bneck = max(gemm_names, key=gemm_names.get)
+    lane_idx = None
+    for i, c in enumerate(lane_cols):
+        if len({r[3 + i] for r in rows if r[0] == bneck}) > 1:
+            lane_idx = 3 + i
+            break
+    lanes = {}
+    for k, r in enumerate(rows):
+        lanes.setdefault(r[lane_idx] if lane_idx is not None else 0, []).append(k)
+    per_lane = []   # per lane: list of (window_start, window_end, [gemm intervals]) per call
+    for lane, idxs in sorted(lanes.items(), key=lambda kv: kv[1][0]):
+        g = [k for k in idxs if rows[k][0] == bneck]
+        if not g:
+            continue
+        pos = {k: p for p, k in enumerate(idxs)}
+        calls = []
+        for c0 in range(0, len(g) - nres + 1, nres):
+            grp = g[c0:c0 + nres]
+            first = grp[0]
+            # the stage starts with the input transform dispatched on this lane right in front of the first GEMM
+            p = pos[first]
+            start = rows[first][1]
+            if p > 0 and "wino4_input_transform_kernel" in rows[idxs[p - 1]][0]:
+                start = rows[idxs[p - 1]][1]
+            calls.append((start, rows[grp[-1]][2], [(rows[k][1], rows[k][2]) for k in grp]))
+        per_lane.append(calls)
+    ncalls = min(len(c) for c in per_lane)
+    out = []
+    for i in range(ncalls):
+        out.append({"chains": [c[i][:2] for c in per_lane], "gemm": [iv for c in per_lane for iv in c[i][2]]})
+    return out, short(bneck), ("one lane" if lane_idx is None else lane_cols[lane_idx - 3])
+
+
+def timeline_report(bench_json, db):
+    line = json.load(open(bench_json))
+    roof = line["roofline"]
+    con = sqlite3.connect(db)
+    calls, kernel, lane = bottleneck_timeline(con)
+    steps, warm = int(line["steps"]), int(line["warmup"])
+    timed = calls[warm:warm + steps] if len(calls) >= warm + steps else calls
+    print(f"== bottleneck-stage timeline from {db}")
+    print(f"kernel: {kernel}; chains told apart by `{lane}`; {len(calls)} forward calls in the trace, "
+          f"calls {warm}..{warm + len(timed) - 1} = bench.py's timed region ({steps} steps after {warm} warm-up)")
+    print(f"{'call':>4s} {'chain windows (ms)':40s} {'union_ms':>9s} {'sum_ms':>9s} {'gemm_union_ms':>13s} {'chain offsets (us)':>20s}")
+    un, sm, gu = [], [], []
+    for i, c in enumerate(timed):
+        w = [(b - a) / 1e6 for a, b in c["chains"]]
+        u, g = union_ms(c["chains"]), union_ms(c["gemm"])
+        un.append(u); sm.append(sum(w)); gu.append(g)
+        offs = " ".join(f"{(a - c['chains'][0][0]) / 1e3:+.0f}" for a, _ in c["chains"])
+        print(f"{warm + i:4d} {' '.join(f'{x:.4f}' for x in w):40s} {u:9.4f} {sum(w):9.4f} {g:13.4f} {offs:>20s}")
+    n = max(1, len(timed))
+    u_avg, s_avg, g_avg = sum(un) / n, sum(sm) / n, sum(gu) / n
+    gf = roof["bneck_executed_gflop_per_step"]
+    ev = roof["bneck_union_ms_per_step"]
+    print(f"average over the timed calls: union {u_avg:.4f} ms, sum of windows {s_avg:.4f} ms, union of the GEMM kernels alone {g_avg:.4f} ms")
+    print(f"bench.py (HIP events, same run): bneck_union_ms_per_step {ev:.4f} -> trace / events = {u_avg / ev:.4f}")
+    print(f"roofline.frac from the trace: {gf:.2f} GFLOP / {u_avg:.4f} ms / {FP32_MFMA_PEAK_TFLOPS} = {gf / u_avg / FP32_MFMA_PEAK_TFLOPS:.4f}"
+          f"   (bench.py line: {roof['frac']:.4f})")
+    return u_avg, ev
+
+
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--bneck-timeline":
+        timeline_report(sys.argv[2], sys.argv[3])
+        return
     for path in sys.argv[1:]:
         con = sqlite3.connect(path)
         print(f"== {path}")
