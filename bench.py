@@ -140,7 +140,7 @@ def train_step_leg(cfg, sd, size, pairs, steps=4):
     target = train_step_target(pairs, size).to(dev)
     fwd, bwd = [], []
     for it in range(steps + 1):
-        for p in gen.parameters():
+        for p in list(gen.parameters()) + list(kp_d.values()):
             p.grad = None
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -180,6 +180,10 @@ def main():
     ap.add_argument("--clip-frames", type=int, default=2048, help="frames of the configs[3] clip leg (0 = skip)")
     ap.add_argument("--clip-gather", action="store_true", help="clip leg: gather uint8 frames on rank 0 inside the timed region")
     ap.add_argument("--train-pairs", type=int, default=8, help="pairs per step of the training-step leg (N = 1 only; 0 = skip)")
+    ap.add_argument("--graph", action="store_true",
+                    help="after the contract's timed region: capture one step into a HIP graph and time `--steps` replays (extra key "
+                         "`graph`).  Used by tools/gpu_profile.sh: under rocprofv3 the host's per-launch cost delays the second "
+                         "chain's launches by ~1.8 ms, a replayed graph keeps the two chains' kernels together as an unprofiled run does")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 16 if args.size <= 256 else 8
@@ -298,6 +302,28 @@ def main():
     eng.check_numeric()
     # the timed launches must have produced frames (parity itself is tests/' job: this only refuses to print a rate for
     # a build whose kernels write garbage): sigmoid-ranged, finite, and not constant
+    graph_leg = None
+    if args.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            g_out = step()["prediction"]
+        g.replay()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g.replay()
+        fence()
+        dt_g = max_over_ranks(time.perf_counter() - t0)
+        assert bool(torch.isfinite(g_out).all()) and float(g_out.std()) > 0.02
+        graph_leg = {"steps": args.steps, "ms_per_step": round(dt_g / args.steps * 1e3, 4),
+                     "value": round(args.steps * B * world / dt_g, 2), "unit": "frames/s",
+                     "note": "the same step captured once into a HIP graph (both chains' streams) and replayed; not the contract's `value`"}
+        del g, g_out
     chk = step()["prediction"]
     assert bool(torch.isfinite(chk).all()) and 0.0 < float(chk.min()) and float(chk.max()) < 1.0 and float(chk.std()) > 0.02, \
         "bench.py: the forward pass produced non-finite or degenerate frames"
@@ -488,6 +514,8 @@ def main():
         if t_bcast_ms is not None:
             line["source_broadcast_ms"] = round(t_bcast_ms, 3)
         line["clip"] = clip
+        if graph_leg is not None:
+            line["graph"] = graph_leg
         if world == 1 and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, S, args.cpu_frames)
             line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)

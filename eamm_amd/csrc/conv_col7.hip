@@ -122,6 +122,10 @@ __global__ __launch_bounds__(CWAVES * 64) void conv_col7_kernel(const Col7Args p
     const int a_off = idx0 * BK + ((half ^ ((idx0 >> 1) & 7)) << 2);   // + 8*s for K step s via XOR; + tap * CT * BK
     const int b_off = l31 * BK + ((half ^ ((l31 >> 1) & 7)) << 2);
 
+    float bias_r[3] = {0.f, 0.f, 0.f};
+    if constexpr (FUSED) {
+        bias_r[0] = p.bias[0]; bias_r[1] = p.bias[1]; bias_r[2] = p.bias[2];
+    }
     for (int u = 0; u < units; ++u) {
         const int st = u & 1;
         const bool more = u + 1 < units;
@@ -182,24 +186,35 @@ __global__ __launch_bounds__(CWAVES * 64) void conv_col7_kernel(const Col7Args p
                 const float* carry_in = Carry + (tix & 1) * CARRY;          // columns tx0-6 .. tx0-1 (from tile T-1)
                 float* carry_out = Carry + ((tix + 1) & 1) * CARRY;
                 const int ncol = last ? CT + 3 : CT;                          // the row's last tile also finishes its last three columns
-                for (int i = tid; i < 3 * CT * ncol; i += CWAVES * 64) {
-                    const int xl = i % ncol, t2 = i / ncol;
-                    const int row = t2 % CT, co = t2 / CT;
+                // One thread per (row, output column): 16 rows x 32 column slots (16 or 19 used) = the 512 threads, the three
+                // output channels in registers -- no integer division, no divergent tap loop (round 3 ran `i % ncol`, `i / ncol`
+                // per output and a branch per tap: ~5 us of the ~17 us a tile takes; the stage is matrix-pipe time otherwise).
+                // Tap dx of output column xl reads partial column c = xl - 6 + dx of this tile, of the carry (c < 0) or nothing.
+                {
+                    const int xl = tid & 31, row = tid >> 5;
                     const int x = tx0 - 3 + xl, y = ty0 + row;
-                    if (x < 0 || x >= p.W || y >= p.H) continue;
-                    float v = p.bias[co];
+                    float v0 = bias_r[0], v1 = bias_r[1], v2 = bias_r[2];
 #pragma unroll
                     for (int dx = 0; dx < 7; ++dx) {
-                        const int c = xl - 6 + dx;                            // partial column relative to tx0: x + dx - 3 - tx0
-                        float pv = 0.f;
-                        if (c >= 0) {
-                            if (c < CT) pv = scratch[(row * CT + c) * PS + dx * 3 + co];          // (c >= 16: beyond the row's last tile: zero padding)
-                        } else if (tix > 0) {
-                            pv = carry_in[(row * 6 + c + 6) * PS + dx * 3 + co];                   // (tix == 0: left of the image: zero padding)
-                        }
-                        v += pv;
+                        const int c = xl - 6 + dx;
+                        const bool in_tile = (unsigned)c < (unsigned)CT, in_carry = (c < 0) & (tix > 0);
+                        // clamped (always valid) addresses, values selected afterwards: the loads issue back to back
+                        const float* src = in_tile ? scratch + (row * CT + c) * PS + dx * 3
+                                                   : carry_in + (row * 6 + max(c, -6) + 6) * PS + dx * 3;
+                        const float* safe = (in_tile | in_carry) ? src : scratch;
+                        const float p0 = safe[0], p1 = safe[1], p2 = safe[2];
+                        const bool use = in_tile | in_carry;
+                        v0 += use ? p0 : 0.f;
+                        v1 += use ? p1 : 0.f;
+                        v2 += use ? p2 : 0.f;
                     }
-                    p.final_out[(((size_t)b * 3 + co) * p.H + y) * p.W + x] = 1.f / (1.f + __expf(-v));
+                    if (xl < ncol && x >= 0 && x < p.W && y < p.H) {
+                        float* o = p.final_out + ((size_t)b * 3 * p.H + y) * p.W + x;
+                        const size_t plane = (size_t)p.H * p.W;
+                        o[0] = 1.f / (1.f + __expf(-v0));
+                        o[plane] = 1.f / (1.f + __expf(-v1));
+                        o[2 * plane] = 1.f / (1.f + __expf(-v2));
+                    }
                 }
                 for (int i = tid; i < CARRY; i += CWAVES * 64) {                // columns 10..15 -> the next tile's carry
                     const int n = i % PS, t2 = i / PS;

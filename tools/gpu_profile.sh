@@ -11,11 +11,12 @@ O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd $R
 BENCH="python bench.py --size $SIZE --batch $BATCH --steps 10 --warmup 3 --cpu-frames 0 --clip-frames 0 --train-pairs 0"   # the contract line's kernels only
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $BENCH > $O/kt_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $BENCH --graph > $O/kt_bench.log 2>&1
 python tools/rocpd_summary.py $O/kt/kt_results.db > $O/kernel_trace_stats.txt 2>&1
 grep '^{' $O/kt_bench.log > $O/bench_under_kernel_trace.json
 # the bottleneck stage's union window re-derived from the trace's kernel timestamps (vs bench.py's HIP events, same run)
-python tools/rocpd_summary.py --bneck-timeline $O/bench_under_kernel_trace.json $O/kt/kt_results.db > $O/bneck_timeline.txt 2>&1
+$BENCH > $O/bench_unprofiled.log 2>&1; grep '^{' $O/bench_unprofiled.log > $O/bench_unprofiled.json   # the same command without the profiler
+python tools/rocpd_summary.py --bneck-timeline $O/bench_under_kernel_trace.json $O/kt/kt_results.db $O/bench_unprofiled.json > $O/bneck_timeline.txt 2>&1
 pmc() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o $name -- $BENCH > $O/$name.log 2>&1; python tools/rocpd_summary.py $O/$name/${name}_results.db | grep -v rocclr > $O/pmc_$name.txt; }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE

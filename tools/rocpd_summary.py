@@ -2,7 +2,7 @@
 """Summarise rocprofv3 (rocpd SQLite) results as text: per-kernel duration statistics and, when the run
 collected PMC counters, per-kernel counter averages.  Usage: tools/rocpd_summary.py results.db [...]
 
-    tools/rocpd_summary.py --bneck-timeline bench_line.json results.db
+    tools/rocpd_summary.py --bneck-timeline bench_line.json results.db [unprofiled_bench_line.json]
 
 prints instead the TIMELINE of the bottleneck stage from the kernel trace of a bench.py run: for every forward call the
 [start, end] interval of each chain's bottleneck stage (first Winograd input transform in front of the chain's first
@@ -99,6 +99,26 @@ def timeline_report(bench_json, db):
     print(f"== bottleneck-stage timeline from {db}")
     print(f"kernel: {kernel}; chains told apart by `{lane}`; {len(calls)} forward calls in the trace, "
           f"calls {warm}..{warm + len(timed) - 1} = bench.py's timed region ({steps} steps after {warm} warm-up)")
+    if "graph" in line and len(calls) >= warm + steps + int(line["graph"]["steps"]) + 1:
+        # bench.py --graph: the trace ends with [graph warm-up replay, `steps` timed replays, the final check step]
+        gs = int(line["graph"]["steps"])
+        replays = calls[-(gs + 1):-1]
+        print(f"-- graph replays (bench.py --graph: one captured step replayed; no per-launch host cost, so the chains' kernels stay "
+              f"together under the profiler as they do in an unprofiled run): calls {len(calls) - gs - 1}..{len(calls) - 2}")
+        gu = [union_ms(c["chains"]) for c in replays]
+        gsum = [sum((b - a) / 1e6 for a, b in c["chains"]) for c in replays]
+        offs = [max(a for a, _ in c["chains"]) - min(a for a, _ in c["chains"]) for c in replays]
+        gu_avg = sum(gu) / len(gu)
+        gf0 = roof["bneck_executed_gflop_per_step"]
+        print(f"   union {gu_avg:.4f} ms (min {min(gu):.4f}, max {max(gu):.4f}), sum of windows {sum(gsum) / len(gsum):.4f} ms, "
+              f"offset between the chains' stage starts {sum(offs) / len(offs) / 1e3:.0f} us")
+        print(f"   roofline.frac from the replayed trace: {gf0:.2f} GFLOP / {gu_avg:.4f} ms / {FP32_MFMA_PEAK_TFLOPS} = "
+              f"{gf0 / gu_avg / FP32_MFMA_PEAK_TFLOPS:.4f}; graph replay ran {line['graph']['value']} frames/s under the profiler")
+        if len(sys.argv) > 4:   # the unprofiled run's line: the number the trace has to reproduce
+            ref = json.load(open(sys.argv[4]))["roofline"]
+            print(f"   unprofiled bench.py (HIP events): bneck_union_ms_per_step {ref['bneck_union_ms_per_step']:.4f}, frac {ref['frac']:.4f}"
+                  f" -> replayed trace / unprofiled events = {gu_avg / ref['bneck_union_ms_per_step']:.4f}")
+    print("-- eager calls of the timed region (under the profiler the host needs ~1.8 ms to enqueue a chain: the second chain starts late)")
     print(f"{'call':>4s} {'chain windows (ms)':40s} {'union_ms':>9s} {'sum_ms':>9s} {'gemm_union_ms':>13s} {'chain offsets (us)':>20s}")
     un, sm, gu = [], [], []
     for i, c in enumerate(timed):
