@@ -31,16 +31,28 @@ def test_bottleneck_timeline_union(tmp_path):
                 rows.append((TR, t, t + T, T, lane, lane))
                 rows.append((GEMM, t + T, t + T + G, G, lane, lane))
                 t += T + G
+    # bench.py --graph: [graph warm-up replay, 2 timed replays, final eager check step]; replays run on the graph's own streams
+    for call, lanes in ((calls, (7, 8)), (calls + 1, (7, 8)), (calls + 2, (7, 8)), (calls + 3, (1, 2))):
+        base = call * 5_000_000
+        for lane, off in zip(lanes, (0, 5_000)):
+            t = base + off
+            for _ in range(nres):
+                rows.append((TR, t, t + T, T, lane, lane))
+                rows.append((GEMM, t + T, t + T + G, G, lane, lane))
+                t += T + G
     con.executemany("insert into kernels values (?,?,?,?,?,?,124,0,131072)", rows)
     con.commit()
     con.close()
     window = nres * (T + G) / 1e6
-    line = {"steps": 3, "warmup": 1, "roofline": {"bneck_union_ms_per_step": window + 0.040, "frac": 0.59,
-                                                  "bneck_executed_gflop_per_step": 231.93}}
+    line = {"steps": 3, "warmup": 1, "roofline": {"bneck_union_ms_per_step": window + 0.040, "frac": 0.59, "pass_chains": 2,
+                                                  "bneck_executed_gflop_per_step": 231.93},
+            "graph": {"steps": 2, "value": 3800.0}}
     (tmp_path / "line.json").write_text(json.dumps(line))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), "--bneck-timeline",
                           str(tmp_path / "line.json"), str(db)], capture_output=True, text=True, check=True).stdout
-    assert "wino4_gemm_kernel<2, 4, 2, 4, 2, 8, 0>" in out and "stream_id" in out and "5 forward calls" in out
+    assert "wino4_gemm_kernel<2, 4, 2, 4, 2, 8, 0>" in out and "stream_id" in out and "9 forward calls" in out
+    replay = [l for l in out.splitlines() if l.strip().startswith("union ")][0]
+    assert f"union {window + 0.005:.4f} ms" in replay and "offset between the chains' stage starts 5 us" in replay
     avg = [l for l in out.splitlines() if l.startswith("average over the timed calls")][0]
     assert f"union {window + 0.040:.4f} ms" in avg and f"sum of windows {2 * window:.4f} ms" in avg
     assert "trace / events = 1.0000" in out

@@ -39,10 +39,12 @@ def union_ms(intervals):
     return total / 1e6
 
 
-def bottleneck_timeline(con, nres=12):
+def bottleneck_timeline(con, nres=12, nchains=2):
     """-> list over forward calls of {"chains": [(start, end), ...], "gemm": [(start, end), ...]} (ns), in time order.
-    The bottleneck GEMM is the wino4_gemm_kernel instantiation with the most dispatches (2 * num_bottleneck_blocks = `nres`
-    per chain and call); chains are told apart by the stream / queue column that takes more than one value."""
+    The bottleneck GEMM is the wino4_gemm_kernel instantiation with the most dispatches; a forward call is `nchains` x `nres`
+    (= 2 * num_bottleneck_blocks) consecutive dispatches of it in time order (calls never overlap: every call joins its chains
+    before it returns); inside a call the chains are told apart by the stream / queue column (eager launches and graph replays
+    run on different streams, so the lanes are looked up per call)."""
     cols = [r[1] for r in con.execute("pragma table_info('kernels')")]
     if not cols:   # a view: ask one row
         cols = [d[0] for d in con.execute("select * from kernels limit 1").description]
@@ -57,43 +59,46 @@ def bottleneck_timeline(con, nres=12):
     if not gemm_names:
         raise SystemExit("no wino4_gemm_kernel dispatch in the trace (the bottleneck did not run in F(4x4) form)")
     bneck = max(gemm_names, key=gemm_names.get)
-    lane_idx = None
-    for i, c in enumerate(lane_cols):
-        if len({r[3 + i] for r in rows if r[0] == bneck}) > 1:
-            lane_idx = 3 + i
-            break
-    lanes = {}
-    for k, r in enumerate(rows):
-        lanes.setdefault(r[lane_idx] if lane_idx is not None else 0, []).append(k)
-    per_lane = []   # per lane: list of (window_start, window_end, [gemm intervals]) per call
-    for lane, idxs in sorted(lanes.items(), key=lambda kv: kv[1][0]):
-        g = [k for k in idxs if rows[k][0] == bneck]
-        if not g:
-            continue
-        pos = {k: p for p, k in enumerate(idxs)}
-        calls = []
-        for c0 in range(0, len(g) - nres + 1, nres):
-            grp = g[c0:c0 + nres]
-            first = grp[0]
-            # the stage starts with the input transform dispatched on this lane right in front of the first GEMM
-            p = pos[first]
-            start = rows[first][1]
-            if p > 0 and "wino4_input_transform_kernel" in rows[idxs[p - 1]][0]:
-                start = rows[idxs[p - 1]][1]
-            calls.append((start, rows[grp[-1]][2], [(rows[k][1], rows[k][2]) for k in grp]))
-        per_lane.append(calls)
-    ncalls = min(len(c) for c in per_lane)
-    out = []
-    for i in range(ncalls):
-        out.append({"chains": [c[i][:2] for c in per_lane], "gemm": [iv for c in per_lane for iv in c[i][2]]})
-    return out, short(bneck), ("one lane" if lane_idx is None else lane_cols[lane_idx - 3])
+    g_all = [k for k, r in enumerate(rows) if r[0] == bneck]
+    per_call = nres * nchains
+    out, lane_used = [], set()
+    prev_end = 0
+    for c0 in range(0, len(g_all) - per_call + 1, per_call):
+        grp = g_all[c0:c0 + per_call]
+        lane_idx = None
+        for i, c in enumerate(lane_cols):   # the column that splits this call's dispatches into `nchains` equal groups
+            vals = {}
+            for k in grp:
+                vals[rows[k][3 + i]] = vals.get(rows[k][3 + i], 0) + 1
+            if len(vals) == nchains and set(vals.values()) == {nres}:
+                lane_idx = 3 + i
+                lane_used.add(c)
+                break
+        chains = {}
+        for k in grp:
+            chains.setdefault(rows[k][lane_idx] if lane_idx is not None else 0, []).append(k)
+        windows = []
+        for lane, ks in chains.items():
+            start = rows[ks[0]][1]
+            # the stage starts with the input transform dispatched on this lane right in front of the chain's first GEMM
+            for k in range(ks[0] - 1, -1, -1):
+                if rows[k][2] <= prev_end or rows[ks[0]][1] - rows[k][1] > 2_000_000:
+                    break
+                if (lane_idx is None or rows[k][lane_idx] == lane):
+                    if "wino4_input_transform_kernel" in rows[k][0]:
+                        start = rows[k][1]
+                    break
+            windows.append((start, rows[ks[-1]][2]))
+        out.append({"chains": sorted(windows), "gemm": [(rows[k][1], rows[k][2]) for k in grp]})
+        prev_end = max(rows[k][2] for k in grp)
+    return out, short(bneck), ("/".join(sorted(lane_used)) or "one lane")
 
 
 def timeline_report(bench_json, db):
     line = json.load(open(bench_json))
     roof = line["roofline"]
     con = sqlite3.connect(db)
-    calls, kernel, lane = bottleneck_timeline(con)
+    calls, kernel, lane = bottleneck_timeline(con, 2 * int(line.get("config", {}).get("num_bottleneck_blocks", 6)), int(roof.get("pass_chains", 2)))
     steps, warm = int(line["steps"]), int(line["warmup"])
     timed = calls[warm:warm + steps] if len(calls) >= warm + steps else calls
     print(f"== bottleneck-stage timeline from {db}")
