@@ -294,7 +294,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv_col7_kernel(const Col7Args p
 // chunk) it reads ONE ds_read_b128 of the patch (lane = pixel: its 4 k values) and ONE of the weights (lane = n: W[n][4 k]),
 // and issues 4 k x 3 groups = 12 MFMAs on three rotating accumulators.  Same LDS images (weights [chunk][tap][32 n][32 k]
 // swizzled, patch (16+6) x 16 pixels x 32 k swizzled), same DMA pipeline, same tile walk, same gather epilogue as above.
-template <int NH, typename DmaPiece>
+template <int NH, int EVERY, typename DmaPiece>
 __device__ __forceinline__ void col7q_unit(const float* a_stage, const float* w_stage, int a_off, int b_off, f32x4 (&acc)[3],
                                            bool more, int wave, const Col7Pos& nxt, int st, int dbg, const DmaPiece& dma_patch_piece) {
     constexpr int BK = CONV_BK;
@@ -319,14 +319,15 @@ __device__ __forceinline__ void col7q_unit(const float* a_stage, const float* w_
             acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[g & 1][q], xa[g & 1][q], acc[1], 4, 3 * NH + 1, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[g & 1][q], xa[g & 1][q], acc[2], 4, 3 * NH + 2, 0);
         });
-        if constexpr (g % 8 == 3 && g / 8 < 6) {     // one patch piece of the next unit per tap, 6 slots
+        if constexpr (g % EVERY == EVERY / 2 - 1 && g / EVERY < 6) {     // one patch piece of the next unit every EVERY groups, 6 slots
             __builtin_amdgcn_sched_barrier(0);
-            if (more && wave + CWAVES * (g / 8) < A_PIECES && !(dbg & 1)) dma_patch_piece(std::integral_constant<int, g / 8>{}, nxt, st ^ 1);
+            if (more && wave + CWAVES * (g / EVERY) < A_PIECES && !(dbg & 1)) dma_patch_piece(std::integral_constant<int, g / EVERY>{}, nxt, st ^ 1);
             __builtin_amdgcn_sched_barrier(0);
         }
     });
 }
 
+template <int EVERY>
 __global__ __launch_bounds__(CWAVES * 64) void conv_col7q_kernel(const Col7Args p) {
     constexpr int BK = CONV_BK;
     constexpr int A_STAGE = CPIX * BK;             // floats (44 KiB)
@@ -398,9 +399,9 @@ __global__ __launch_bounds__(CWAVES * 64) void conv_col7q_kernel(const Col7Args 
         col7_pos_next<true>(nxt, p, cchunks, (int)gridDim.x);
         const float* w_stage = Ws + cc * 7 * W_TAP;
         if (nh == 0)
-            col7q_unit<0>(a_stage, w_stage, a_off, b_off, acc, more, wave, nxt, st, p.dbg, dma_patch_piece);
+            col7q_unit<0, EVERY>(a_stage, w_stage, a_off, b_off, acc, more, wave, nxt, st, p.dbg, dma_patch_piece);
         else
-            col7q_unit<1>(a_stage, w_stage, a_off, b_off, acc, more, wave, nxt, st, p.dbg, dma_patch_piece);
+            col7q_unit<1, EVERY>(a_stage, w_stage, a_off, b_off, acc, more, wave, nxt, st, p.dbg, dma_patch_piece);
         if (cc == cchunks - 1 && !(p.dbg & 2)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -617,10 +618,12 @@ static hipError_t col7_launch_impl(const float* in, int C, int B, int H, int W, 
     // EAMM_FINAL_MFMA4 = 0: the fused form on the 32x32x2 MFMA with N padded to 32 (round 3); default: the 4x4x1 multi-block form
     static const bool mfma4 = [] { const char* e = getenv("EAMM_FINAL_MFMA4"); return e ? atoi(e) != 0 : true; }();
     if (fused && mfma4) {
+        // (one patch piece of the next unit per tap, six of the seven taps: issuing them twice as densely at the start of the
+        // unit measured the same -- 210.4 vs 213.4 us at 8 frames, 3915 vs 3912 frames/s in the pipeline)
         static lds_once_mask configured_q{0};
-        if (hipError_t e = ensure_dynamic_lds(conv_col7q_kernel, 160 * 1024, &configured_q); e != hipSuccess) return e;
         note_mfma_flops(2.0 * a.tiles * (CT * CT) * 7.0 * 24 * C);      // N = 24 columns issued
-        hipLaunchKernelGGL(conv_col7q_kernel, dim3(blocks), dim3(CWAVES * 64), lds, stream, a);
+        if (hipError_t e = ensure_dynamic_lds(conv_col7q_kernel<8>, 160 * 1024, &configured_q); e != hipSuccess) return e;
+        hipLaunchKernelGGL(conv_col7q_kernel<8>, dim3(blocks), dim3(CWAVES * 64), lds, stream, a);
         return hipGetLastError();
     }
     note_mfma_flops(2.0 * a.tiles * (CT * CT) * 7.0 * 32 * C);

@@ -33,6 +33,17 @@ namespace eamm {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// a - b on four floats as two v_pk_add_f32 with the second operand negated: hipcc 7.2 turns a vector ADD into packed
+// instructions but scalarises a vector SUBTRACT into four v_sub_f32 (172 of them per chunk in this kernel's MFMA stream --
+// the f32-input MFMA shares the vector pipe, so every VALU instruction is matrix-pipe time).  Bit-identical to a - b.
+__device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]}, rlo, rhi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rlo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rhi) : "v"(ahi), "v"(bhi));
+    return f32x4{rlo[0], rlo[1], rhi[0], rhi[1]};
+}
+
 namespace {
 constexpr int ZT = 16;                   // tile side in low-resolution pixels
 constexpr int ZW = ZT + 2;               // patch side (halo 1)
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(ZWAVES * 64) void conv_patch_poly_kernel(const Patc
         constexpr int q = decltype(qc)::value, i = q % 3;
         f32x4 r0, r1, r2;
         if constexpr (i == 0) { r0 = x1[0]; r1 = x1[1]; r2 = x1[2]; }
-        else { r0 = xr[0] - x1[0]; r1 = xr[1] - x1[1]; r2 = xr[2] - x1[2]; }
+        else { r0 = pk_sub4(xr[0], x1[0]); r1 = pk_sub4(xr[1], x1[1]); r2 = pk_sub4(xr[2], x1[2]); }
         v[q & 1][0] = r1;
         v[q & 1][1] = r0 - r1;
         v[q & 1][2] = r2 - r1;
