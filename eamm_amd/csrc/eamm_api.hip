@@ -126,6 +126,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->pass_chains = c->pass_chains < 0 ? 1 : std::min(c->pass_chains, 4);
     c->bneck_chains = std::max(1, std::min(c->bneck_chains, 16));
     c->bneck_stagger = env_int("EAMM_BNECK_STAGGER", c->bneck_stagger);
+    c->warp_joint = env_int("EAMM_WARP_JOINT", c->warp_joint);
     c->pass_chains_min_frames = env_int("EAMM_PASS_CHAINS_MIN_FRAMES", c->pass_chains_min_frames);
     c->pass_chains_min_blocks = env_int("EAMM_PASS_CHAINS_MIN_BLOCKS", c->pass_chains_min_blocks);
     c->head_col7_min_tiles = env_int("EAMM_HEAD_COL7_MIN_TILES", c->head_col7_min_tiles);
@@ -149,6 +150,7 @@ void eamm_destroy(eamm_ctx* c) {
     for (auto& e : c->prof_chain_ev) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_stagger) (void)hipEventDestroy(c->ev_stagger);
+    if (c->ev_warp) (void)hipEventDestroy(c->ev_warp);
     for (auto& e : c->ev_join) (void)hipEventDestroy(e);
     for (auto& st : c->side_streams) (void)hipStreamDestroy(st);
     delete c;
@@ -448,6 +450,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
     if (max_chains > 1) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_warp, hipEventDisableTiming));
         for (int k = 1; k < max_chains; ++k) {
             hipStream_t st = nullptr;
             hipEvent_t ev = nullptr;
@@ -643,8 +646,12 @@ static int pass_chains(const eamm_ctx* c, int n) {
 }
 
 // One launch sequence over the frames of `v` on stream s.  `chained`: another sequence runs beside this one.
+// phase: the whole pass, or its two halves around the feature warp (PH_PRE: key points ... flow head; PH_POST: warp ... final
+// layer).  With `joint` (first chain's PH_POST) the warps run ONCE for all the call's frames -- the view `joint` -- and the
+// other chains' PH_POST skip them and start behind c->ev_warp.
+enum { PH_ALL = 0, PH_PRE = 1, PH_POST = 2 };
 static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent_t* ev, bool chained, hipEvent_t* cev = nullptr,
-                        int chain_idx = 0) {
+                        int chain_idx = 0, int phase = PH_ALL, const FrameView* joint = nullptr) {
     const int n = v.n, ns = v.ns;
     const int h = c->h, w = c->w, hf = c->hf, wf = c->wf, K = c->K;
     const bool occ = c->cfg.estimate_occlusion_map != 0;
@@ -671,6 +678,7 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         HIP_TRY(c, broadcast_features_launch(v.feat, n, ns, hf, wf, c->Cb, v.xa, wino ? nullptr : v.act, c->pre_s[0], c->pre_t[0], s));
         STAGE_MARK(5);
     } else {
+    if (phase != PH_POST) {
     STAGE_MARK(0);
     // key-point records; 'jacobian' missing from kp_driving => identity (dense_motion.py:55)
     HIP_TRY(c, kp_prepare_launch(v.kd_val, v.kd_jac, v.ks_val, v.kd_jac ? v.ks_jac : nullptr, n, ns, K, v.kp_rec, c->bad_flag, s));
@@ -765,13 +773,26 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
             HIP_TRY(c, hipMemcpyAsync(v.out.deformation, defo, (size_t)n * h * w * 2 * sizeof(float),
                                       hipMemcpyDeviceToDevice, s));
     }
-    STAGE_MARK(4);
-    // feature warp x occlusion (+ r0's pre-activation for the direct form)       generator.py:79-84
-    HIP_TRY(c, warp_features_launch(v.feat, v.deformation, occ ? v.occlusion : nullptr, n, ns, hf, wf, c->Cb, h, w,
-                                    v.xa, wino ? nullptr : v.act, c->pre_s[0], c->pre_t[0], s));
-    if (v.out.deformed)                                                         // generator.py:86
-        HIP_TRY(c, warp_image_launch(v.src_full, v.deformation, n, ns, c->H, c->W, h, w, v.out.deformed, s));
-    STAGE_MARK(5);
+    }   // phase != PH_POST
+    if (phase == PH_PRE) {
+        account(3);
+        return EAMM_OK;
+    }
+    if (phase == PH_POST && joint == nullptr) {
+        HIP_TRY(c, hipStreamWaitEvent(s, c->ev_warp, 0));    // the first chain's launch warped this chain's frames as well
+    } else {
+        if (phase == PH_POST)   // every chain's flow is ready (the caller made this stream wait for the others' PH_PRE)
+            for (size_t k = 0; k < c->ev_join.size(); ++k) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[k], 0));
+        STAGE_MARK(4);
+        // feature warp x occlusion (+ r0's pre-activation for the direct form)       generator.py:79-84
+        const FrameView& wv = joint ? *joint : v;
+        HIP_TRY(c, warp_features_launch(wv.feat, wv.deformation, occ ? wv.occlusion : nullptr, wv.n, wv.ns, hf, wf, c->Cb, h, w,
+                                        wv.xa, wino ? nullptr : wv.act, c->pre_s[0], c->pre_t[0], s));
+        if (wv.out.deformed)                                                        // generator.py:86
+            HIP_TRY(c, warp_image_launch(wv.src_full, wv.deformation, wv.n, wv.ns, c->H, c->W, h, w, wv.out.deformed, s));
+        if (joint) HIP_TRY(c, hipEventRecord(c->ev_warp, s));
+        STAGE_MARK(5);
+    }
     }
     // bottleneck                                                               generator.py:89
     float *x = v.xa, *xn = v.xb;
@@ -968,12 +989,20 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         const int nbase = n / chains, nrem = n % chains;   // the first nrem chains take one more frame
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         for (int k = 1; k < chains; ++k) HIP_TRY(c, hipStreamWaitEvent(c->side_streams[k - 1], c->ev_fork, 0));
-        for (int k = 0; k < chains; ++k) {
-            const int nk = nbase + (k < nrem ? 1 : 0), f0 = k * nbase + std::min(k, nrem);
-            const FrameView v = make_view(c, f0, nk, ns, k, kd_val, kd_jac, ks_val, ks_jac, o);
-            if (int rc = forward_view(c, v, k ? c->side_streams[k - 1] : s, k ? nullptr : ev, true,
-                                      (cev && k < eamm_ctx::MAXCHAIN) ? cev + 2 * k : nullptr, k))
-                return rc;
+        // EAMM_WARP_JOINT: the chains meet once, after their flow heads: ONE warp launch over all frames (an HBM-bound kernel
+        // that fills the chip alone; per chain it runs beside the other chain's kernels at half the rate), then they part again
+        const bool joint = c->warp_joint && c->nb > 0 && c->ev_warp != nullptr;
+        for (int pass = 0; pass < (joint ? 2 : 1); ++pass) {
+            for (int k = 0; k < chains; ++k) {
+                const int nk = nbase + (k < nrem ? 1 : 0), f0 = k * nbase + std::min(k, nrem);
+                const FrameView v = make_view(c, f0, nk, ns, k, kd_val, kd_jac, ks_val, ks_jac, o);
+                const FrameView all = make_view(c, 0, n, ns, 0, kd_val, kd_jac, ks_val, ks_jac, o);
+                hipStream_t sk = k ? c->side_streams[k - 1] : s;
+                if (int rc = forward_view(c, v, sk, k ? nullptr : ev, true, (cev && k < eamm_ctx::MAXCHAIN) ? cev + 2 * k : nullptr, k,
+                                          joint ? (pass == 0 ? PH_PRE : PH_POST) : PH_ALL, (joint && pass == 1 && k == 0) ? &all : nullptr))
+                    return rc;
+                if (joint && pass == 0 && k > 0) HIP_TRY(c, hipEventRecord(c->ev_join[k - 1], sk));
+            }
         }
         for (int k = 1; k < chains; ++k) {
             HIP_TRY(c, hipEventRecord(c->ev_join[k - 1], c->side_streams[k - 1]));
@@ -1669,5 +1698,99 @@ int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B,
     if (e != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "eamm_op_conv_wgrad failed: %s", hipGetErrorString(e));
     return EAMM_OK;
 }
+
+// ---- differentiable dense-motion front end and flow head (motion.hip forward kernels, motion_backward.hip) -----------------------
+#define MOTION_ENTRY(cond, msg)                                                                  \
+    if (cond) return fail(nullptr, EAMM_ERR_ARG, msg);                                           \
+    DeviceGuard guard(device);                                                                   \
+    if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");   \
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_)
+#define MOTION_DONE(e, name) \
+    return (e) == hipSuccess ? EAMM_OK : fail(nullptr, EAMM_ERR_HIP, name " failed: %s", hipGetErrorString(e))
+
+int eamm_op_antialias_down(int device, const float* source, const float* aa_weight, int B, int H, int W, int inv_scale, float* small,
+                           void* stream_) {
+    MOTION_ENTRY(!source || !small || B < 1 || H < 1 || W < 1 || (inv_scale != 1 && inv_scale != 4) || (inv_scale == 4 && !aa_weight) ||
+                     H % inv_scale || W % inv_scale,
+                 "eamm_op_antialias_down: bad argument (inv_scale 1 | 4: the 13x13 kernel of scale_factor 0.25)");
+    hipError_t e = antialias_down_launch(source, aa_weight, B, H, W, inv_scale, 4, small, s);
+    MOTION_DONE(e, "eamm_op_antialias_down");
+}
+
+int eamm_op_antialias_down_backward(int device, const float* grad_small, const float* aa_weight, int B, int H, int W, int inv_scale,
+                                    float* grad_source, void* stream_) {
+    MOTION_ENTRY(!grad_small || !grad_source || B < 1 || H < 1 || W < 1 || (inv_scale != 1 && inv_scale != 4) ||
+                     (inv_scale == 4 && !aa_weight) || H % inv_scale || W % inv_scale,
+                 "eamm_op_antialias_down_backward: bad argument");
+    hipError_t e = antialias_down_backward_launch(grad_small, aa_weight, B, H, W, inv_scale, grad_source, s);
+    MOTION_DONE(e, "eamm_op_antialias_down_backward");
+}
+
+int eamm_op_kp_records(int device, const float* kd_val, const float* kd_jac, const float* ks_val, const float* ks_jac, int n, int K,
+                       float* records, int* singular_flag, void* stream_) {
+    MOTION_ENTRY(!kd_val || !ks_val || !records || !singular_flag || n < 1 || K < 1 || K > 31 || ((kd_jac == nullptr) != (ks_jac == nullptr)),
+                 "eamm_op_kp_records: bad argument");
+    hipError_t e = kp_prepare_launch(kd_val, kd_jac, ks_val, ks_jac, n, n, K, records, singular_flag, s);
+    MOTION_DONE(e, "eamm_op_kp_records");
+}
+
+int eamm_op_kp_records_backward(int device, const float* kd_jac, const float* ks_jac, const float* grad_records, int n, int K,
+                                float* grad_kd_val, float* grad_ks_val, float* grad_kd_jac, float* grad_ks_jac, void* stream_) {
+    MOTION_ENTRY(!grad_records || n < 1 || K < 1 || ((kd_jac == nullptr) != (ks_jac == nullptr)) ||
+                     ((grad_kd_jac || grad_ks_jac) && !kd_jac),
+                 "eamm_op_kp_records_backward: bad argument");
+    hipError_t e = kp_records_backward_launch(kd_jac, ks_jac, grad_records, n, K, grad_kd_val, grad_ks_val, grad_kd_jac, grad_ks_jac, s);
+    MOTION_DONE(e, "eamm_op_kp_records_backward");
+}
+
+size_t eamm_op_motion_workspace_floats(int n, int K, int h, int w) {
+    if (n < 1 || K < 1 || h < 1 || w < 1) return 0;
+    return motion_backward_workspace_floats(n, K, h, w);
+}
+
+int eamm_op_motion_front(int device, const float* records, const float* small, int n, int K, int h, int w, float kp_variance, int Cpad,
+                         float* hourglass_in, float* sparse_deformed, void* stream_) {
+    MOTION_ENTRY(!records || !small || !hourglass_in || n < 1 || K < 1 || K > 31 || h < 2 || w < 2 || Cpad < 4 * (K + 1) || (Cpad & 3) ||
+                     !(kp_variance > 0.f),
+                 "eamm_op_motion_front: bad argument");
+    hipError_t e = motion_front_launch(records, small, n, n, K, h, w, kp_variance, Cpad, hourglass_in, sparse_deformed, s);
+    MOTION_DONE(e, "eamm_op_motion_front");
+}
+
+int eamm_op_motion_front_backward(int device, const float* records, const float* small, int n, int K, int h, int w, float kp_variance,
+                                  int Cpad, const float* grad_hourglass_in, const float* grad_sparse_deformed, float* grad_small,
+                                  float* grad_records, float* workspace, size_t workspace_floats, void* stream_) {
+    MOTION_ENTRY(!records || !small || !grad_records || !workspace || (!grad_hourglass_in && !grad_sparse_deformed) || n < 1 || K < 1 ||
+                     K > 31 || h < 2 || w < 2 || Cpad < 4 * (K + 1) || (Cpad & 3) || !(kp_variance > 0.f) ||
+                     workspace_floats < motion_backward_workspace_floats(n, K, h, w),
+                 "eamm_op_motion_front_backward: bad argument");
+    hipError_t e = motion_front_backward_launch(records, small, n, K, h, w, kp_variance, Cpad, grad_hourglass_in, grad_sparse_deformed,
+                                                grad_small, grad_records, workspace, s);
+    MOTION_DONE(e, "eamm_op_motion_front_backward");
+}
+
+int eamm_op_motion_head(int device, const float* mask_logits, int ld, const float* occlusion_logits, int ldo, const float* records, int n,
+                        int K, int h, int w, float* mask, float* deformation, float* occlusion, void* stream_) {
+    MOTION_ENTRY(!mask_logits || !records || !mask || !deformation || n < 1 || K < 1 || K > 31 || h < 2 || w < 2 || ld < K + 1 ||
+                     (occlusion_logits && (ldo < 1 || !occlusion)),
+                 "eamm_op_motion_head: bad argument");
+    hipError_t e = motion_head_forward_launch(mask_logits, ld, occlusion_logits, ldo, records, n, K, h, w, mask, deformation, occlusion, s);
+    MOTION_DONE(e, "eamm_op_motion_head");
+}
+
+int eamm_op_motion_head_backward(int device, const float* mask, const float* occlusion, const float* records, int n, int K, int h, int w,
+                                 const float* grad_mask, const float* grad_deformation, const float* grad_occlusion,
+                                 float* grad_mask_logits, int ld, float* grad_occlusion_logits, int ldo, float* grad_records,
+                                 float* workspace, size_t workspace_floats, void* stream_) {
+    MOTION_ENTRY(!mask || !records || !grad_mask_logits || !grad_records || !workspace || n < 1 || K < 1 || K > 31 || h < 2 || w < 2 ||
+                     ld < K + 1 || (grad_occlusion_logits && (ldo < 1 || !occlusion)) ||
+                     workspace_floats < motion_backward_workspace_floats(n, K, h, w),
+                 "eamm_op_motion_head_backward: bad argument");
+    hipError_t e = motion_head_backward_launch(mask, occlusion, records, n, K, h, w, grad_mask, grad_deformation, grad_occlusion,
+                                               grad_mask_logits, ld, grad_occlusion_logits, ldo, grad_records, workspace, s);
+    MOTION_DONE(e, "eamm_op_motion_head_backward");
+}
+#undef MOTION_ENTRY
+#undef MOTION_DONE
 
 }  // extern "C"

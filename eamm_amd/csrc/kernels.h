@@ -241,4 +241,19 @@ hipError_t conv7_thin_in_launch(const float* thin, const float* w, const float* 
 hipError_t conv7_thin_wgrad_launch(const float* thin, const float* wide, int B, int H, int W, int N, int thin_is_input, float* dw,
                                    float* workspace, hipStream_t s);
 
+// ---- backward of the dense-motion front end / flow head (motion_backward.hip; forward kernels in motion.hip)
+hipError_t antialias_down_backward_launch(const float* dsmall /*[B,h,w,4]*/, const float* aa_w, int B, int H, int W, int inv_scale,
+                                          float* dsrc /*[B,3,H,W]*/, hipStream_t s);
+hipError_t kp_records_backward_launch(const float* kd_jac, const float* ks_jac, const float* drec, int n, int K, float* dkd_val,
+                                      float* dks_val, float* dkd_jac, float* dks_jac, hipStream_t s);
+size_t motion_backward_workspace_floats(int n, int K, int h, int w);
+hipError_t motion_front_backward_launch(const float* rec, const float* src_small, int n, int K, int h, int w, float variance, int Cpad,
+                                        const float* dhg, const float* dsd, float* dsrc_small, float* drec, float* workspace,
+                                        hipStream_t s);
+hipError_t motion_head_forward_launch(const float* lm, int ld, const float* lo, int ldo, const float* rec, int n, int K, int h, int w,
+                                      float* mask, float* deformation, float* occlusion, hipStream_t s);
+hipError_t motion_head_backward_launch(const float* mask, const float* occlusion, const float* rec, int n, int K, int h, int w,
+                                       const float* dmask, const float* ddef, const float* docc, float* dlm, int ld, float* dlo, int ldo,
+                                       float* drec, float* workspace, hipStream_t s);
+
 }  // namespace eamm

@@ -26,6 +26,7 @@ GPU only: no CPU fallback.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import torch
@@ -46,9 +47,11 @@ def _pad_last(x: torch.Tensor, mult: int) -> torch.Tensor:
     return x if c % mult == 0 else F.pad(x, (0, _round_up(c, mult) - c))
 
 
-def conv(x: torch.Tensor, mod: torch.nn.Conv2d, feeds_norm: bool = False) -> torch.Tensor:
+def conv(x: torch.Tensor, mod: torch.nn.Conv2d, feeds_norm: bool = False, keep_padded: bool = False) -> torch.Tensor:
     """``mod(x)`` for the path's stride-1 "same" 3x3 / 7x7 convolutions on NHWC [B,H,W,Cin] -> NHWC [B,H,W,Cout]; channels
-    zero-padded to the kernels' granule (the padded filter rows / columns are zeros and the slice drops their gradient)."""
+    zero-padded to the kernels' granule (the padded filter rows / columns are zeros and the slice drops their gradient).  An input
+    that already carries zero channels up to the granule is taken as it is; ``keep_padded`` returns the granule-padded output
+    (channels >= Cout are exactly zero... plus nothing: their filters and biases are zeros)."""
     w, b = mod.weight, mod.bias
     cout, cin = w.shape[:2]
     cin_p, cout_p = _round_up(cin, _G), _round_up(cout, _G)
@@ -60,7 +63,7 @@ def conv(x: torch.Tensor, mod: torch.nn.Conv2d, feeds_norm: bool = False) -> tor
         b = F.pad(b, (0, cout_p - cout)) if b is not None else None
     # feeds_norm: the output goes straight into a batch-statistics BatchNorm -- the bias gradient is exactly zero
     y = autograd_ops.conv2d_same_nhwc(x, w, b, bias_grad_is_zero=feeds_norm)
-    return y[..., :cout] if cout_p != cout else y
+    return y[..., :cout] if (cout_p != cout and not keep_padded) else y
 
 
 def warp(features: torch.Tensor, deformation: torch.Tensor, occlusion=None) -> torch.Tensor:
@@ -193,7 +196,33 @@ def _antialias_down(x: torch.Tensor, weight: torch.Tensor, scale: float) -> torc
 
 
 def _dense_motion(g: _Graph, source_image, kp_driving, kp_source):
-    """dense_motion.py:32-113.  source_image NCHW as the caller passed it."""
+    """dense_motion.py:32-113.  source_image NCHW as the caller passed it.  Round 4: anti-aliasing, key-point records, heat-maps +
+    sparse motions + the K+1 warps, and the softmax / flow / sigmoid head are HIP operators with HIP backward (``motion_ops``); the
+    torch composition below remains for configurations those kernels do not cover (scale_factor other than 0.25 / 1, more than
+    three image channels)."""
+    dm = g.gen.dense_motion_network
+    inv = 1.0 / dm.scale_factor
+    if os.environ.get("EAMM_MOTION_TORCH") != "1" and source_image.shape[1] == 3 and abs(inv - round(inv)) < 1e-6 and int(round(inv)) in (1, 4) and dm.num_kp <= 31 and \
+            source_image.shape[2] % int(round(inv)) == 0 and source_image.shape[3] % int(round(inv)) == 0:
+        from . import motion_ops
+        small = motion_ops.antialias_down(source_image, dm.down.weight if dm.scale_factor != 1 else None, dm.scale_factor)
+        rec = motion_ops.kp_records(kp_driving, kp_source)
+        # hourglass input [B,h,w,64]: 4 (K+1) real channels + zeros up to the kernels' granule -- the convolutions take it as it is
+        hg_in, sparse = motion_ops.motion_front(rec, small, dm.kp_variance, _round_up(4 * (dm.num_kp + 1), _G))
+        if dm.hourglass.decoder.up_blocks[-1].conv.weight.shape[0] % _G:   # the last concatenation would not end on the granule
+            hg_in = hg_in[..., :4 * (dm.num_kp + 1)]
+        feat = g.hourglass(hg_in, dm.hourglass)
+        lo = conv(feat, dm.occlusion, keep_padded=True) if dm.occlusion is not None else None
+        mask, deformation, occ = motion_ops.motion_head(conv(feat, dm.mask, keep_padded=True), lo, rec)
+        out = {"sparse_deformed": sparse, "mask": mask, "deformation": deformation}
+        if occ is not None:
+            out["occlusion_map"] = occ
+        return out
+    return _dense_motion_torch(g, source_image, kp_driving, kp_source)
+
+
+def _dense_motion_torch(g: _Graph, source_image, kp_driving, kp_source):
+    """The same stage as torch-ROCm ops with torch's own autograd (rounds 3's composition)."""
     dm = g.gen.dense_motion_network
     src = _antialias_down(source_image, dm.down.weight, dm.scale_factor) if dm.scale_factor != 1 else source_image
     b, c, h, w = src.shape

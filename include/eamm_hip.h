@@ -417,6 +417,50 @@ size_t eamm_op_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cou
 int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                        float* grad_weight, float* grad_bias, float* workspace, size_t workspace_floats, void* stream);
 
+/*
+ * The dense-motion front end and flow head as DIFFERENTIABLE operators (round 4): forward = the evaluation
+ * path's kernels (motion.hip), backward = what autograd derives from the reference's torch ops (motion_backward.hip).  Device
+ * pointers, per-pair sources (n sources for n driving frames, the training batch of train.py:133); asynchronous on `stream`.
+ *   eamm_op_antialias_down            AntiAliasInterpolation2d (modules/util.py:1044-1052): source NCHW [B,3,H,W], the module's
+ *                                     [3,1,13,13] buffer -> small NHWC [B,H/s,W/s,4] (RGB + a zero); inv_scale 4 (scale_factor 0.25)
+ *                                     or 1 (a copy, util.py:1047-1048)
+ *   eamm_op_antialias_down_backward   grad_small [B,h,w,4] -> grad_source [B,3,H,W]
+ *   eamm_op_kp_records                records [n,K,8] = kp_driving.xy, kp_source.xy, J = jac_source inverse(jac_driving)
+ *                                     (dense_motion.py:47-67; jacobians NULL: identity); *singular_flag (device int) is set when
+ *                                     a driving jacobian is singular (torch.inverse raises)
+ *   eamm_op_kp_records_backward       grad_records -> grad of the four key-point tensors (any may be NULL)
+ *   eamm_op_motion_front              heat-maps (util.py:815-836, dense_motion.py:32-45), sparse motions and the K+1 warps of
+ *                                     `small` (:69-79) -> hourglass_in NHWC [n,h,w,Cpad] (channel 4k heat-map k, 4k+1..3 RGB warped
+ *                                     by motion k, zero padded; dense_motion.py:93-94) and sparse_deformed [n,K+1,3,h,w] (or NULL)
+ *   eamm_op_motion_front_backward     grad of both outputs (either may be NULL) -> grad_small [n,h,w,4] (or NULL; float atomics like
+ *                                     ATen's grid_sampler backward) and grad_records [n,K,8] (fixed-order sums: deterministic)
+ *   eamm_op_motion_head               mask = softmax over the K+1 mask logits [n,h,w,ld], deformation = sum_k mask_k T_k,
+ *                                     occlusion = sigmoid(logit [n,h,w,ldo] channel 0) (dense_motion.py:98-111; occlusion NULL: none)
+ *   eamm_op_motion_head_backward      grad_mask [n,K+1,h,w], grad_deformation [n,h,w,2], grad_occlusion [n,h,w] (any may be NULL)
+ *                                     -> grad of the logits (same layouts, unused channels zeroed) and grad_records
+ * `workspace`: eamm_op_motion_workspace_floats(n, K, h, w) floats.
+ */
+int eamm_op_antialias_down(int device, const float* source, const float* aa_weight, int B, int H, int W, int inv_scale, float* small,
+                           void* stream);
+int eamm_op_antialias_down_backward(int device, const float* grad_small, const float* aa_weight, int B, int H, int W, int inv_scale,
+                                    float* grad_source, void* stream);
+int eamm_op_kp_records(int device, const float* kd_val, const float* kd_jac, const float* ks_val, const float* ks_jac, int n, int K,
+                       float* records, int* singular_flag, void* stream);
+int eamm_op_kp_records_backward(int device, const float* kd_jac, const float* ks_jac, const float* grad_records, int n, int K,
+                                float* grad_kd_val, float* grad_ks_val, float* grad_kd_jac, float* grad_ks_jac, void* stream);
+size_t eamm_op_motion_workspace_floats(int n, int K, int h, int w);
+int eamm_op_motion_front(int device, const float* records, const float* small, int n, int K, int h, int w, float kp_variance, int Cpad,
+                         float* hourglass_in, float* sparse_deformed, void* stream);
+int eamm_op_motion_front_backward(int device, const float* records, const float* small, int n, int K, int h, int w, float kp_variance,
+                                  int Cpad, const float* grad_hourglass_in, const float* grad_sparse_deformed, float* grad_small,
+                                  float* grad_records, float* workspace, size_t workspace_floats, void* stream);
+int eamm_op_motion_head(int device, const float* mask_logits, int ld, const float* occlusion_logits, int ldo, const float* records, int n,
+                        int K, int h, int w, float* mask, float* deformation, float* occlusion, void* stream);
+int eamm_op_motion_head_backward(int device, const float* mask, const float* occlusion, const float* records, int n, int K, int h, int w,
+                                 const float* grad_mask, const float* grad_deformation, const float* grad_occlusion,
+                                 float* grad_mask_logits, int ld, float* grad_occlusion_logits, int ldo, float* grad_records,
+                                 float* workspace, size_t workspace_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,9 +83,9 @@ def compare(z, grads, floors_allowed, min_rel, report=False):
         # it feeds -- a weight gradient's Cin x taps entries of one output channel at once.  (Seen: replacing a batched 2x2
         # matmul by its element-wise form moved 8 sampled entries of up_blocks.1.conv.weight by up to 0.8 % of the tensor's
         # largest gradient, everything else by ~1e-6.)  So (not "95 % within the bar" -- a systematic halo error of
-        # a weight-gradient kernel could hide in the other 5 %): at most 0.5 % of a tensor's sampled elements (and never more
-        # than 2 of a small one) beyond the bar, none beyond 20 bars.
-        allowed = max(2, diff.numel() // 200) if diff.numel() >= 40 else 0
+        # a weight-gradient kernel could hide in the other 5 %): at most 0.5 % of a tensor's sampled elements (2 of a tensor of a few
+        # hundred, ONE of a smaller one: a flip moves a bias / BatchNorm-parameter gradient too) beyond the bar, none beyond 20 bars.
+        allowed = max(2, diff.numel() // 200) if diff.numel() >= 400 else 1
         beyond = int((diff > bar).sum())
         err = float(torch.quantile(diff, 1.0 - allowed / diff.numel())) if allowed else float(diff.max())
         rows.append((err / bar, k, err / scale, floor_k, beyond, diff.numel()))
@@ -342,29 +342,40 @@ def test_only_the_key_points_need_a_gradient():
 
 # ---------------------------------------------------------------------------------------------------------------------
 # replicas and constructor variants: the oracle's training branch, differentiated in double, is the reference here
-def _oracle_gradients(cfg, sd, src, kp_s, kp_d, weights, parallel):
+def _oracle_gradients(cfg, sd, src, kp_s, kp_d, weights, parallel, dtype=torch.float64):
     leaf = lambda k, v: v.is_floating_point() and "running" not in k and "down.weight" not in k
-    sdd = {k: (v.double().requires_grad_() if leaf(k, v) else v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-    ks = {k: v.double().requires_grad_() for k, v in kp_s.items()}
-    kd = {k: v.double().requires_grad_() for k, v in kp_d.items()}
-    out, _ = orc.generator_forward_train(sdd, cfg, src.double(), kd, ks, parallel=parallel)
-    sum((out[k] * weights[k].double()).sum() for k in weights).backward()
+    sdd = {k: (v.to(dtype).requires_grad_() if leaf(k, v) else v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+    ks = {k: v.to(dtype).requires_grad_() for k, v in kp_s.items()}
+    kd = {k: v.to(dtype).requires_grad_() for k, v in kp_d.items()}
+    out, _ = orc.generator_forward_train(sdd, cfg, src.to(dtype), kd, ks, parallel=parallel)
+    sum((out[k] * weights[k].to(dtype)).sum() for k in weights).backward()
     grads = {"param/" + k: v.grad for k, v in sdd.items() if v.requires_grad}
     grads.update({"kp_source/" + k: v.grad for k, v in ks.items()})
     grads.update({"kp_driving/" + k: v.grad for k, v in kd.items()})
     return grads
 
 
-def _close(got, want, what):
-    """fp32 run against the double gradients, without per-tensor floors: the reference's own fp32 run sits up to 9.3e-3 of a
-    tensor's largest entry away from its double run on this network (fixture: up_blocks.0.conv.weight; 7.9e-3
-    down_blocks.1.norm.weight, ...), so the bar is 2e-2 -- 95 % of a tensor's entries within it, none beyond 10 x (a wrong
-    kernel is off by the gradient's own size)."""
+def _close(got, want, what, want32=None):
+    """fp32 run against the double gradients: the reference's own fp32 run sits up to 9.3e-3 of a tensor's largest entry away
+    from its double run on this network (fixture: up_blocks.0.conv.weight; 7.9e-3 down_blocks.1.norm.weight, ...), so the bar
+    is 2e-2 -- 95 % of a tensor's entries within it, none beyond 10 x (a wrong kernel is off by the gradient's own size).
+    With ``want32`` (the ORACLE's fp32 run of the same computation) a tensor's bar is at least 4 x its own fp32-vs-fp64
+    distance: one- and few-element gradients that are heavily cancelling sums (the occlusion head's bias: one float summed over
+    every pixel of the batch) sit several per cent away from the double value in any fp32 run."""
     gmax = max(float(v.abs().max()) for v in want.values())
     for k, w in want.items():
         diff = (got[k].detach().cpu().double() - w).abs().reshape(-1)
         scale = float(w.abs().max())
-        bar = 2e-2 * (scale if scale >= 1e-9 * gmax else gmax)
+        scale = scale if scale >= 1e-9 * gmax else gmax
+        rel = 2e-2
+        if want32 is not None:
+            rel = max(rel, 4.0 * float((want32[k].double() - w).abs().max()) / scale)
+        if diff.numel() < 8:
+            # a one-float gradient that is a cancelling sum over every pixel (dense_motion_network.occlusion.bias: -0.65 left of
+            # terms two orders larger) moves by 1.3 % when the source image is scaled by (1 + 1e-7) and by 3.7 % between two
+            # routes that agree to 1e-5 in evaluation mode (tools/micro/noise_probe.py, batch-statistics BatchNorm): 6e-2
+            rel = max(rel, 6e-2)
+        bar = rel * scale
         q = float(torch.quantile(diff, 0.95)) if diff.numel() >= 40 else float(diff.max())
         assert q <= bar and float(diff.max()) <= 10 * bar, (what, k, q, float(diff.max()), bar)
 
@@ -453,11 +464,60 @@ def test_generator_backward_variants_against_oracle_autograd(variant):
     weights = {k: torch.randn(out[k].shape, generator=g) for k in out}
     sum((out[k] * weights[k].to(DEV)).sum() for k in out).backward()
     want = _oracle_gradients(cfg, sd, src, kp_s, kp_d, weights, parallel=False)
+    want32 = _oracle_gradients(cfg, sd, src, kp_s, kp_d, weights, parallel=False, dtype=torch.float32)
     got = {"param/" + k: p.grad for k, p in gen.named_parameters()}
     if variant == "no_motion_network":     # the key points are never looked at (generator.py:64)
         assert all(v.grad is None for v in list(ks.values()) + list(kd.values()))
         want = {k: v for k, v in want.items() if k.startswith("param/") and v is not None}
+        want32 = {k: want32[k] for k in want}
     else:
         got.update({"kp_source/" + k: v.grad for k, v in ks.items()})
         got.update({"kp_driving/" + k: v.grad for k, v in kd.items()})
-    _close(got, want, variant)
+    _close(got, want, variant, want32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["jacobian", "no_jacobian"])
+def test_hip_motion_operators_and_torch_composition_give_the_same_gradients(variant, monkeypatch):
+    """Round 4: the dense-motion stage of the differentiable forward runs on HIP operators with HIP backward (motion_ops); the
+    torch-ROCm composition it replaced (EAMM_MOTION_TORCH=1) is the same function -- outputs and every gradient of the two
+    routes agree far inside the fixtures' bars (they differ by fp32 rounding and the odd flipped ReLU only)."""
+    cfg = tiny_config()
+    n = 3
+    src = synthetic_source(64, seed=3, batch=n)
+    jac = variant == "jacobian"
+    kp_s, kp_d = synthetic_keypoints(n, 10, seed=4, jacobian=jac), synthetic_keypoints(n, 10, seed=5, jacobian=jac)
+    runs = {}
+    for route in ("hip", "torch"):
+        monkeypatch.setenv("EAMM_MOTION_TORCH", "1" if route == "torch" else "0")
+        gen = _make(cfg, 77).eval()          # running statistics: no batch-statistics cancellation in the comparison
+        s = src.to(DEV).requires_grad_()
+        ks = {k: v.to(DEV).requires_grad_() for k, v in kp_s.items()}
+        kd = {k: v.to(DEV).requires_grad_() for k, v in kp_d.items()}
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = gen(s, kp_driving=kd, kp_source=ks)
+        g = torch.Generator().manual_seed(9)
+        weights = {k: torch.randn(out[k].shape, generator=g) for k in KEYS}
+        sum((out[k] * weights[k].to(DEV)).sum() for k in KEYS).backward()
+        grads = {"source_image": s.grad}
+        grads.update({"kp_source/" + k: v.grad for k, v in ks.items()})
+        grads.update({"kp_driving/" + k: v.grad for k, v in kd.items()})
+        grads.update({"param/" + k: p.grad for k, p in gen.named_parameters()})
+        runs[route] = ({k: out[k].detach() for k in KEYS}, grads)
+    for k in KEYS:
+        assert float((runs["hip"][0][k] - runs["torch"][0][k]).abs().max()) <= 2e-5, k
+    worst = (0.0, None)
+    for k, gt in runs["torch"][1].items():
+        gh = runs["hip"][1][k]
+        scale = float(gt.abs().max())
+        diff = (gh - gt).abs().reshape(-1)
+        rel = float(diff.max()) / max(scale, 1e-12)
+        if rel > worst[0]:
+            worst = (rel, k)
+        # everything within 2e-3 of the tensor's largest entry; 99.5 % within 2e-4
+        assert rel <= 2e-3, (k, rel)
+        if diff.numel() >= 400:
+            assert float(torch.quantile(diff[:1 << 20], 0.995)) <= 2e-4 * scale, k
+    print(f"hip vs torch motion stage ({variant}): worst relative gradient difference {worst[0]:.2e} at {worst[1]}")
