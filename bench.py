@@ -434,7 +434,8 @@ def main():
         traffic, traffic_src = measured_traffic(form, S, B, chains)
         which = "configs[2]" if (S, B) == (256, 16) else ("configs[4]" if (S, B) == (512, 8) else "a non-BASELINE size")
         warp_bytes_frame = (2 * hf * hf * cb + 3 * (S // 4) * (S // 4)) * 4.0    # 8.438 MB at 256^2
-        warp_frames = B // pchains                                              # frames of ONE in-pipeline launch
+        warp_joint = os.environ.get("EAMM_WARP_JOINT") == "1" and pchains > 1      # one launch for all chains' frames (knob, off by default)
+        warp_frames = B if warp_joint else B // pchains                         # frames of ONE in-pipeline launch
         warp_ms = pm["warp"] / calls
 
         # per-stage fraction of the chip's fp32 matrix peak: executed matrix-core GFLOP of the stage (ALL chains, library-side
@@ -501,8 +502,11 @@ def main():
             # algorithmic bytes per frame = feature map read + written once + flow + occlusion
             "roofline_warp": dict({"bound": "hbm", "kernel": "warp_features_kernel", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frames_per_launch": warp_frames,
-                                   "note": "in the pipeline: one launch of the main stream's chain (stage events incl. the "
-                                           "boundary), beside the other chain's kernels"},
+                                   "note": ("in the pipeline: ONE launch for all chains' frames behind a join of the chains (EAMM_WARP_JOINT=1; "
+                                            "stage events incl. the boundary)") if warp_joint else
+                                           ("in the pipeline: one launch of the main stream's chain (stage events incl. the boundary), "
+                                            "beside the other chain's kernels; EAMM_WARP_JOINT=1 joins the chains for one launch over all "
+                                            "frames: 0.58 of the HBM peak in the pipeline, -0.8 % frames/s (profiles/r04_experiments.txt)")},
                                   **hbm(warp_frames * warp_bytes_frame, warp_ms),
                                   **({"isolated": dict({"frames_per_launch": B, "note": "the same kernel alone on the chip "
                                                         "(eamm_op_warp, 50 back-to-back launches)"},

@@ -17,6 +17,6 @@ timeout 300 python tools/bn_bench.py 2>&1 < /dev/null | grep -v amdgpu.ids > $O/
 timeout 300 python tools/backward_bench.py 16 2>&1 < /dev/null | grep -v amdgpu.ids > $O/backward_bench.txt; cut -c1-260 $O/backward_bench.txt
 timeout 300 python tools/train_step_bench.py 8 5 2>&1 < /dev/null | grep -v amdgpu.ids > $O/train_step.txt; cat $O/train_step.txt
 if [ "${PROFILE:-1}" = "1" ]; then
-  timeout 600 bash tools/gpu_profile.sh 256 16 ${ROUND}${TAG}_256_b16 > $O/profile_256.log 2>&1; tail -25 $O/profile_256.log
-  timeout 600 bash tools/gpu_profile.sh 512 8 ${ROUND}${TAG}_512_b8 > $O/profile_512.log 2>&1; tail -25 $O/profile_512.log
+  timeout 900 bash tools/gpu_profile.sh 256 16 ${ROUND}${TAG}_256_b16 > $O/profile_256.log 2>&1; tail -25 $O/profile_256.log
+  timeout 900 bash tools/gpu_profile.sh 512 8 ${ROUND}${TAG}_512_b8 > $O/profile_512.log 2>&1; tail -25 $O/profile_512.log
 fi
