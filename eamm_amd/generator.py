@@ -152,6 +152,7 @@ class OcclusionAwareGenerator(nn.Module):
         self._engine_key = None
         self._train_engine: Optional[Engine] = None
         self._train_key = None
+        self._train_weight_changes = 0     # graph-free .train() forwards that found the convolution weights changed since the last
         # .train() mode: replicas for the BatchNorm statistics (None: the world group when torch.distributed runs with more
         # than one rank -- the analogue of DataParallel replicating the reference module); sync_batchnorm forces the
         # replicas' formula on or off (sync_batchnorm/batchnorm.py:48-53 vs :55-125)
@@ -233,8 +234,33 @@ class OcclusionAwareGenerator(nn.Module):
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.process_group)
             t.copy_(h)
 
+    def _train_weights_keep_changing(self, height, width) -> bool:
+        """A fine-tuning loop that mixes optimiser steps with graph-free .train() forwards (validation passes in training mode)
+        would rebuild the training engine -- allocation, state_dict copy, filter repack: hundreds of milliseconds -- after every
+        step.  From the second such change on, those forwards take the operator composition under no_grad instead
+        (it packs filters per call on the device, 6-17 us per layer) and the idle engine is freed."""
+        e = self._train_engine
+        if e is None or self._train_key is None or self._train_key[1:3] != (height, width):
+            return False
+        conv_version = tuple((id(store[key]), store[key]._version) for store, key, name in self._tensor_slots()
+                             if ".norm" not in name and store[key] is not None)
+        if conv_version == self._train_key[3]:
+            return False
+        self._train_weight_changes += 1
+        if self._train_weight_changes < 2:
+            return False
+        e.close()
+        self._train_engine = self._train_key = None
+        return True
+
     def _forward_train(self, source_image, kp_driving, kp_source):
         b, _, hh, ww = source_image.shape
+        if self._train_weight_changes >= 2 or self._train_weights_keep_changing(hh, ww):
+            from . import train_graph
+            out = train_graph.forward_train(self, source_image, kp_driving, kp_source)      # (the caller holds torch.no_grad())
+            self._bump_running_stats()
+            self._src_ref = None
+            return {k: out[k] for k in ("mask", "sparse_deformed", "occlusion_map", "deformed", "prediction") if k in out}
         e = self._ensure_train_engine(hh, ww, b)
         world = self._replicas()
         sync = world > 1 if self.sync_batchnorm is None else bool(self.sync_batchnorm)

@@ -248,3 +248,27 @@ def test_gpu_train_forward_constructor_variants(name):
     new = gen.state_dict()
     for p in stats:
         assert float((new[p + ".running_mean"].cpu() - stats[p][0]).abs().max()) <= TOL_STAT, (name, p)
+
+
+@pytest.mark.gpu
+def test_gpu_train_forward_while_the_weights_keep_changing():
+    """ADVICE r03: graph-free .train() forwards between optimiser steps.  The first weight change rebuilds the training engine;
+    from the second on the module takes the operator composition under no_grad (no engine rebuild per step) -- same outputs
+    as the oracle's training branch on the CURRENT weights each time, running statistics moving."""
+    cfg = tiny_config()
+    src, kp_s, kp_d = inputs(3)
+    gen = _make(cfg, 1234).train()
+    routes = []
+    for step in range(4):
+        if step:
+            with torch.no_grad():                      # an optimiser step: in-place updates bump the version counters
+                gen.bottleneck.r0.conv1.weight.mul_(1.01)
+                gen.up_blocks[0].conv.bias.add_(0.01)
+        sd_now = {k: v.detach().cpu().clone() for k, v in gen.state_dict().items()}
+        out = gen(src.to(DEV), kp_source=_cuda(kp_s), kp_driving=_cuda(kp_d))
+        assert not out["prediction"].requires_grad
+        routes.append("engine" if gen._train_engine is not None else "graph")
+        ref, _ = orc.generator_forward_train(sd_now, cfg, src, kp_d, kp_s, parallel=False)
+        for k in KEYS:
+            assert float((out[k].cpu() - ref[k]).abs().max()) <= (2e-4 if k == "deformed" else 4e-5), (step, k)
+    assert routes == ["engine", "engine", "graph", "graph"], routes
