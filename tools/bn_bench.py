@@ -51,12 +51,15 @@ n = 16
 src = synthetic_source(256, batch=n).cuda()
 kp_s = {k: v.cuda() for k, v in synthetic_keypoints(n, 10, seed=0).items()}
 kp_d = {k: v.cuda() for k, v in synthetic_keypoints(n, 10, seed=2).items()}
-for _ in range(2):
-    gen(src, kp_source=kp_s, kp_driving=kp_d)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(5):
-    gen(src, kp_source=kp_s, kp_driving=kp_d)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 5
-print(f"generator.train() forward, 256x256 x {n} pairs (encoder + 27 BatchNorm sites on batch statistics, raw-weight direct convolutions): "
-      f"{dt*1e3:.2f} ms = {n/dt:.0f} pairs/s")
+def timed(label):
+    for _ in range(2):
+        gen(src, kp_source=kp_s, kp_driving=kp_d)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5):
+        gen(src, kp_source=kp_s, kp_driving=kp_d)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f"generator.train() forward, 256x256 x {n} pairs, {label}: {dt*1e3:.2f} ms = {n/dt:.0f} pairs/s")
+with torch.no_grad():
+    timed("graph-free resumable engine under torch.no_grad() (encoder + 27 BatchNorm sites on batch statistics, raw-weight direct convolutions)")
+timed("with the autograd graph (differentiable HIP operators of train_graph: Winograd forms, fused BatchNorm + ReLU, motion_ops)")
