@@ -105,6 +105,12 @@ CONV_CASES = {
     # >= 2048 4x4 tiles: forward and data gradient on the F(4x4,3x3) Winograd kernels, filter transformed on the device
     "wino4_64_64":   dict(B=2, H=128, W=128, cin=64, cout=64, k=3, bias=True),
     "wino4_128_64":  dict(B=8, H=64, W=64, cin=128, cout=64, k=3, bias=True),          # transposed filter is not square
+    # the generator's ACTUAL layer shapes at 256x256, 2 pairs: the bottleneck convolution (512 tiles: the Winograd
+    # weight-gradient form and the split-group F(4x4) forward / data gradient), the last up block's convolution (after x2), the
+    # 7x7 on 64 channels at full resolution (filter-row weight gradient, W % 32 == 0)
+    "gen_bottleneck_2x64x64":   dict(B=2, H=64, W=64, cin=256, cout=256, k=3, bias=True),
+    "gen_up1_2x256x256":        dict(B=2, H=256, W=256, cin=128, cout=64, k=3, bias=True),
+    "gen_7x7_2x256x256_64_32":  dict(B=2, H=256, W=256, cin=64, cout=32, k=7, bias=True),
 }
 
 
