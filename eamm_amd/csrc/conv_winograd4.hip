@@ -159,6 +159,7 @@ struct Wino4Args {
     float* out;            // NHWC [B,H,W,Cout]
     int groups;            // > 1: the six rows of transform points are split over `groups` workgroups per tile (small M)
     float* zout;           // groups > 1: [24][Mq][Cout] x-folded products Z[i][q], finished by wino4_output_transform_kernel
+    float* epi_scratch;    // DBG 30 (timing experiment, EAMM_WINO4_EPI_V): the epilogue also writes 2.25 x the output here
 };
 
 __constant__ float WINO4_AT[4][8] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f},
@@ -477,6 +478,16 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
             v = v + r4;
             v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rso, e_off[k], soff, 0);
+            if constexpr (DBG == 30) {
+                // UPPER BOUND of "the producing epilogue writes the next convolution's V" (VERDICT r03 route (a)): the bytes of V
+                // (36 / 16 = 2.25 x the output) leave from here -- 9 extra 16-byte stores per 4 rounds -- without the transform's
+                // arithmetic and without the halo exchange; the caller skips the standalone transform.  Wrong results.
+                const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc((void*)p.epi_scratch, 0, 3u * out_bytes, 0x00020000);
+                constexpr int extra = py == 3 ? 3 : 2;
+                static_for<extra>([&](auto jc) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rse, e_off[k], soff + decltype(jc)::value * out_bytes, 0);
+                });
+            }
         }
     });
 }
@@ -649,6 +660,8 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     if (groups > 1 && zbuf == nullptr) return hipErrorInvalidValue;
     a.groups = groups;
     a.zout = groups > 1 ? zbuf : nullptr;
+    a.epi_scratch = (variant == 50 && groups == 1) ? zbuf : nullptr;
+    if (variant == 50 && a.epi_scratch == nullptr) variant = 3;
     const size_t vb = (size_t)36 * a.Mq * a.C * sizeof(float), ub = wino4_packed_elems(L.Cout, L.Cin, BN) * sizeof(float);
     if (vb >= 0xFFFFF000ull || ub >= 0xFFFFF000ull) return hipErrorInvalidValue;
     a.v_bytes = (unsigned)vb;
@@ -658,6 +671,7 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     if (narrow) variant = 30;
     switch (variant) {   // (chunks per barrier, ring depth, MFMAs per DMA piece)
         case 30: e = wino4_launch_variant<4, 2, 4, 0, 2>(a, stream); break;
+        case 50: e = sub4 ? wino4_launch_variant<4, 2, 8, 30>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream); break;
         case 0: e = sub4 ? wino4_launch_variant<4, 2, 4>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream); break;
         case 1: e = wino4_launch_variant<2, 2, 4>(a, stream); break;
         case 2: e = wino4_launch_variant<2, 3, 4>(a, stream); break;

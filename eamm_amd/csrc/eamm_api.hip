@@ -127,6 +127,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->bneck_chains = std::max(1, std::min(c->bneck_chains, 16));
     c->bneck_stagger = env_int("EAMM_BNECK_STAGGER", c->bneck_stagger);
     c->warp_joint = env_int("EAMM_WARP_JOINT", c->warp_joint);
+    c->epi_v = env_int("EAMM_WINO4_EPI_V", c->epi_v);
     c->pass_chains_min_frames = env_int("EAMM_PASS_CHAINS_MIN_FRAMES", c->pass_chains_min_frames);
     c->pass_chains_min_blocks = env_int("EAMM_PASS_CHAINS_MIN_BLOCKS", c->pass_chains_min_blocks);
     c->head_col7_min_tiles = env_int("EAMM_HEAD_COL7_MIN_TILES", c->head_col7_min_tiles);
@@ -362,6 +363,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
         }
     if (!c->wres1.empty() && (rc = dev_alloc(c, &c->wino_v, v_elems))) return rc;
     if (!c->w4res1.empty() && (rc = dev_alloc(c, &c->wino_z, z_elems))) return rc;
+    if (c->epi_v && !c->w4res1.empty() && (rc = dev_alloc(c, &c->epi_scratch, (size_t)3 * c->cfg.max_frames * c->hf * c->wf * c->Cb))) return rc;
     c->up_buf.resize(c->nd);
     for (int i = 0; i < c->nd; ++i)
         if ((rc = dev_alloc(c, &c->up_buf[i], F * (hwf << (2 * (i + 1))) * c->up_c[i]))) return rc;
@@ -845,14 +847,19 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         if (wino4) {
             const bool stagger = chained && c->bneck_stagger && c->ev_stagger && i == 0;
             if (stagger && chain_idx > 0) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_stagger, 0));
-            HIP_TRY(c, wino4_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, v.wino_v, s));
+            // EAMM_WINO4_EPI_V (timing experiment, wrong results): only the stage's FIRST transform runs (every GEMM then reads that
+            // V: realistic operand values), and the GEMMs' epilogues write V-sized extra output instead (variant 50)
+            const bool epi = c->epi_v && c->epi_scratch && w4g == 1;
+            float* escr = epi ? c->epi_scratch + (size_t)3 * (v.xa - c->xa) : v.wino_z;
+            const int wvar = epi ? 50 : c->wino4_variant;
+            if (!epi || i == 0) HIP_TRY(c, wino4_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, v.wino_v, s));
             if (stagger && chain_idx == 0) HIP_TRY(c, hipEventRecord(c->ev_stagger, s));
             SUB_MARK();
-            HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], v.wino_v, n, hf, wf, ACT_RELU, nullptr, v.tmp, s, c->wino4_variant, w4g, v.wino_z));
+            HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], v.wino_v, n, hf, wf, ACT_RELU, nullptr, v.tmp, s, wvar, w4g, escr));
             SUB_MARK();
-            HIP_TRY(c, wino4_transform_launch(v.tmp, nullptr, nullptr, n, hf, wf, c->Cb, v.wino_v, s));
+            if (!epi) HIP_TRY(c, wino4_transform_launch(v.tmp, nullptr, nullptr, n, hf, wf, c->Cb, v.wino_v, s));
             SUB_MARK();
-            HIP_TRY(c, wino4_gemm_launch(c->w4res2[i], v.wino_v, n, hf, wf, ACT_NONE, x, xn, s, c->wino4_variant, w4g, v.wino_z));   // out += x
+            HIP_TRY(c, wino4_gemm_launch(c->w4res2[i], v.wino_v, n, hf, wf, ACT_NONE, x, xn, s, wvar, w4g, escr));   // out += x
         } else {
             HIP_TRY(c, wino_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, v.wino_v, s));
             SUB_MARK();

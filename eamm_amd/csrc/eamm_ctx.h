@@ -45,6 +45,8 @@ struct eamm_ctx : eamm::CtxBase {
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_stagger = nullptr;       // recorded by the first chain after its first bottleneck input transform
     hipEvent_t ev_warp = nullptr;          // recorded by the first chain behind the joint warp launch (EAMM_WARP_JOINT)
+    int epi_v = 0;                         // EAMM_WINO4_EPI_V=1: timing experiment (wrong results): see conv_winograd4.hip DBG 30
+    float* epi_scratch = nullptr;
     int warp_joint = 0;                    // one feature-warp launch for all chains' frames
     int bneck_stagger = 0;                 // EAMM_BNECK_STAGGER=1: the other whole-pass chains start their bottleneck stage behind that event, so the
                                            // chains' HBM-bound input transforms run beside the other chain's GEMM instead of beside each other
