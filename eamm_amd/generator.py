@@ -24,6 +24,7 @@ encoder (the reference recomputes it per frame, generator.py:61-63 inside demo.p
 from __future__ import annotations
 
 import operator
+import os
 import warnings
 from typing import Dict, Iterable, Optional
 
@@ -153,6 +154,11 @@ class OcclusionAwareGenerator(nn.Module):
         self._train_engine: Optional[Engine] = None
         self._train_key = None
         self._train_weight_changes = 0     # graph-free .train() forwards that found the convolution weights changed since the last
+        # route of the graph-free (torch.no_grad()) .train() forward: "engine" = the library's resumable batch-statistics pass
+        # (eamm_train_begin / eamm_train_next: one handle, saved plan, direct convolutions: 15.7 ms per 16 pairs at 256x256),
+        # "operators" = the differentiable operator composition under no_grad (Winograd forms, fused BatchNorm: 9.6 ms; packs its
+        # filters per call).  EAMM_TRAIN_ROUTE overrides the default.
+        self.train_route = os.environ.get("EAMM_TRAIN_ROUTE", "engine")
         # .train() mode: replicas for the BatchNorm statistics (None: the world group when torch.distributed runs with more
         # than one rank -- the analogue of DataParallel replicating the reference module); sync_batchnorm forces the
         # replicas' formula on or off (sync_batchnorm/batchnorm.py:48-53 vs :55-125)
@@ -281,7 +287,7 @@ class OcclusionAwareGenerator(nn.Module):
 
     def _forward_train(self, source_image, kp_driving, kp_source):
         b, _, hh, ww = source_image.shape
-        if self._train_weight_changes >= 2 or self._train_weights_keep_changing(hh, ww):
+        if self.train_route == "operators" or self._train_weight_changes >= 2 or self._train_weights_keep_changing(hh, ww):
             from . import train_graph
             out = train_graph.forward_train(self, source_image, kp_driving, kp_source)      # (the caller holds torch.no_grad())
             self._bump_running_stats()

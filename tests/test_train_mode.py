@@ -251,6 +251,19 @@ def test_gpu_train_forward_constructor_variants(name):
 
 
 @pytest.mark.gpu
+def test_gpu_train_forward_operator_route_matches_reference_fixture():
+    """``train_route = "operators"``: the graph-free .train() forward on the differentiable operators under no_grad (the faster
+    of the two routes) against the same reference fixture as the engine's resumable pass."""
+    z, names, n, _ = fixture()
+    src, kp_s, kp_d = inputs(n)
+    gen = _make(tiny_config(), int(z["weight_seed"])).train()
+    gen.train_route = "operators"
+    out = gen(src.to(DEV), kp_source=_cuda(kp_s), kp_driving=_cuda(kp_d))
+    assert gen._train_engine is None and not out["prediction"].requires_grad
+    _check(out, gen, z, names, "single")
+
+
+@pytest.mark.gpu
 def test_gpu_train_forward_while_the_weights_keep_changing():
     """ADVICE r03: graph-free .train() forwards between optimiser steps.  The first weight change rebuilds the training engine;
     from the second on the module takes the operator composition under no_grad (no engine rebuild per step) -- same outputs
