@@ -166,6 +166,16 @@ class OcclusionAwareGenerator(nn.Module):
         self.sync_batchnorm: Optional[bool] = None
         # (parameters keep requires_grad=True as in the reference: the optimiser of train.py:136 sees every one of them)
 
+    def __getstate__(self):
+        """copy.deepcopy / pickling: the library handles (and the caches keyed on them) belong to THIS object; a copy builds its
+        own at its first forward."""
+        state = dict(self.__dict__)
+        for k in ("_engine", "_engine_key", "_train_engine", "_train_key", "_src_ref", "_src_engine", "_slots", "_slots_epoch", "_fast_key"):
+            if k in state:
+                state[k] = None
+        state["_src_version"] = state["_src_generation"] = -1
+        return state
+
     # -- engine management ---------------------------------------------------------------------------
     def _tensor_slots(self):
         """(owner dict, key, state_dict name) of every parameter and buffer, collected once: reading the LIVE dicts each call

@@ -429,3 +429,22 @@ def test_odd_frame_counts_across_the_chain_thresholds(n):
         with torch.no_grad():
             ref = orc.generator_forward(sd, cfg, src, {k: v[t:t + 1] for k, v in kp_d.items()}, kp_s)["prediction"]
         assert float((part[t].cpu() - ref[0]).abs().max()) <= TOL["prediction"], (n, t)
+
+
+def test_deepcopy_of_a_module_with_a_live_engine():
+    """a copy must not share (or try to copy) the library handle, nor read the original's tensors."""
+    import copy
+    cfg = tiny_config()
+    gen = OcclusionAwareGenerator(**cfg)
+    gen.load_state_dict(synthetic_state_dict(cfg, seed=1234), strict=True)
+    gen = gen.to(DEV).eval()
+    src = synthetic_source(64, seed=1).to(DEV)
+    kp_s, kp_d = cuda(synthetic_keypoints(1, 10, seed=0)), cuda(synthetic_keypoints(1, 10, seed=2))
+    a = gen(src, kp_source=kp_s, kp_driving=kp_d)["prediction"].clone()
+    twin = copy.deepcopy(gen)
+    assert twin.engine is None and gen.engine is not None
+    with torch.no_grad():
+        twin.final.bias.add_(0.25)                                   # the copy's own tensors
+    b = twin(src, kp_source=kp_s, kp_driving=kp_d)["prediction"]
+    assert twin.engine is not gen.engine and float((a - b).abs().max()) > 1e-3
+    assert torch.equal(gen(src, kp_source=kp_s, kp_driving=kp_d)["prediction"], a)   # the original is untouched
