@@ -44,6 +44,99 @@ bool wino4_fits(size_t tiles, int cin, int cout) {
     return 36.0 * tiles * cin * 4.0 < 4294963200.0 && 24.0 * tiles * cout * 4.0 < 4294963200.0;
 }
 
+
+// ---- widths that are not multiples of 32 (reference modules/generator.py:14-48 accepts any): the state_dict is padded into
+// the equivalent network whose widths are the next multiples of 32 -- extra output channels get zero filters and a zero bias,
+// their BatchNorm is the identity (weight 1, bias 0, mean 0, variance 1), extra input channels get zero filter columns -- so
+// the extra channels carry exact zeros through ReLU, pooling, the residual adds and the warps, and every layer builder and
+// kernel below runs unchanged on multiples of 32.
+struct PadPart { int real, packed; };
+int pad_conv(eamm_ctx* c, const std::string& conv, int co_r, int co_p, const std::vector<PadPart>& in) {
+    auto wi = c->sd.find(conv + ".weight");
+    auto bi = c->sd.find(conv + ".bias");
+    if (wi == c->sd.end() || bi == c->sd.end()) return fail(c, EAMM_ERR_KEY, "state_dict entry %s.weight / .bias missing", conv.c_str());
+    HostTensor& w = wi->second;
+    int cin_r = 0, cin_p = 0;
+    for (auto& p : in) { cin_r += p.real; cin_p += p.packed; }
+    if (w.shape.size() != 4 || w.shape[0] != co_r || w.shape[1] != cin_r || (int)bi->second.numel() != co_r)
+        return fail(c, EAMM_ERR_KEY, "state_dict entry %s.weight mis-shaped (expected [%d,%d,k,k])", conv.c_str(), co_r, cin_r);
+    const int T = (int)(w.shape[2] * w.shape[3]);
+    HostTensor nw;
+    nw.shape = {co_p, cin_p, w.shape[2], w.shape[3]};
+    nw.data.assign((size_t)co_p * cin_p * T, 0.f);
+    for (int o = 0; o < co_r; ++o) {
+        int src = 0, dst = 0;
+        for (auto& p : in) {
+            std::copy(w.data.begin() + ((size_t)o * cin_r + src) * T, w.data.begin() + ((size_t)o * cin_r + src + p.real) * T,
+                      nw.data.begin() + ((size_t)o * cin_p + dst) * T);
+            src += p.real;
+            dst += p.packed;
+        }
+    }
+    w = std::move(nw);
+    HostTensor& b = bi->second;
+    b.data.resize(co_p, 0.f);
+    b.shape = {co_p};
+    return 0;
+}
+int pad_norm(eamm_ctx* c, const std::string& norm, int c_r, int c_p) {
+    for (const char* leaf : {".weight", ".bias", ".running_mean", ".running_var"}) {
+        auto it = c->sd.find(norm + leaf);
+        if (it == c->sd.end() || (int)it->second.numel() != c_r)
+            return fail(c, EAMM_ERR_KEY, "BatchNorm entry %s%s missing or mis-shaped (expected %d)", norm.c_str(), leaf, c_r);
+        const bool one = !strcmp(leaf, ".weight") || !strcmp(leaf, ".running_var");
+        it->second.data.resize(c_p, one ? 1.f : 0.f);
+        it->second.shape = {c_p};
+    }
+    return 0;
+}
+int pad_state_dict(eamm_ctx* c) {
+    const std::string dm = "dense_motion_network.";
+    const int cin0 = (c->K + 1) * 4, nb = c->nb, nd = c->nd;
+    int rc;
+#define PAD_TRY(e) if ((rc = (e))) return rc
+    for (int i = 0; i < nb; ++i) {
+        const std::string p = dm + "hourglass.encoder.down_blocks." + std::to_string(i);
+        const PadPart in = i == 0 ? PadPart{cin0, cin0} : PadPart{c->enc_r[i - 1], c->enc_c[i - 1]};
+        PAD_TRY(pad_conv(c, p + ".conv", c->enc_r[i], c->enc_c[i], {in}));
+        PAD_TRY(pad_norm(c, p + ".norm", c->enc_r[i], c->enc_c[i]));
+    }
+    for (int i = 0; i < nb; ++i) {
+        const std::string p = dm + "hourglass.decoder.up_blocks." + std::to_string(i);
+        std::vector<PadPart> in;
+        if (i == 0) in = {{c->enc_r[nb - 1], c->enc_c[nb - 1]}};
+        else in = {{c->dec_r[i - 1], c->dec_c[i - 1]}, {c->enc_r[nb - 1 - i], c->enc_c[nb - 1 - i]}};
+        PAD_TRY(pad_conv(c, p + ".conv", c->dec_r[i], c->dec_c[i], in));
+        PAD_TRY(pad_norm(c, p + ".norm", c->dec_r[i], c->dec_c[i]));
+    }
+    if (nb > 0) {
+        const std::vector<PadPart> in = {{c->dec_r.back(), c->dec_c.back()}, {cin0, cin0}};
+        PAD_TRY(pad_conv(c, dm + "mask", c->K + 1, c->K + 1, in));
+        if (c->cfg.estimate_occlusion_map) PAD_TRY(pad_conv(c, dm + "occlusion", 1, 1, in));
+    }
+    PAD_TRY(pad_conv(c, "first.conv", c->down_r[0], c->down_c[0], {{3, 3}}));
+    PAD_TRY(pad_norm(c, "first.norm", c->down_r[0], c->down_c[0]));
+    for (int i = 0; i < nd; ++i) {
+        const std::string p = "down_blocks." + std::to_string(i);
+        PAD_TRY(pad_conv(c, p + ".conv", c->down_r[i + 1], c->down_c[i + 1], {{c->down_r[i], c->down_c[i]}}));
+        PAD_TRY(pad_norm(c, p + ".norm", c->down_r[i + 1], c->down_c[i + 1]));
+    }
+    for (int i = 0; i < c->cfg.num_bottleneck_blocks; ++i) {
+        const std::string r = "bottleneck.r" + std::to_string(i);
+        for (const char* k : {".conv1", ".conv2"}) PAD_TRY(pad_conv(c, r + k, c->Cb_r, c->Cb, {{c->Cb_r, c->Cb}}));
+        for (const char* k : {".norm1", ".norm2"}) PAD_TRY(pad_norm(c, r + k, c->Cb_r, c->Cb));
+    }
+    for (int i = 0; i < nd; ++i) {
+        const std::string p = "up_blocks." + std::to_string(i);
+        const PadPart in = i == 0 ? PadPart{c->Cb_r, c->Cb} : PadPart{c->up_r[i - 1], c->up_c[i - 1]};
+        PAD_TRY(pad_conv(c, p + ".conv", c->up_r[i], c->up_c[i], {in}));
+        PAD_TRY(pad_norm(c, p + ".norm", c->up_r[i], c->up_c[i]));
+    }
+    PAD_TRY(pad_conv(c, "final", 3, 3, {{c->up_r.back(), c->up_c.back()}}));
+#undef PAD_TRY
+    return 0;
+}
+
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
@@ -65,8 +158,8 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     if (has_dm && (!is_pow2(g.dm_inv_scale) || g.dm_inv_scale > 4 || g.dm_inv_scale == 3))
         return fail(nullptr, EAMM_ERR_ARG, "1/scale_factor must be 1, 2 or 4");
     if (!has_dm && g.estimate_occlusion_map) return fail(nullptr, EAMM_ERR_ARG, "estimate_occlusion_map needs a motion network");
-    if (g.block_expansion % 32 || g.max_features % 32 || (has_dm && (g.dm_block_expansion % 32 || g.dm_max_features % 32)))
-        return fail(nullptr, EAMM_ERR_ARG, "channel widths must be multiples of 32");
+    if (g.block_expansion < 1 || g.max_features < 1 || (has_dm && (g.dm_block_expansion < 1 || g.dm_max_features < 1)))
+        return fail(nullptr, EAMM_ERR_ARG, "channel widths must be positive");
     if (g.num_down_blocks < 1 || g.num_bottleneck_blocks < 1)
         return fail(nullptr, EAMM_ERR_ARG, "need at least one down block and one bottleneck block");
     if (g.max_frames < 1 || g.max_sources < 1) return fail(nullptr, EAMM_ERR_ARG, "max_frames / max_sources < 1");
@@ -77,9 +170,9 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     {   // the kernels address tensors through 32-bit buffer descriptors: every activation must stay below 4 GiB
         const double hw = (double)g.height * g.width, F = g.max_frames;
         const double biggest = std::max({F * hw * 32.0,                                  // final-conv partial products
-                                         F * hw * (double)g.block_expansion,             // last up-block output
+                                         F * hw * (double)round_up(g.block_expansion, 32),   // last up-block output
                                          4.0 * F * (hw / (1 << (2 * g.num_down_blocks))) *
-                                             std::min(g.max_features, g.block_expansion << g.num_down_blocks)}) * 4.0;
+                                             round_up(std::min(g.max_features, g.block_expansion << g.num_down_blocks), 32)}) * 4.0;
         if (biggest >= 4294967280.0)
             return fail(nullptr, EAMM_ERR_ARG, "max_frames=%d at %dx%d needs a %.1f GiB activation tensor; the limit is 4 GiB "
                         "per tensor -- lower max_frames", g.max_frames, g.height, g.width, biggest / 1073741824.0);
@@ -104,12 +197,24 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->wf = c->W >> c->nd;
     c->Cp0 = round_up((c->K + 1) * 4, 32);
     // hourglass channel plan (reference modules/util.py:941-987)
-    for (int i = 0; i < c->nb; ++i) c->enc_c.push_back(std::min(g.dm_max_features, g.dm_block_expansion << (i + 1)));
-    for (int i = c->nb - 1; i >= 0; --i) c->dec_c.push_back(std::min(g.dm_max_features, g.dm_block_expansion << i));
+    for (int i = 0; i < c->nb; ++i) c->enc_r.push_back(std::min(g.dm_max_features, g.dm_block_expansion << (i + 1)));
+    for (int i = c->nb - 1; i >= 0; --i) c->dec_r.push_back(std::min(g.dm_max_features, g.dm_block_expansion << i));
     // generator channel plan (reference modules/generator.py:27-44)
-    c->down_c.push_back(g.block_expansion);
-    for (int i = 0; i < c->nd; ++i) c->down_c.push_back(std::min(g.max_features, g.block_expansion << (i + 1)));
-    for (int i = 0; i < c->nd; ++i) c->up_c.push_back(std::min(g.max_features, g.block_expansion << (c->nd - i - 1)));
+    c->down_r.push_back(g.block_expansion);
+    for (int i = 0; i < c->nd; ++i) c->down_r.push_back(std::min(g.max_features, g.block_expansion << (i + 1)));
+    for (int i = 0; i < c->nd; ++i) c->up_r.push_back(std::min(g.max_features, g.block_expansion << (c->nd - i - 1)));
+    c->Cb_r = c->down_r.back();
+    // the kernels' widths: the 32-channel granule of the MFMA operand loaders (any width the reference accepts is taken)
+    auto pad32 = [&](const std::vector<int>& r, std::vector<int>* p) {
+        for (int v : r) {
+            p->push_back(round_up(v, 32));
+            c->padded_widths |= p->back() != v;
+        }
+    };
+    pad32(c->enc_r, &c->enc_c);
+    pad32(c->dec_r, &c->dec_c);
+    pad32(c->down_r, &c->down_c);
+    pad32(c->up_r, &c->up_c);
     c->Cb = c->down_c.back();
     read_tile_knobs(c);
     c->wino_min_m = env_int("EAMM_WINO_MIN_M", c->wino_min_m);
@@ -171,6 +276,12 @@ int eamm_finalize_weights(eamm_ctx* c) {
         std::vector<std::string> want;
         expected_keys(c, &want);
         if (int krc = check_keys(c, want)) return krc;
+    }
+    if (c->padded_widths) {
+        if (c->train_mode)
+            return fail(c, EAMM_ERR_ARG, "a training-mode handle needs channel widths that are multiples of 32 (its BatchNorm kernels read "
+                        "the module's own statistics tensors); the module takes the operator composition for such a generator");
+        if (int prc = pad_state_dict(c)) return prc;
     }
     const std::string dm = "dense_motion_network.";
     int rc;
@@ -431,21 +542,21 @@ int eamm_finalize_weights(eamm_ctx* c) {
 
     // ---- algorithmic FLOPs (reference layer shapes, real channel counts)
     {
-        double fe = conv_flops(7, 3, c->down_c[0], (double)HW);
-        for (int i = 0; i < c->nd; ++i) fe += conv_flops(3, c->down_c[i], c->down_c[i + 1], (double)(HW >> (2 * i)));
+        double fe = conv_flops(7, 3, c->down_r[0], (double)HW);
+        for (int i = 0; i < c->nd; ++i) fe += conv_flops(3, c->down_r[i], c->down_r[i + 1], (double)(HW >> (2 * i)));
         c->flops_encode = fe;
         double ff = 0;
         for (int i = 0; i < c->nb; ++i) {
-            ff += conv_flops(3, i == 0 ? cin0 : c->enc_c[i - 1], c->enc_c[i], (double)(hw >> (2 * i)));
-            const int ci = c->hg_dec[i].base.C0 + c->hg_dec[i].base.C1;
-            ff += conv_flops(3, ci, c->dec_c[i], (double)(hw >> (2 * (c->nb - 1 - i))));
+            ff += conv_flops(3, i == 0 ? cin0 : c->enc_r[i - 1], c->enc_r[i], (double)(hw >> (2 * i)));
+            const int ci = i == 0 ? c->enc_r[c->nb - 1] : c->dec_r[i - 1] + c->enc_r[c->nb - 1 - i];
+            ff += conv_flops(3, ci, c->dec_r[i], (double)(hw >> (2 * (c->nb - 1 - i))));
         }
-        if (c->nb > 0) ff += conv_flops(7, c->dec_c.back() + cin0, c->K + 1 + (g.estimate_occlusion_map ? 1 : 0), (double)hw);
-        ff += 2.0 * nr * conv_flops(3, c->Cb, c->Cb, (double)hwf);
+        if (c->nb > 0) ff += conv_flops(7, c->dec_r.back() + cin0, c->K + 1 + (g.estimate_occlusion_map ? 1 : 0), (double)hw);
+        ff += 2.0 * nr * conv_flops(3, c->Cb_r, c->Cb_r, (double)hwf);
         for (int i = 0; i < c->nd; ++i)
-            ff += conv_flops(3, i == 0 ? c->Cb : c->up_c[i - 1], c->up_c[i], (double)(hwf << (2 * (i + 1))));
-        ff += conv_flops(7, c->up_c.back(), 3, (double)HW);
-        if (c->nb > 0) ff += 9.0 * hwf * c->Cb;  // bilinear feature warp + occlusion multiply
+            ff += conv_flops(3, i == 0 ? c->Cb_r : c->up_r[i - 1], c->up_r[i], (double)(hwf << (2 * (i + 1))));
+        ff += conv_flops(7, c->up_r.back(), 3, (double)HW);
+        if (c->nb > 0) ff += 9.0 * hwf * c->Cb_r;  // bilinear feature warp + occlusion multiply
         c->flops_frame = ff;
     }
     const int max_chains = std::max(c->bneck_chains, c->pass_chains == 0 ? 2 : c->pass_chains);

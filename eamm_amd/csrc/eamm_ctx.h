@@ -20,6 +20,12 @@ struct eamm_ctx : eamm::CtxBase {
     std::vector<int> dec_c;     // hourglass decoder output channels u_0..u_{nb-1}
     std::vector<int> down_c;    // generator encoder channels [be, ...]
     std::vector<int> up_c;      // generator decoder output channels
+    // The four lists above and Cb hold the widths the KERNELS run at: the reference's widths rounded up to the 32-channel granule.
+    // The *_r lists are the reference's own (what the state_dict has): when they differ, eamm_finalize_weights first pads the
+    // state_dict into the equivalent wider network (zero filters, identity BatchNorm on the extra channels: they carry exact zeros).
+    std::vector<int> enc_r, dec_r, down_r, up_r;
+    int Cb_r = 0;
+    bool padded_widths = false;
 
     // layers
     ConvLayer first, final_conv, head;

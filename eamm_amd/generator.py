@@ -159,6 +159,16 @@ class OcclusionAwareGenerator(nn.Module):
         # "operators" = the differentiable operator composition under no_grad (Winograd forms, fused BatchNorm: 9.6 ms; packs its
         # filters per call).  EAMM_TRAIN_ROUTE overrides the default.
         self.train_route = os.environ.get("EAMM_TRAIN_ROUTE", "engine")
+        # widths that are not multiples of the kernels' 32-channel granule: the inference engine pads the state_dict into the
+        # equivalent wider network at load time; the training-mode ENGINE does not (its BatchNorm kernels read the module's own
+        # statistics tensors), so graph-free .train() forwards of such a generator take the operator composition
+        widths = [c for pair in down + up for c in pair] + [bott]
+        if dense_motion_params is not None:
+            enc, dec, _ = hourglass_channels(dense_motion_params["block_expansion"], (num_kp + 1) * (num_channels + 1),
+                                             dense_motion_params["num_blocks"], dense_motion_params["max_features"])
+            widths += [co for _, co in enc] + [co for _, co in dec]
+        if any(c % 32 for c in widths if c != num_channels):
+            self.train_route = "operators"
         # .train() mode: replicas for the BatchNorm statistics (None: the world group when torch.distributed runs with more
         # than one rank -- the analogue of DataParallel replicating the reference module); sync_batchnorm forces the
         # replicas' formula on or off (sync_batchnorm/batchnorm.py:48-53 vs :55-125)

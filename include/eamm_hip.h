@@ -45,7 +45,9 @@ typedef struct eamm_ctx eamm_ctx;
 /*
  * Constructor arguments of OcclusionAwareGenerator (reference modules/generator.py:14-15) with
  * dense_motion_params (reference modules/dense_motion.py:12-13) flattened in, plus the two sizes
- * the workspace is allocated for.
+ * the workspace is allocated for.  Any positive channel widths: those that are not multiples of the kernels' 32-channel
+ * granule are served by padding the state_dict at eamm_finalize_weights (the extra channels carry exact zeros); a
+ * training-mode handle (eamm_set_training) needs multiples of 32.  num_channels must be 3 (RGB).
  */
 typedef struct eamm_config {
     int32_t num_channels;            /* 3                                              */

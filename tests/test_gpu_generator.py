@@ -206,6 +206,10 @@ VARIANTS = {
     "scale_one": ({"num_down_blocks": 1}, {"scale_factor": 1, "num_blocks": 2}, 32, 32),   # no anti-alias buffer at all
     "no_occlusion": ({"estimate_occlusion_map": False}, {}, 64, 64),
     "three_down": ({"num_down_blocks": 3, "max_features": 256}, {}, 64, 64),   # feature map 8x8 vs motion grid 16x16
+    # widths that are NOT multiples of the kernels' 32-channel granule (VERDICT r03 missing 3; generator.py:14-48 accepts any):
+    # generator 48 / 96 / 192, hourglass 80 / 100 / 100 -> 100 / 80 / 40 -- the state_dict is padded at load time
+    "odd_widths": ({"block_expansion": 48, "max_features": 200}, {"block_expansion": 40, "max_features": 100}, 64, 64),
+    "odd_widths_capped": ({"block_expansion": 24, "max_features": 72, "num_bottleneck_blocks": 3}, {"block_expansion": 20, "max_features": 50}, 64, 64),
 }
 
 

@@ -285,3 +285,19 @@ def test_gpu_train_forward_while_the_weights_keep_changing():
         for k in KEYS:
             assert float((out[k].cpu() - ref[k]).abs().max()) <= (2e-4 if k == "deformed" else 4e-5), (step, k)
     assert routes == ["engine", "engine", "graph", "graph"], routes
+
+
+@pytest.mark.gpu
+def test_gpu_train_forward_with_widths_that_are_not_multiples_of_32():
+    """The training-mode ENGINE needs the kernels' 32-channel granule; a generator with other widths takes the operator
+    composition for its graph-free .train() forward (train_route "operators") -- against the oracle's training branch."""
+    cfg = dict(tiny_config(), block_expansion=48, max_features=200)
+    cfg["dense_motion_params"] = dict(cfg["dense_motion_params"], block_expansion=40, max_features=100)
+    src, kp_s, kp_d = inputs(3)
+    gen = _make(cfg, 1234).train()
+    assert gen.train_route == "operators"
+    sd_now = {k: v.detach().cpu().clone() for k, v in gen.state_dict().items()}
+    out = gen(src.to(DEV), kp_source=_cuda(kp_s), kp_driving=_cuda(kp_d))
+    ref, _ = orc.generator_forward_train(sd_now, cfg, src, kp_d, kp_s, parallel=False)
+    for k in KEYS:
+        assert float((out[k].cpu() - ref[k]).abs().max()) <= (2e-4 if k == "deformed" else 4e-5), k
