@@ -11,7 +11,8 @@
 //     coalesced rows of each tensor.  conv_bias_grad_kernel: db[co] = sum_p dY[p][co].
 //   The DATA gradient of such a convolution is itself a "same" convolution of dY with the transposed, flipped filter, i.e. the
 //   forward kernels (eamm_op_conv) on repacked weights; BatchNorm's backward is in batchnorm.hip.
-// These are the kernels; composing them into the generator's end-to-end backward is not done.
+// These are the kernels; eamm_amd/train_graph.py composes them (with batchnorm_nhwc.hip and motion_backward.hip) into the
+// generator's end-to-end backward: loss.backward() as in train.py:133.
 #include "conv_common.h"
 
 #include <algorithm>

@@ -10,7 +10,8 @@
 // The forward is therefore RESUMABLE: eamm_train_begin lays it out as a list of steps, eamm_train_next runs them up to the
 // next statistics hand-over and returns 1 with the buffer to reduce, 0 when the pass is complete.  Everything else of the
 // pass (anti-aliasing, heat-maps, sparse motions, flow head, warps, final convolution) is the evaluation path's kernels.
-// Forward only: the convolution / warp backward kernels are not built (the BatchNorm backward is: batchnorm.hip).
+// This file is the graph-free FORWARD; the backward operators live in backward.hip, conv7_thin.hip, batchnorm*.hip and
+// motion_backward.hip and are composed by eamm_amd/train_graph.py (which also offers this forward, `train_route = "operators"`).
 #include "eamm_ctx.h"
 
 namespace {
