@@ -232,6 +232,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->bneck_chains = std::max(1, std::min(c->bneck_chains, 16));
     c->bneck_stagger = env_int("EAMM_BNECK_STAGGER", c->bneck_stagger);
     c->warp_joint = env_int("EAMM_WARP_JOINT", c->warp_joint);
+    c->enc_cus_pct = std::max(1, env_int("EAMM_ENC_CUS_PCT", c->enc_cus_pct));
     c->epi_v = env_int("EAMM_WINO4_EPI_V", c->epi_v);
     c->pass_chains_min_frames = env_int("EAMM_PASS_CHAINS_MIN_FRAMES", c->pass_chains_min_frames);
     c->pass_chains_min_blocks = env_int("EAMM_PASS_CHAINS_MIN_BLOCKS", c->pass_chains_min_blocks);
@@ -822,6 +823,7 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
             const int nblk = ((tiles + 63) / 64) * L.ntiles;
             int cus = 256, g = 2;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            cus = cus * c->enc_cus_pct / 100;   // EAMM_ENC_CUS_PCT (experiment): the CU count the split of the point rows is sized for
             for (int gsel : {6, 3})
                 if (nblk * gsel <= cus) {
                     g = gsel;

@@ -51,6 +51,8 @@ struct eamm_ctx : eamm::CtxBase {
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_stagger = nullptr;       // recorded by the first chain after its first bottleneck input transform
     hipEvent_t ev_warp = nullptr;          // recorded by the first chain behind the joint warp launch (EAMM_WARP_JOINT)
+    int enc_cus_pct = 100;                 // EAMM_ENC_CUS_PCT: the hourglass encoder's F(4x4) point-row split is sized for this share of the chip's CUs
+                                           // (measured hg_enc ms per step: 25 %: 0.342, 50 %: 0.256, 100 %: 0.242, 200 %: 0.252, 400 %: 0.251)
     int epi_v = 0;                         // EAMM_WINO4_EPI_V=1: timing experiment (wrong results): see conv_winograd4.hip DBG 30
     float* epi_scratch = nullptr;
     int warp_joint = 0;                    // one feature-warp launch for all chains' frames
