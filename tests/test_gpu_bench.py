@@ -50,6 +50,9 @@ def test_bench_single_gpu_line():
     assert 15.0 < wp["executed_gflop_per_frame"] < d["config"]["flops_per_frame"]       # fewer multiplies than the reference's 86.7
     assert abs(wp["frac_chip_executed"] - wp["executed_gflop_per_frame"] * d["value"] / 157.3e3) < 5e-3 and wp["frac_chip_executed"] <= 1.0
     assert abs(sum(d["stage_ms_per_step"].values()) - d["ms_per_step"]) / d["ms_per_step"] < 0.05  # events ~ wall clock
+    # `value` is timed with the library's events OFF; the stage / roofline keys come from a second region of the same K steps
+    # with them on: the two regions' wall clocks agree (the events cost next to nothing)
+    assert abs(d["stage_region_ms_per_step"] - d["ms_per_step"]) / d["ms_per_step"] < 0.03
     w = d["roofline_warp"]
     assert w["bound"] == "hbm" and w["unit"] == "GB/s" and w["peak"] == 8000.0 and 0.1 < w["frac"] <= 1.0
     # bytes are those of the frames the TIMED launch covers (one chain's), 8.438 MB per frame
