@@ -186,7 +186,8 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
         e = min(stop, s + backend.batch)
         chunks.append(backend.run({k: v[s:e] for k, v in kp_driving.items()}, kp_source, uint8))
     backend.finish()
-    shape_tail = (height, width, 3) if uint8 else (3, height, width)
+    channels = int(getattr(getattr(backend, "generator", None), "num_channels", 3))   # (test backends without a generator: RGB)
+    shape_tail = (height, width, channels) if uint8 else (channels, height, width)
     dtype = torch.uint8 if uint8 else torch.float32
     local = torch.cat(chunks, dim=0) if chunks else torch.empty((0,) + shape_tail, dtype=dtype, device=backend.device)
     mark("compute_ms")

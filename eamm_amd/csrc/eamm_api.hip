@@ -92,13 +92,15 @@ int pad_norm(eamm_ctx* c, const std::string& norm, int c_r, int c_p) {
 }
 int pad_state_dict(eamm_ctx* c) {
     const std::string dm = "dense_motion_network.";
-    const int cin0 = (c->K + 1) * 4, nb = c->nb, nd = c->nd;
+    const int nb = c->nb, nd = c->nd;
+    // the hourglass input line: per motion (heat-map, image channels) -- C + 1 values of the reference land in the kernels' four
+    const std::vector<PadPart> motion_line((size_t)c->K + 1, PadPart{c->Cimg + 1, 4});
     int rc;
 #define PAD_TRY(e) if ((rc = (e))) return rc
     for (int i = 0; i < nb; ++i) {
         const std::string p = dm + "hourglass.encoder.down_blocks." + std::to_string(i);
-        const PadPart in = i == 0 ? PadPart{cin0, cin0} : PadPart{c->enc_r[i - 1], c->enc_c[i - 1]};
-        PAD_TRY(pad_conv(c, p + ".conv", c->enc_r[i], c->enc_c[i], {in}));
+        const std::vector<PadPart> in = i == 0 ? motion_line : std::vector<PadPart>{PadPart{c->enc_r[i - 1], c->enc_c[i - 1]}};
+        PAD_TRY(pad_conv(c, p + ".conv", c->enc_r[i], c->enc_c[i], in));
         PAD_TRY(pad_norm(c, p + ".norm", c->enc_r[i], c->enc_c[i]));
     }
     for (int i = 0; i < nb; ++i) {
@@ -110,11 +112,19 @@ int pad_state_dict(eamm_ctx* c) {
         PAD_TRY(pad_norm(c, p + ".norm", c->dec_r[i], c->dec_c[i]));
     }
     if (nb > 0) {
-        const std::vector<PadPart> in = {{c->dec_r.back(), c->dec_c.back()}, {cin0, cin0}};
+        std::vector<PadPart> in = {{c->dec_r.back(), c->dec_c.back()}};
+        in.insert(in.end(), motion_line.begin(), motion_line.end());
         PAD_TRY(pad_conv(c, dm + "mask", c->K + 1, c->K + 1, in));
         if (c->cfg.estimate_occlusion_map) PAD_TRY(pad_conv(c, dm + "occlusion", 1, 1, in));
+        if (c->cfg.dm_inv_scale != 1 && c->Cimg != 3) {   // anti-alias buffer [C,1,13,13] (util.py:1038): one filter per channel
+            auto it = c->sd.find(dm + "down.weight");
+            if (it == c->sd.end() || (int)it->second.numel() != c->Cimg * 169)
+                return fail(c, EAMM_ERR_KEY, "%sdown.weight must be [%d,1,13,13]", dm.c_str(), c->Cimg);
+            it->second.data.resize(3 * 169, 0.f);
+            it->second.shape = {3, 1, 13, 13};
+        }
     }
-    PAD_TRY(pad_conv(c, "first.conv", c->down_r[0], c->down_c[0], {{3, 3}}));
+    PAD_TRY(pad_conv(c, "first.conv", c->down_r[0], c->down_c[0], {{c->Cimg, 3}}));
     PAD_TRY(pad_norm(c, "first.norm", c->down_r[0], c->down_c[0]));
     for (int i = 0; i < nd; ++i) {
         const std::string p = "down_blocks." + std::to_string(i);
@@ -132,7 +142,7 @@ int pad_state_dict(eamm_ctx* c) {
         PAD_TRY(pad_conv(c, p + ".conv", c->up_r[i], c->up_c[i], {in}));
         PAD_TRY(pad_norm(c, p + ".norm", c->up_r[i], c->up_c[i]));
     }
-    PAD_TRY(pad_conv(c, "final", 3, 3, {{c->up_r.back(), c->up_c.back()}}));
+    PAD_TRY(pad_conv(c, "final", c->Cimg, 3, {{c->up_r.back(), c->up_c.back()}}));
 #undef PAD_TRY
     return 0;
 }
@@ -150,7 +160,9 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     if (!cfg || !out) return fail(nullptr, EAMM_ERR_ARG, "null argument");
     *out = nullptr;
     const eamm_config& g = *cfg;
-    if (g.num_channels != 3) return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 3 (got %d)", g.num_channels);
+    if (g.num_channels < 1 || g.num_channels > 3)
+        return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 1, 2 or 3 (got %d): the motion kernels keep a pixel's image channels in "
+                    "one float4 beside its heat-map value", g.num_channels);
     if (g.num_kp < 1 || g.num_kp + 2 > 32) return fail(nullptr, EAMM_ERR_ARG, "num_kp out of range");
     // dm_num_blocks == 0: a generator without a motion network (dense_motion_params=None, generator.py:22-23)
     const bool has_dm = g.dm_num_blocks > 0;
@@ -196,6 +208,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->hf = c->H >> c->nd;
     c->wf = c->W >> c->nd;
     c->Cp0 = round_up((c->K + 1) * 4, 32);
+    c->Cimg = g.num_channels;
     // hourglass channel plan (reference modules/util.py:941-987)
     for (int i = 0; i < c->nb; ++i) c->enc_r.push_back(std::min(g.dm_max_features, g.dm_block_expansion << (i + 1)));
     for (int i = c->nb - 1; i >= 0; --i) c->dec_r.push_back(std::min(g.dm_max_features, g.dm_block_expansion << i));
@@ -278,10 +291,11 @@ int eamm_finalize_weights(eamm_ctx* c) {
         expected_keys(c, &want);
         if (int krc = check_keys(c, want)) return krc;
     }
-    if (c->padded_widths) {
+    if (c->padded_widths || c->Cimg != 3) {
         if (c->train_mode)
-            return fail(c, EAMM_ERR_ARG, "a training-mode handle needs channel widths that are multiples of 32 (its BatchNorm kernels read "
-                        "the module's own statistics tensors); the module takes the operator composition for such a generator");
+            return fail(c, EAMM_ERR_ARG, "a training-mode handle needs three image channels and channel widths that are multiples of 32 "
+                        "(its BatchNorm kernels read the module's own statistics tensors); the module takes the operator composition "
+                        "for such a generator");
         if (int prc = pad_state_dict(c)) return prc;
     }
     const std::string dm = "dense_motion_network.";
@@ -442,6 +456,12 @@ int eamm_finalize_weights(eamm_ctx* c) {
     if ((rc = dev_alloc(c, &c->feat, S * hwf * c->Cb))) return rc;
     if ((rc = dev_alloc(c, &c->src_small, S * hw * 4))) return rc;
     if ((rc = dev_alloc(c, &c->src_full, S * 3 * HW))) return rc;
+    if (c->Cimg != 3) {   // the channels a source does not have stay zero for the handle's life (eamm_encode_source copies only the real ones)
+        HIP_TRY(c, hipMemset(c->src_full, 0, S * 3 * HW * sizeof(float)));
+        if ((rc = dev_alloc(c, &c->stage_pred, F * 3 * HW))) return rc;
+        if (c->nb > 0 && (rc = dev_alloc(c, &c->stage_deformed, F * 3 * HW))) return rc;
+        if (c->nb > 0 && (rc = dev_alloc(c, &c->stage_sparse, F * (c->K + 1) * 3 * hw))) return rc;
+    }
     if ((rc = dev_alloc(c, &c->src_nhwc, S * HW * c->Csrc))) return rc;
     c->enc_tmp.resize(c->nd);
     for (int i = 0; i < c->nd; ++i)  // enc_tmp[0] = first output @HxW; enc_tmp[i] = down[i-1] output
@@ -543,20 +563,21 @@ int eamm_finalize_weights(eamm_ctx* c) {
 
     // ---- algorithmic FLOPs (reference layer shapes, real channel counts)
     {
-        double fe = conv_flops(7, 3, c->down_r[0], (double)HW);
+        const int cin0_r = (c->K + 1) * (c->Cimg + 1);
+        double fe = conv_flops(7, c->Cimg, c->down_r[0], (double)HW);
         for (int i = 0; i < c->nd; ++i) fe += conv_flops(3, c->down_r[i], c->down_r[i + 1], (double)(HW >> (2 * i)));
         c->flops_encode = fe;
         double ff = 0;
         for (int i = 0; i < c->nb; ++i) {
-            ff += conv_flops(3, i == 0 ? cin0 : c->enc_r[i - 1], c->enc_r[i], (double)(hw >> (2 * i)));
+            ff += conv_flops(3, i == 0 ? cin0_r : c->enc_r[i - 1], c->enc_r[i], (double)(hw >> (2 * i)));
             const int ci = i == 0 ? c->enc_r[c->nb - 1] : c->dec_r[i - 1] + c->enc_r[c->nb - 1 - i];
             ff += conv_flops(3, ci, c->dec_r[i], (double)(hw >> (2 * (c->nb - 1 - i))));
         }
-        if (c->nb > 0) ff += conv_flops(7, c->dec_r.back() + cin0, c->K + 1 + (g.estimate_occlusion_map ? 1 : 0), (double)hw);
+        if (c->nb > 0) ff += conv_flops(7, c->dec_r.back() + cin0_r, c->K + 1 + (g.estimate_occlusion_map ? 1 : 0), (double)hw);
         ff += 2.0 * nr * conv_flops(3, c->Cb_r, c->Cb_r, (double)hwf);
         for (int i = 0; i < c->nd; ++i)
             ff += conv_flops(3, i == 0 ? c->Cb_r : c->up_r[i - 1], c->up_r[i], (double)(hwf << (2 * (i + 1))));
-        ff += conv_flops(7, c->up_r.back(), 3, (double)HW);
+        ff += conv_flops(7, c->up_r.back(), c->Cimg, (double)HW);
         if (c->nb > 0) ff += 9.0 * hwf * c->Cb_r;  // bilinear feature warp + occlusion multiply
         c->flops_frame = ff;
     }
@@ -588,7 +609,13 @@ int eamm_encode_source(eamm_ctx* c, const float* source, int ns, void* stream_) 
     if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     const size_t HW = (size_t)c->H * c->W;
-    HIP_TRY(c, hipMemcpyAsync(c->src_full, source, (size_t)ns * 3 * HW * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (c->Cimg == 3) {
+        HIP_TRY(c, hipMemcpyAsync(c->src_full, source, (size_t)ns * 3 * HW * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {   // [ns,C,H,W] into the first C planes of [ns,3,H,W]; the kernels below read the zero-extended copy
+        HIP_TRY(c, hipMemcpy2DAsync(c->src_full, 3 * HW * sizeof(float), source, c->Cimg * HW * sizeof(float), c->Cimg * HW * sizeof(float),
+                                    (size_t)ns, hipMemcpyDeviceToDevice, s));
+        source = c->src_full;
+    }
     HIP_TRY(c, source_prepare_launch(source, c->aa_w, ns, c->H, c->W, c->cfg.dm_inv_scale, c->Csrc, c->src_nhwc,
                                      c->src_small, s));
     ConvIO io{};
@@ -1085,6 +1112,15 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     DeviceGuard guard(c->device);
     if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    const eamm_outputs* const user = o;
+    eamm_outputs staged = *o;
+    if (c->Cimg != 3) {   // one or two image channels: the pass writes three-channel staging tensors (eamm_ctx.h: Cimg)
+        if (o->frames_u8) return fail(c, EAMM_ERR_ARG, "uint8 RGB frames need num_channels == 3");
+        staged.prediction = c->stage_pred;
+        if (o->deformed) staged.deformed = c->stage_deformed;
+        if (o->sparse_deformed) staged.sparse_deformed = c->stage_sparse;
+        o = &staged;
+    }
 
     hipEvent_t* ev = nullptr;  // stage boundaries (of the main stream's sequence), recorded only while profiling
     hipEvent_t* cev = nullptr; // bottleneck window of every whole-pass chain
@@ -1128,6 +1164,15 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
             HIP_TRY(c, hipEventRecord(c->ev_join[k - 1], c->side_streams[k - 1]));
             HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0));
         }
+    }
+    if (c->Cimg != 3) {   // the real channels of every frame: rows of C planes out of rows of three
+        const size_t HW = (size_t)c->H * c->W * sizeof(float), hw = (size_t)c->h * c->w * sizeof(float), C = (size_t)c->Cimg;
+        HIP_TRY(c, hipMemcpy2DAsync(user->prediction, C * HW, c->stage_pred, 3 * HW, C * HW, (size_t)n, hipMemcpyDeviceToDevice, s));
+        if (user->deformed)
+            HIP_TRY(c, hipMemcpy2DAsync(user->deformed, C * HW, c->stage_deformed, 3 * HW, C * HW, (size_t)n, hipMemcpyDeviceToDevice, s));
+        if (user->sparse_deformed)
+            HIP_TRY(c, hipMemcpy2DAsync(user->sparse_deformed, C * hw, c->stage_sparse, 3 * hw, C * hw, (size_t)n * (c->K + 1),
+                                        hipMemcpyDeviceToDevice, s));
     }
     if (ev) {   // the last stage ends where the call ends (after the join)
         HIP_TRY(c, hipEventRecord(ev[eamm_ctx::NMARK], s));

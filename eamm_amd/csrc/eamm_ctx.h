@@ -26,6 +26,13 @@ struct eamm_ctx : eamm::CtxBase {
     std::vector<int> enc_r, dec_r, down_r, up_r;
     int Cb_r = 0;
     bool padded_widths = false;
+    // Image channels (num_channels, reference modules/generator.py:14,25,46): the kernels are written for three (a float4 per pixel:
+    // RGB + a zero; the hourglass input line is (heat, R, G, B) per motion).  One or two channels run as the equivalent
+    // three-channel network -- zero filters on the missing input channels of `first` / the hourglass's first block / the flow
+    // head, zero filters + bias on the missing outputs of `final` (pad_state_dict) -- on a zero-extended source; the three-channel
+    // results land in the staging buffers below and only the real channels are copied to the caller's tensors.
+    int Cimg = 3;
+    float *stage_pred = nullptr, *stage_deformed = nullptr, *stage_sparse = nullptr;
 
     // layers
     ConvLayer first, final_conv, head;

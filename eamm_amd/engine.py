@@ -61,6 +61,7 @@ class Engine:
         self.height, self.width = int(height), int(width)
         self.max_frames, self.max_sources = int(max_frames), int(max_sources)
         self.num_kp = cfg["num_kp"]
+        self.num_channels = cfg["num_channels"]   # 1..3 (include/eamm_hip.h: one or two run as the equivalent three-channel network)
         self._L = _lib.lib()
         self._cs = config_struct(cfg, height, width, max_frames, max_sources)
         self.inv_scale = self._cs.dm_inv_scale
@@ -125,7 +126,7 @@ class Engine:
     def encode_source(self, source: torch.Tensor) -> int:
         if self.training:
             raise RuntimeError("a training-mode engine has no BatchNorm folded into its convolutions: use train_forward()")
-        src = self._check_dev(source, "source_image", (3, self.height, self.width))
+        src = self._check_dev(source, "source_image", (self.num_channels, self.height, self.width))
         ns = src.shape[0]
         with torch.cuda.device(self.device):
             _lib.check(self._L.eamm_encode_source(self._ctx, _dev_ptr(src), ns, self._stream()), self._ctx)
@@ -147,7 +148,7 @@ class Engine:
         if not self.training:
             raise RuntimeError("train_forward needs an Engine(training=True)")
         K, H, W, h, w = self.num_kp, self.height, self.width, self.h, self.w
-        src = self._check_dev(source, "source_image", (3, H, W))
+        src = self._check_dev(source, "source_image", (self.num_channels, H, W))
         n = src.shape[0]
         kd = ks = kdj = ksj = None
         if self.has_motion:
@@ -161,8 +162,9 @@ class Engine:
         want = set(outputs) | {"prediction"}
         if "occlusion_map" in want and not self.has_occlusion:
             want.discard("occlusion_map")
-        shapes = {"prediction": (n, 3, H, W), "mask": (n, K + 1, h, w), "sparse_deformed": (n, K + 1, 3, h, w),
-                  "occlusion_map": (n, 1, h, w), "deformed": (n, 3, H, W), "deformation": (n, h, w, 2)}
+        ch = self.num_channels
+        shapes = {"prediction": (n, ch, H, W), "mask": (n, K + 1, h, w), "sparse_deformed": (n, K + 1, ch, h, w),
+                  "occlusion_map": (n, 1, h, w), "deformed": (n, ch, H, W), "deformation": (n, h, w, 2)}
         res = {k: torch.empty(shapes[k], dtype=torch.float32, device=self.device) for k in _OUTPUT_KEYS if k in want}
         o = _lib.EammOutputs()
         for k, t in res.items():
@@ -223,12 +225,15 @@ class Engine:
             want.discard("occlusion_map")
         if not self.has_motion and want != {"prediction"}:
             raise KeyError(f"this generator has no motion network: only 'prediction' exists, not {sorted(want - {'prediction'})}")
-        shapes = {"prediction": (n, 3, H, W), "mask": (n, K + 1, h, w), "sparse_deformed": (n, K + 1, 3, h, w),
-                  "occlusion_map": (n, 1, h, w), "deformed": (n, 3, H, W), "deformation": (n, h, w, 2)}
+        ch = self.num_channels
+        shapes = {"prediction": (n, ch, H, W), "mask": (n, K + 1, h, w), "sparse_deformed": (n, K + 1, ch, h, w),
+                  "occlusion_map": (n, 1, h, w), "deformed": (n, ch, H, W), "deformation": (n, h, w, 2)}
         res = {k: torch.empty(shapes[k], dtype=torch.float32, device=self.device) for k in _OUTPUT_KEYS if k in want}
         o = _lib.EammOutputs()
         for k, t in res.items():
             setattr(o, k, t.data_ptr())
+        if uint8_frames and self.num_channels != 3:
+            raise RuntimeError("uint8 RGB frames need num_channels == 3")
         if uint8_frames:
             res["frames_u8"] = torch.empty((n, H, W, 3), dtype=torch.uint8, device=self.device)
             o.frames_u8 = res["frames_u8"].data_ptr()

@@ -167,7 +167,7 @@ class OcclusionAwareGenerator(nn.Module):
             enc, dec, _ = hourglass_channels(dense_motion_params["block_expansion"], (num_kp + 1) * (num_channels + 1),
                                              dense_motion_params["num_blocks"], dense_motion_params["max_features"])
             widths += [co for _, co in enc] + [co for _, co in dec]
-        if any(c % 32 for c in widths if c != num_channels):
+        if any(c % 32 for c in widths if c != num_channels) or num_channels != 3:
             self.train_route = "operators"
         # .train() mode: replicas for the BatchNorm statistics (None: the world group when torch.distributed runs with more
         # than one rank -- the analogue of DataParallel replicating the reference module); sync_batchnorm forces the

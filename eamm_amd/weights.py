@@ -191,10 +191,10 @@ def synthetic_state_dict(cfg, seed: int = 1234, spec=None) -> "OrderedDict[str, 
     return sd
 
 
-def synthetic_source(size: int, seed: int = 1, batch: int = 1) -> torch.Tensor:
-    """uniform[0,1) RGB source, float32 [batch,3,size,size]."""
+def synthetic_source(size: int, seed: int = 1, batch: int = 1, channels: int = 3) -> torch.Tensor:
+    """uniform[0,1) RGB source, float32 [batch,3,size,size]; ``channels``: grey-scale / two-channel variants."""
     rs = np.random.RandomState(seed)
-    return torch.from_numpy(rs.uniform(0.0, 1.0, (batch, 3, size, size)).astype(np.float32))
+    return torch.from_numpy(rs.uniform(0.0, 1.0, (batch, channels, size, size)).astype(np.float32))
 
 
 def synthetic_keypoints(n: int, num_kp: int = 10, seed: int = 0, jacobian: bool = True) -> dict:

@@ -47,10 +47,13 @@ typedef struct eamm_ctx eamm_ctx;
  * dense_motion_params (reference modules/dense_motion.py:12-13) flattened in, plus the two sizes
  * the workspace is allocated for.  Any positive channel widths: those that are not multiples of the kernels' 32-channel
  * granule are served by padding the state_dict at eamm_finalize_weights (the extra channels carry exact zeros); a
- * training-mode handle (eamm_set_training) needs multiples of 32.  num_channels must be 3 (RGB).
+ * training-mode handle (eamm_set_training) needs multiples of 32 and three image channels.  num_channels: 1, 2 or 3 -- one
+ * or two channels run as the equivalent three-channel network (zero filters on the channels that do not exist), sources
+ * and outputs keep the reference's shapes [.,C,H,W]; more than three are refused (the motion kernels hold a pixel's image
+ * channels in one float4 beside its heat-map value).
  */
 typedef struct eamm_config {
-    int32_t num_channels;            /* 3                                              */
+    int32_t num_channels;            /* 3 (1 and 2 accepted)                           */
     int32_t num_kp;                  /* 10                                             */
     int32_t block_expansion;         /* 64                                             */
     int32_t max_features;            /* 512                                            */
@@ -70,13 +73,13 @@ typedef struct eamm_config {
 /* Optional outputs of a forward call; NULL pointers are skipped.  Shapes for n frames, frame
  * HxW, motion grid hxw = H/inv_scale x W/inv_scale, K = num_kp (reference generator.py:70-95). */
 typedef struct eamm_outputs {
-    float* prediction;       /* [n,3,H,W]      'prediction'      -- required            */
+    float* prediction;       /* [n,C,H,W]      'prediction'      -- required (C = num_channels) */
     float* mask;             /* [n,K+1,h,w]    'mask'                                   */
-    float* sparse_deformed;  /* [n,K+1,3,h,w]  'sparse_deformed'                        */
+    float* sparse_deformed;  /* [n,K+1,C,h,w]  'sparse_deformed'                        */
     float* occlusion_map;    /* [n,1,h,w]      'occlusion_map'                          */
-    float* deformed;         /* [n,3,H,W]      'deformed'                               */
+    float* deformed;         /* [n,C,H,W]      'deformed'                               */
     float* deformation;      /* [n,h,w,2]      dense_motion 'deformation' (internal to the reference) */
-    uint8_t* frames_u8;      /* [n,H,W,3] uint8 = round(255*prediction), HWC: the layout demo.py:281,507 saves */
+    uint8_t* frames_u8;      /* [n,H,W,3] uint8 = round(255*prediction), HWC: the layout demo.py:281,507 saves (C = 3 only) */
 } eamm_outputs;
 
 int eamm_abi_version(void);
@@ -99,7 +102,7 @@ int eamm_finalize_weights(eamm_ctx* ctx);
 /*
  * Frame-invariant part of OcclusionAwareGenerator.forward, hoisted out of the per-frame loop
  * (generator.py:61-63 encoder, dense_motion.py:83 anti-alias down-sampling): caches, for `ns`
- * source images [ns,3,H,W] on the device, the encoder feature map, the down-sampled source and the
+ * source images [ns,C,H,W] on the device, the encoder feature map, the down-sampled source and the
  * full-resolution source.
  */
 int eamm_encode_source(eamm_ctx* ctx, const float* source, int ns, void* stream);

@@ -65,7 +65,7 @@ def case(OAG, name, cfg, size, n_frames, seed_w, stride, with_jacobian=True, per
     gen = OAG(**cfg).eval()
     gen.load_state_dict(sd, strict=True)
     nsrc = n_frames if per_frame_source else 1
-    source = synthetic_source(size, seed=1, batch=nsrc)
+    source = synthetic_source(size, seed=1, batch=nsrc, channels=cfg["num_channels"])
     kp_s = synthetic_keypoints(nsrc, cfg["num_kp"], seed=0)
     kp_d = synthetic_keypoints(n_frames, cfg["num_kp"], seed=2, jacobian=with_jacobian)
     if per_frame_source:      # the module contract: batch of independent (source, kp) pairs
@@ -648,6 +648,17 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "eval_backward":
         train_backward_case(import_reference(), "tiny64_eval_backward", tiny_config(), 64, 2, training=False)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "channels":   # num_channels 1 and 2 (generator.py:14,25,46; dense_motion.py:17-18,27)
+        OAG = import_reference()
+        for name, ch in (("tiny64_gray", 1), ("tiny64_two_channels", 2)):
+            rep = case(OAG, name, {**tiny_config(), "num_channels": ch}, 64, 2, 1234, 1, per_frame_source=(ch == 2))
+            print(name, {k: (r["oracle_vs_reference"], r["fp32_vs_fp64_floor"]) for k, r in rep.items()})
+            path = os.path.join(GOLDEN, "summary.json")   # (added without regenerating the other fixtures)
+            summary = json.load(open(path))
+            summary["cases"][name] = rep
+            with open(path, "w") as f:
+                json.dump(summary, f, indent=1, sort_keys=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         os.makedirs(GOLDEN, exist_ok=True)
         train_mode_case(import_reference())
@@ -690,6 +701,8 @@ def main():
     summary["tiny64_nojac"] = case(OAG, "tiny64_nojac", tiny, 64, 2, 1234, 1, with_jacobian=False)
     summary["full256_clip2"] = case(OAG, "full256_clip2", full, 256, 2, 1234, 4)
     summary["full512_clip1"] = case(OAG, "full512_clip1", full, 512, 1, 1234, 8)
+    summary["tiny64_gray"] = case(OAG, "tiny64_gray", {**tiny, "num_channels": 1}, 64, 2, 1234, 1)
+    summary["tiny64_two_channels"] = case(OAG, "tiny64_two_channels", {**tiny, "num_channels": 2}, 64, 2, 1234, 1, per_frame_source=True)
     no_motion_case(OAG)
     normalize_kp_case()
     emotion_case()

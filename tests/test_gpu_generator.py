@@ -9,7 +9,7 @@ from conftest import TOL
 from eamm_amd import EngineBackend, OcclusionAwareGenerator, animate_clip, hot_path_config, tiny_config
 from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict
 from oracle import eamm_oracle as orc
-from test_oracle_golden import inputs_from_fixture, load_case, sample
+from test_oracle_golden import gray_config, inputs_from_fixture, load_case, sample, two_channel_config
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -46,9 +46,11 @@ def report(tag, errs):
 
 @pytest.mark.parametrize("name,cfg_fn", [("tiny64_clip3", tiny_config), ("tiny64_batch2", tiny_config),
                                          ("tiny64_nojac", tiny_config), ("full256_clip2", hot_path_config),
-                                         ("full512_clip1", hot_path_config)])
+                                         ("full512_clip1", hot_path_config),
+                                         ("tiny64_gray", gray_config), ("tiny64_two_channels", two_channel_config)])
 def test_module_forward_matches_reference_fixture(name, cfg_fn):
-    """Reference contract forward(source, kp_driving, kp_source) -> dict, against reference outputs."""
+    """Reference contract forward(source, kp_driving, kp_source) -> dict, against reference outputs.  The last two: one and two
+    image channels (num_channels; generator.py:14 accepts any) -- [n,C,H,W] in and out, run as the zero-extended RGB network."""
     cfg = cfg_fn()
     fx = load_case(name)
     sd, src, kp_d, kp_s, n, per_frame = inputs_from_fixture(fx, cfg)
@@ -67,6 +69,22 @@ def test_module_forward_matches_reference_fixture(name, cfg_fn):
     report(name, errs)
     for key in KEYS:
         assert errs[key] <= TOL[key], (name, key, errs[key])
+
+
+def test_gray_clip_interface_and_rgb_only_uint8():
+    """One image channel through encode-once + batched frames (chains of ragged size), and the uint8 RGB packing refuses it."""
+    cfg = gray_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    gen = generator(gray_config)
+    src = synthetic_source(64, seed=1, channels=1)
+    kp_s, kp_d = synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(5, 10, seed=2)
+    frames, span = animate_clip(EngineBackend(gen, batch=3), src, kp_s, kp_d, 64, 64)
+    assert span == (0, 5) and frames.shape == (5, 1, 64, 64)
+    ref = orc.generator_forward(sd, cfg, src.expand(5, -1, -1, -1).contiguous(), kp_d,
+                                {k: v.expand(5, *v.shape[1:]).contiguous() for k, v in kp_s.items()})["prediction"]
+    assert float((frames.cpu() - ref).abs().max()) <= TOL["prediction"]
+    with pytest.raises(RuntimeError, match="num_channels == 3"):
+        animate_clip(EngineBackend(gen, batch=3), src, kp_s, kp_d, 64, 64, uint8=True)
 
 
 def test_internal_flow_matches_fixture():
@@ -210,6 +228,9 @@ VARIANTS = {
     # generator 48 / 96 / 192, hourglass 80 / 100 / 100 -> 100 / 80 / 40 -- the state_dict is padded at load time
     "odd_widths": ({"block_expansion": 48, "max_features": 200}, {"block_expansion": 40, "max_features": 100}, 64, 64),
     "odd_widths_capped": ({"block_expansion": 24, "max_features": 72, "num_bottleneck_blocks": 3}, {"block_expansion": 20, "max_features": 50}, 64, 64),
+    # one / two image channels (run as the zero-extended RGB network) together with the other load-time rewrites
+    "gray_scale_one": ({"num_channels": 1}, {"scale_factor": 1}, 64, 64),
+    "two_channels_odd_widths": ({"num_channels": 2, "block_expansion": 48, "max_features": 200}, {"block_expansion": 40, "max_features": 100}, 64, 96),
 }
 
 
@@ -228,7 +249,7 @@ def test_constructor_variants_match_oracle(name):
     gen = gen.to(DEV).eval()
     n = 2
     rs = np.random.RandomState(9)
-    src = torch.from_numpy(rs.uniform(0, 1, (n, 3, H, W)).astype(np.float32))
+    src = torch.from_numpy(rs.uniform(0, 1, (n, cfg["num_channels"], H, W)).astype(np.float32))
     kp_s, kp_d = synthetic_keypoints(n, 10, seed=0), synthetic_keypoints(n, 10, seed=2)
     out = gen(src.to(DEV), kp_source=cuda(kp_s), kp_driving=cuda(kp_d))
     with torch.no_grad():

@@ -11,8 +11,20 @@ from eamm_amd.config import hot_path_config, tiny_config
 from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict
 from oracle import eamm_oracle as orc
 
+
+
+def gray_config():
+    """num_channels = 1 (reference modules/generator.py:14,25,46; modules/dense_motion.py:17-18,27 accept any)."""
+    return {**tiny_config(), "num_channels": 1}
+
+
+def two_channel_config():
+    return {**tiny_config(), "num_channels": 2}
+
+
 CASES = [("tiny64_clip3", tiny_config), ("tiny64_batch2", tiny_config), ("tiny64_nojac", tiny_config),
-         ("full256_clip2", hot_path_config), ("full512_clip1", hot_path_config)]
+         ("full256_clip2", hot_path_config), ("full512_clip1", hot_path_config),
+         ("tiny64_gray", gray_config), ("tiny64_two_channels", two_channel_config)]
 
 
 def load_case(name):
@@ -27,7 +39,7 @@ def inputs_from_fixture(fx, cfg):
     per_frame = bool(fx["per_frame_source"])
     sd = synthetic_state_dict(cfg, seed=int(fx["weight_seed"]))
     nsrc = n if per_frame else 1
-    src = synthetic_source(size, seed=int(fx["source_seed"]), batch=nsrc)
+    src = synthetic_source(size, seed=int(fx["source_seed"]), batch=nsrc, channels=cfg["num_channels"])
     kp_s = {"value": torch.from_numpy(fx["kp_source_value"]), "jacobian": torch.from_numpy(fx["kp_source_jacobian"])}
     kp_d = {"value": torch.from_numpy(fx["kp_driving_value"])}
     if "kp_driving_jacobian" in fx:

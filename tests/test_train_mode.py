@@ -288,12 +288,18 @@ def test_gpu_train_forward_while_the_weights_keep_changing():
 
 
 @pytest.mark.gpu
-def test_gpu_train_forward_with_widths_that_are_not_multiples_of_32():
-    """The training-mode ENGINE needs the kernels' 32-channel granule; a generator with other widths takes the operator
-    composition for its graph-free .train() forward (train_route "operators") -- against the oracle's training branch."""
-    cfg = dict(tiny_config(), block_expansion=48, max_features=200)
-    cfg["dense_motion_params"] = dict(cfg["dense_motion_params"], block_expansion=40, max_features=100)
+@pytest.mark.parametrize("variant", ["odd_widths", "gray"])
+def test_gpu_train_forward_with_widths_that_are_not_multiples_of_32(variant):
+    """The training-mode ENGINE needs the kernels' 32-channel granule (and three image channels); a generator with other widths
+    takes the operator composition for its graph-free .train() forward (train_route "operators") -- against the oracle's
+    training branch."""
+    if variant == "gray":
+        cfg = dict(tiny_config(), num_channels=1)
+    else:
+        cfg = dict(tiny_config(), block_expansion=48, max_features=200)
+        cfg["dense_motion_params"] = dict(cfg["dense_motion_params"], block_expansion=40, max_features=100)
     src, kp_s, kp_d = inputs(3)
+    src = src[:, :cfg["num_channels"]].contiguous()
     gen = _make(cfg, 1234).train()
     assert gen.train_route == "operators"
     sd_now = {k: v.detach().cpu().clone() for k, v in gen.state_dict().items()}
