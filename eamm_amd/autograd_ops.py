@@ -35,6 +35,26 @@ def _stream(dev) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+# The weight gradient of a convolution and its data gradient are independent given (x, dY).  EAMM_WGRAD_STREAM=1 runs the weight
+# gradient on a side stream beside the data gradient (the current stream waits for it before the backward returns, so autograd
+# sees both results in stream order; buffers are allocated on the CURRENT stream and released only after that wait, so the
+# caching allocator's stream-order reuse holds).  MEASURED AND OFF (profiles/r04_experiments.txt section 14): 8 pairs at 256x256
+# backward 12.1-12.2 -> 12.4-12.5 ms, 16 pairs 21.2 -> 21.7 ms -- both launch sequences already fill the chip, the overlap only
+# adds contention and two event hand-overs per layer.
+_SIDE_STREAMS = {}
+
+
+def _wgrad_stream(dev: torch.device):
+    import os
+    if os.environ.get("EAMM_WGRAD_STREAM", "0") != "1" or torch.cuda.is_current_stream_capturing():
+        return None
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _need_gpu(t: torch.Tensor, what: str):
     if t.device.type != "cuda":
         raise RuntimeError(f"eamm_amd.autograd_ops.{what} runs only on a ROCm GPU (there is no CPU fallback)")
@@ -131,10 +151,7 @@ class _Conv2dSameFunction(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         b, h, w, cin = x.shape
         cout, _, kh, kw = weight.shape
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            # dX = "same" correlation of dY with the filter transposed over (out, in) and flipped over (y, x)
-            gx = _Conv2dSameFunction._conv(grad_out, weight, None, transposed=True)
+        gx = gw = gb = side = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             L = _lib.lib()
             gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
@@ -144,11 +161,22 @@ class _Conv2dSameFunction(torch.autograd.Function):
             gb = torch.empty(cout, dtype=torch.float32, device=x.device) if (ctx.has_bias and not zero_gb) else None
             nwork = L.eamm_op_conv_wgrad_workspace_floats(b, h, w, cin, cout, kh, kw)
             work = torch.empty(max(1, nwork), dtype=torch.float32, device=x.device)
+            if zero_gb:
+                gb0 = torch.zeros(cout, dtype=torch.float32, device=x.device)
+            side = _wgrad_stream(x.device) if ctx.needs_input_grad[0] else None
+            cur = torch.cuda.current_stream(x.device)
+            if side is not None:
+                side.wait_stream(cur)            # x, dY and the buffers above are ready in the current stream's order
             with torch.cuda.device(x.device):
                 _lib.check(L.eamm_op_conv_wgrad(x.device.index, _ptr(x), _ptr(grad_out), b, h, w, cin, cout, kh, kw, _ptr(gw), _ptr(gb),
-                                                _ptr(work), nwork, _stream(x.device)), None)
+                                                _ptr(work), nwork, C.c_void_p((side or cur).cuda_stream)), None)
             if zero_gb:
-                gb = torch.zeros(cout, dtype=torch.float32, device=x.device)
+                gb = gb0
+        if ctx.needs_input_grad[0]:
+            # dX = "same" correlation of dY with the filter transposed over (out, in) and flipped over (y, x)
+            gx = _Conv2dSameFunction._conv(grad_out, weight, None, transposed=True)
+        if side is not None:
+            cur.wait_stream(side)
         return gx, gw, gb, None
 
 
