@@ -25,6 +25,8 @@ import torch
 from . import _lib
 
 _CONV_BK = 32   # channel granule of the implicit-GEMM loaders (conv_common.h CONV_BK)
+_NO_OFFSET = C.c_size_t(-1).value
+_SAVE_TRANSFORM = __import__("os").environ.get("EAMM_SAVE_TRANSFORM", "1") != "0"
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -119,9 +121,10 @@ class _Conv2dSameFunction(torch.autograd.Function):
     """NHWC x [B,H,W,Cin], OIHW weight, bias -> NHWC [B,H,W,Cout]."""
 
     @staticmethod
-    def _conv(x, weight, bias, transposed=False):
+    def _conv(x, weight, bias, transposed=False, keep_work=False):
         """eamm_op_conv_dev: parameters stay on the device, the filter is packed there.  transposed: `weight` is the FORWARD
-        filter [Cin,Cout,k,k] of the convolution whose data gradient this call computes (x = grad_out)."""
+        filter [Cin,Cout,k,k] of the convolution whose data gradient this call computes (x = grad_out).  keep_work: also return
+        the call's workspace (it holds the transformed input the weight gradient can start from)."""
         b, h, w, cin = x.shape
         cout = weight.shape[1] if transposed else weight.shape[0]
         kh, kw = weight.shape[2:]
@@ -136,18 +139,29 @@ class _Conv2dSameFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(L.eamm_op_conv_dev(x.device.index, _ptr(x), b, h, w, cin, _ptr(wt), _ptr(bt), cout, kh, kw, int(transposed),
                                           _ptr(out), _ptr(work), nwork, _stream(x.device)), None)
-        return out
+        return (out, work) if keep_work else out
 
     @staticmethod
     def forward(ctx, x, weight, bias, bias_grad_is_zero=False):
-        ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.bias_grad_is_zero = bool(bias_grad_is_zero)
+        # Where the forward ran the F(4x4,3x3) form and the weight gradient takes its F(3x3,4x4) form, both start from the same
+        # transformed input: the forward's workspace is kept for the backward (2.25 x the activation; EAMM_SAVE_TRANSFORM=0: not kept)
+        b, h, w, cin = x.shape
+        cout, _, kh, kw = weight.shape
+        off = _lib.lib().eamm_op_conv_saved_transform_offset(b, h, w, cin, cout, kh, kw) if _SAVE_TRANSFORM and ctx.needs_input_grad[1] else _NO_OFFSET
+        ctx.v_offset = off
+        if off != _NO_OFFSET:
+            out, work = _Conv2dSameFunction._conv(x, weight, bias, keep_work=True)
+            ctx.save_for_backward(x, weight, work)
+            return out
+        ctx.save_for_backward(x, weight)
         return _Conv2dSameFunction._conv(x, weight, bias)
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
+        saved_work = ctx.saved_tensors[2] if ctx.v_offset != _NO_OFFSET else None
         grad_out = grad_out.contiguous()
         b, h, w, cin = x.shape
         cout, _, kh, kw = weight.shape
@@ -168,8 +182,13 @@ class _Conv2dSameFunction(torch.autograd.Function):
             if side is not None:
                 side.wait_stream(cur)            # x, dY and the buffers above are ready in the current stream's order
             with torch.cuda.device(x.device):
-                _lib.check(L.eamm_op_conv_wgrad(x.device.index, _ptr(x), _ptr(grad_out), b, h, w, cin, cout, kh, kw, _ptr(gw), _ptr(gb),
-                                                _ptr(work), nwork, C.c_void_p((side or cur).cuda_stream)), None)
+                if saved_work is not None:
+                    v = C.c_void_p(saved_work.data_ptr() + 4 * ctx.v_offset)
+                    _lib.check(L.eamm_op_conv_wgrad_saved(x.device.index, v, _ptr(grad_out), b, h, w, cin, cout, _ptr(gw), _ptr(gb),
+                                                          _ptr(work), nwork, C.c_void_p((side or cur).cuda_stream)), None)
+                else:
+                    _lib.check(L.eamm_op_conv_wgrad(x.device.index, _ptr(x), _ptr(grad_out), b, h, w, cin, cout, kh, kw, _ptr(gw), _ptr(gb),
+                                                    _ptr(work), nwork, C.c_void_p((side or cur).cuda_stream)), None)
             if zero_gb:
                 gb = gb0
         if ctx.needs_input_grad[0]:

@@ -479,8 +479,14 @@ long long wgrad_splits(long long tiles, long long K, long long min_k) {
 size_t round64(size_t n) { return (n + 63) / 64 * 64; }
 }  // namespace
 
+bool conv_wgrad_takes_transformed(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
+    return wgrad_wino4_applies(B, H, W, Cin, Cout, kh, kw);
+}
+
+// x_transformed (optional, only in the F(3x3,4x4) form): V = B^T x B as wino4_transform_launch wrote it for the forward convolution
+// of the same x ([36][tiles][Cin]) -- the transform is then not run again
 hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int kh, int kw, float* dweight,
-                             float* dbias, float* workspace, size_t workspace_floats, hipStream_t s) {
+                             float* dbias, float* workspace, size_t workspace_floats, hipStream_t s, const float* x_transformed) {
     if ((Cin & 3) || (Cout & 3) || Cout > 1024 || !(kh & 1) || !(kw & 1) || B < 1 || (long long)B * H * W >= (1ll << 30)) return hipErrorInvalidValue;
     if (workspace_floats < conv_wgrad_workspace_floats(B, H, W, Cin, Cout, kh, kw)) return hipErrorInvalidValue;
     const size_t bias_floats = (size_t)BIAS_PARTS * Cout;   // the tail of the workspace
@@ -498,8 +504,12 @@ hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int 
         float* V = workspace;
         float* Yh = V + round64((size_t)36 * Mq * Cin);
         float* partial = Yh + round64((size_t)36 * Mq * Cout);
-        hipError_t e = wino4_transform_launch(x, nullptr, nullptr, B, H, W, Cin, V, s);
-        if (e != hipSuccess) return e;
+        if (x_transformed) {
+            V = const_cast<float*>(x_transformed);
+        } else {
+            hipError_t e = wino4_transform_launch(x, nullptr, nullptr, B, H, W, Cin, V, s);
+            if (e != hipSuccess) return e;
+        }
         const size_t ty = (size_t)Mq * (Cout / 4);
         hipLaunchKernelGGL(wino4_dy_transform_kernel, dim3((unsigned)std::min<size_t>((ty + 255) / 256, (size_t)1 << 20)), dim3(256), 0, s, dy,
                            B, H, W, Cout, Yh);

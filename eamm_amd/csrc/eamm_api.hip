@@ -5,6 +5,7 @@
 //   eamm_forward_frames -- per frame batch: key-point records, motion front end, hourglass, flow head,
 //                          feature warp, bottleneck, up blocks, final 7x7 + sigmoid
 #include "eamm_ctx.h"
+#include <mutex>
 
 namespace {
 
@@ -1752,6 +1753,28 @@ bool conv_dev_plan(int B, int H, int W, int Cin, int Cout, int kh, int kw, ConvD
 }
 }  // namespace
 
+namespace {
+// A per-device vector of zeros (never written after its allocation): the bias of the convolutions that have none.
+const float* device_zeros(int device, size_t n) {
+    constexpr size_t CAP = 16384;
+    constexpr int MAXDEV = 64;
+    static std::mutex mu;
+    static float* zeros[MAXDEV] = {};
+    if (n > CAP || device < 0 || device >= MAXDEV) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!zeros[device]) {
+        void* p = nullptr;
+        if (hipMalloc(&p, CAP * sizeof(float)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, CAP * sizeof(float)) != hipSuccess) {   // synchronous: visible to every stream that follows
+            (void)hipFree(p);
+            return nullptr;
+        }
+        zeros[device] = static_cast<float*>(p);
+    }
+    return zeros[device];
+}
+}  // namespace
+
 size_t eamm_op_conv_dev_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
     ConvDevPlan P;
     return conv_dev_plan(B, H, W, Cin, Cout, kh, kw, &P) ? P.packed + P.bias + P.aux + P.zbuf : 0;
@@ -1768,7 +1791,17 @@ int eamm_op_conv_dev(int device, const float* x, int B, int H, int W, int Cin, c
     if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     float *wp = workspace, *bp = workspace + P.packed, *aux = workspace + P.packed + P.bias;
-    hipError_t e = bias_pad_dev_launch(bias, Cout, P.ntiles * P.BN, bp, s);
+    // the kernels read ntiles * BN bias values: a bias of exactly that length is read where it lies, a missing one (every data
+    // gradient) is the device's shared zero vector -- the padding kernel only runs for a Cout off the tile grid
+    hipError_t e = hipSuccess;
+    const int nbias = P.ntiles * P.BN;
+    if (bias && nbias == Cout) {
+        bp = const_cast<float*>(bias);
+    } else if (const float* z = bias ? nullptr : device_zeros(device, (size_t)nbias)) {
+        bp = const_cast<float*>(z);
+    } else {
+        e = bias_pad_dev_launch(bias, Cout, nbias, bp, s);
+    }
     if (e == hipSuccess && P.wino4) {
         WinoLayer WL;
         WL.Cin = Cin;
@@ -1861,6 +1894,26 @@ int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B,
     hipError_t e = conv_wgrad_launch(x, grad_out, B, H, W, Cin, Cout, kh, kw, grad_weight, grad_bias, workspace, workspace_floats,
                                      reinterpret_cast<hipStream_t>(stream_));
     if (e != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "eamm_op_conv_wgrad failed: %s", hipGetErrorString(e));
+    return EAMM_OK;
+}
+
+size_t eamm_op_conv_saved_transform_offset(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
+    ConvDevPlan P;
+    if (!conv_dev_plan(B, H, W, Cin, Cout, kh, kw, &P) || !P.wino4 || !conv_wgrad_takes_transformed(B, H, W, Cin, Cout, kh, kw))
+        return (size_t)-1;
+    return P.packed + P.bias;
+}
+
+int eamm_op_conv_wgrad_saved(int device, const float* x_transformed, const float* grad_out, int B, int H, int W, int Cin, int Cout,
+                             float* grad_weight, float* grad_bias, float* workspace, size_t workspace_floats, void* stream_) {
+    if (!x_transformed || !grad_out || !grad_weight || !workspace || eamm_op_conv_saved_transform_offset(B, H, W, Cin, Cout, 3, 3) == (size_t)-1 ||
+        Cout > 1024)
+        return fail(nullptr, EAMM_ERR_ARG, "eamm_op_conv_wgrad_saved: only where eamm_op_conv_saved_transform_offset names a saved transform");
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
+    hipError_t e = conv_wgrad_launch(nullptr, grad_out, B, H, W, Cin, Cout, 3, 3, grad_weight, grad_bias, workspace, workspace_floats,
+                                     reinterpret_cast<hipStream_t>(stream_), x_transformed);
+    if (e != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "eamm_op_conv_wgrad_saved failed: %s", hipGetErrorString(e));
     return EAMM_OK;
 }
 

@@ -225,7 +225,8 @@ hipError_t warp_features_backward_launch(const float* feat, const float* defo, c
                                          int hf, int wf, int C, float* dfeat, float* ddefo, float* docc, hipStream_t s);
 size_t conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw);
 hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int kh, int kw, float* dweight,
-                             float* dbias, float* workspace, size_t workspace_floats, hipStream_t s);
+                             float* dbias, float* workspace, size_t workspace_floats, hipStream_t s, const float* x_transformed = nullptr);
+bool conv_wgrad_takes_transformed(int B, int H, int W, int Cin, int Cout, int kh, int kw);
 
 // conv_pack_dev.hip: the packings of conv_pack_host (register-staged kernel) and wino4_pack_host from a DEVICE OIHW tensor;
 // transposed = 1 reads the forward filter [Cin][Cout][kh][kw] transposed and flipped (the data gradient's filter)

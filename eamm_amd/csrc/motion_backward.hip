@@ -318,7 +318,10 @@ __global__ __launch_bounds__(MB_THREADS) void motion_head_backward_kernel(const 
                                                                           const float* __restrict__ rec_all, int K, int h, int w,
                                                                           const float* __restrict__ dmask, const float* __restrict__ ddef,
                                                                           const float* __restrict__ docc, float* __restrict__ dlm, int ld,
-                                                                          float* __restrict__ dlo, int ldo, float* __restrict__ part) {
+                                                                          float* __restrict__ dlo, int ldo, int stacked,
+                                                                          float* __restrict__ part) {
+    // stacked: the occlusion logit is channel K + 1 of the mask logits' rows (one convolution produced both): its gradient goes
+    // to dlm[.., K + 1] and dlo is null
     __shared__ float red[MB_THREADS / 64];
     const int f = blockIdx.y;
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -368,11 +371,17 @@ __global__ __launch_bounds__(MB_THREADS) void motion_head_backward_kernel(const 
         }
     }
     if (live) {
-        for (int k = K + 1; k < ld; ++k) dl[k] = 0.f;
+        float dol = 0.f;
+        if ((dlo || stacked) && docc) {
+            const float o = occlusion[(size_t)f * plane + p];
+            dol = docc[(size_t)f * plane + p] * o * (1.f - o);
+        }
+        int k0 = K + 1;
+        if (stacked) dl[k0++] = dol;
+        for (int k = k0; k < ld; ++k) dl[k] = 0.f;
         if (dlo) {
             float* d = dlo + ((size_t)f * plane + p) * ldo;
-            const float o = occlusion[(size_t)f * plane + p];
-            d[0] = docc ? docc[(size_t)f * plane + p] * o * (1.f - o) : 0.f;
+            d[0] = dol;
             for (int k = 1; k < ldo; ++k) d[k] = 0.f;
         }
     }
@@ -391,8 +400,10 @@ hipError_t motion_head_backward_launch(const float* mask, const float* occlusion
                                        float* drec, float* workspace, hipStream_t s) {
     if (K < 1 || K > MB_MAXK || ld < K + 1 || (dlo && (ldo < 1 || occlusion == nullptr))) return hipErrorInvalidValue;
     const int blocks = (h * w + MB_THREADS - 1) / MB_THREADS;
+    // occlusion logits that are channel K + 1 of the mask logits' rows (the caller stacked the two convolutions)
+    const int stacked = dlo != nullptr && dlo == dlm + (K + 1) && ldo == ld && ld >= K + 2;
     hipLaunchKernelGGL(motion_head_backward_kernel, dim3(blocks, n), dim3(MB_THREADS), 0, s, mask, occlusion, rec, K, h, w, dmask, ddef, docc,
-                       dlm, ld, dlo, ldo, workspace);
+                       dlm, ld, stacked ? nullptr : dlo, ldo, stacked, workspace);
     const int tot = n * K * KP_STRIDE;
     hipLaunchKernelGGL(rec_partial_reduce_kernel, dim3((tot + 127) / 128), dim3(128), 0, s, workspace, n, blocks, K, 0, drec);
     return hipGetLastError();

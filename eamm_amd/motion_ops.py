@@ -167,18 +167,21 @@ class _MotionHeadFunction(torch.autograd.Function):
     occlusion [n,h,w] (or None)."""
 
     @staticmethod
-    def forward(ctx, lm, lo, rec):
+    def forward(ctx, lm, lo, rec, stacked=False):
+        """stacked: the occlusion logit is channel K + 1 of ``lm`` (one convolution produced both); ``lo`` is None then."""
         n, h, w, ld = lm.shape
         k = rec.shape[1]
         dev = lm.device
         mask = torch.empty(n, k + 1, h, w, dtype=torch.float32, device=dev)
         defo = torch.empty(n, h, w, 2, dtype=torch.float32, device=dev)
-        occ = torch.empty(n, h, w, dtype=torch.float32, device=dev) if lo is not None else None
+        occ = torch.empty(n, h, w, dtype=torch.float32, device=dev) if (lo is not None or stacked) else None
+        lo_ptr = C.c_void_p(lm.data_ptr() + 4 * (k + 1)) if stacked else _ptr(lo)
+        ldo = ld if stacked else (0 if lo is None else lo.shape[3])
         with torch.cuda.device(dev):
-            _check(_lib.lib().eamm_op_motion_head(dev.index, _ptr(lm), ld, _ptr(lo), 0 if lo is None else lo.shape[3], _ptr(rec), n, k, h, w,
+            _check(_lib.lib().eamm_op_motion_head(dev.index, _ptr(lm), ld, lo_ptr, ldo, _ptr(rec), n, k, h, w,
                                                   _ptr(mask), _ptr(defo), _ptr(occ), _stream(dev)))
         ctx.save_for_backward(mask, occ, rec)
-        ctx.ld, ctx.ldo = ld, (0 if lo is None else lo.shape[3])
+        ctx.ld, ctx.ldo, ctx.stacked = ld, ldo, bool(stacked)
         return mask, defo, occ
 
     @staticmethod
@@ -190,24 +193,28 @@ class _MotionHeadFunction(torch.autograd.Function):
         cont = lambda t: None if t is None else t.contiguous()
         g_mask, g_defo, g_occ = cont(g_mask), cont(g_defo), cont(g_occ)
         g_lm = torch.empty(n, h, w, ctx.ld, dtype=torch.float32, device=dev)
-        g_lo = torch.empty(n, h, w, ctx.ldo, dtype=torch.float32, device=dev) if occ is not None else None
+        g_lo = torch.empty(n, h, w, ctx.ldo, dtype=torch.float32, device=dev) if (occ is not None and not ctx.stacked) else None
+        g_lo_ptr = C.c_void_p(g_lm.data_ptr() + 4 * (k + 1)) if ctx.stacked else _ptr(g_lo)
         g_rec = torch.empty_like(rec)
         ws = _workspace(n, k, h, w, dev)
         with torch.cuda.device(dev):
             _check(_lib.lib().eamm_op_motion_head_backward(dev.index, _ptr(mask), _ptr(occ), _ptr(rec), n, k, h, w, _ptr(g_mask), _ptr(g_defo),
-                                                           _ptr(g_occ), _ptr(g_lm), ctx.ld, _ptr(g_lo), ctx.ldo, _ptr(g_rec), _ptr(ws),
+                                                           _ptr(g_occ), _ptr(g_lm), ctx.ld, g_lo_ptr, ctx.ldo, _ptr(g_rec), _ptr(ws),
                                                            ws.numel(), _stream(dev)))
-        return g_lm, g_lo, (g_rec if ctx.needs_input_grad[2] else None)
+        return g_lm, g_lo, (g_rec if ctx.needs_input_grad[2] else None), None
 
 
-def motion_head(mask_logits: torch.Tensor, occlusion_logits: Optional[torch.Tensor], records: torch.Tensor):
+def motion_head(mask_logits: torch.Tensor, occlusion_logits: Optional[torch.Tensor], records: torch.Tensor, stacked: bool = False):
     """dense_motion.py:98-111 on the two 7x7 convolutions' NHWC outputs (channels 0..K of ``mask_logits``, channel 0 of
-    ``occlusion_logits``): mask [n,K+1,h,w], deformation [n,h,w,2], occlusion [n,h,w] or None."""
+    ``occlusion_logits``): mask [n,K+1,h,w], deformation [n,h,w,2], occlusion [n,h,w] or None.  ``stacked``: ONE convolution with
+    the two filters stacked produced both -- the occlusion logit is channel K + 1 of ``mask_logits``, ``occlusion_logits`` is None."""
     _need_gpu(mask_logits, "motion_head")
     n, k = records.shape[:2]
-    if mask_logits.dim() != 4 or mask_logits.shape[0] != n or mask_logits.shape[3] < k + 1:
+    if mask_logits.dim() != 4 or mask_logits.shape[0] != n or mask_logits.shape[3] < k + 1 + int(stacked):
         raise ValueError(f"motion_head: mask logits {tuple(mask_logits.shape)} do not hold {k + 1} motions of {n} frames")
+    if stacked and occlusion_logits is not None:
+        raise ValueError("motion_head: stacked logits carry the occlusion logit in channel K + 1; pass occlusion_logits=None")
     if occlusion_logits is not None and tuple(occlusion_logits.shape[:3]) != tuple(mask_logits.shape[:3]):
         raise ValueError("motion_head: occlusion logits and mask logits differ in shape")
     return _MotionHeadFunction.apply(mask_logits.contiguous(), None if occlusion_logits is None else occlusion_logits.contiguous(),
-                                     records.contiguous())
+                                     records.contiguous(), stacked)

@@ -27,7 +27,7 @@ GPU only: no CPU fallback.
 from __future__ import annotations
 
 import os
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F
@@ -52,7 +52,11 @@ def conv(x: torch.Tensor, mod: torch.nn.Conv2d, feeds_norm: bool = False, keep_p
     zero-padded to the kernels' granule (the padded filter rows / columns are zeros and the slice drops their gradient).  An input
     that already carries zero channels up to the granule is taken as it is; ``keep_padded`` returns the granule-padded output
     (channels >= Cout are exactly zero... plus nothing: their filters and biases are zeros)."""
-    w, b = mod.weight, mod.bias
+    return conv_wb(x, mod.weight, mod.bias, feeds_norm, keep_padded)
+
+
+def conv_wb(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], feeds_norm: bool = False, keep_padded: bool = False) -> torch.Tensor:
+    """``conv`` on a filter / bias pair that is not a module's (the flow head's two stacked convolutions)."""
     cout, cin = w.shape[:2]
     cin_p, cout_p = _round_up(cin, _G), _round_up(cout, _G)
     if cin_p != cin:
@@ -212,8 +216,16 @@ def _dense_motion(g: _Graph, source_image, kp_driving, kp_source):
         if dm.hourglass.decoder.up_blocks[-1].conv.weight.shape[0] % _G:   # the last concatenation would not end on the granule
             hg_in = hg_in[..., :4 * (dm.num_kp + 1)]
         feat = g.hourglass(hg_in, dm.hourglass)
-        lo = conv(feat, dm.occlusion, keep_padded=True) if dm.occlusion is not None else None
-        mask, deformation, occ = motion_ops.motion_head(conv(feat, dm.mask, keep_padded=True), lo, rec)
+        if dm.occlusion is not None and dm.mask.bias is not None and dm.occlusion.bias is not None:
+            # dense_motion.py:98,110: the mask and occlusion 7x7 convolutions read the same features -- run as ONE convolution with
+            # the filters stacked (K + 2 of the granule's 32 output channels instead of K + 1 and 1 of 32 each; the engine does the
+            # same); autograd splits the stacked filter's gradient back onto the two modules
+            logits = conv_wb(feat, torch.cat([dm.mask.weight, dm.occlusion.weight], dim=0), torch.cat([dm.mask.bias, dm.occlusion.bias]),
+                             keep_padded=True)
+            mask, deformation, occ = motion_ops.motion_head(logits, None, rec, stacked=True)
+        else:
+            lo = conv(feat, dm.occlusion, keep_padded=True) if dm.occlusion is not None else None
+            mask, deformation, occ = motion_ops.motion_head(conv(feat, dm.mask, keep_padded=True), lo, rec)
         out = {"sparse_deformed": sparse, "mask": mask, "deformation": deformation}
         if occ is not None:
             out["occlusion_map"] = occ

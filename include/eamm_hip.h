@@ -421,6 +421,14 @@ int eamm_op_final_conv_sigmoid(int device, const float* x, const float* weight, 
 size_t eamm_op_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw);
 int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                        float* grad_weight, float* grad_bias, float* workspace, size_t workspace_floats, void* stream);
+/* Where eamm_op_conv_dev ran the F(4x4,3x3) form AND the weight gradient takes its F(3x3,4x4) form, both start from the same
+ * transformed input V = B^T x B: a caller that keeps the forward call's workspace alive until the backward (autograd's saved
+ * tensors) passes workspace + eamm_op_conv_saved_transform_offset(...) as `x_transformed` and the transform is not run again
+ * (2.25 x the activation kept instead of 1 x; the same sums in the same order: bit-identical to eamm_op_conv_wgrad).
+ * The offset is (size_t)-1 for a shape without a shared transform.  Workspace: eamm_op_conv_wgrad_workspace_floats. */
+size_t eamm_op_conv_saved_transform_offset(int B, int H, int W, int Cin, int Cout, int kh, int kw);
+int eamm_op_conv_wgrad_saved(int device, const float* x_transformed, const float* grad_out, int B, int H, int W, int Cin, int Cout,
+                             float* grad_weight, float* grad_bias, float* workspace, size_t workspace_floats, void* stream);
 
 /*
  * The dense-motion front end and flow head as DIFFERENTIABLE operators (round 4): forward = the evaluation
@@ -442,7 +450,10 @@ int eamm_op_conv_wgrad(int device, const float* x, const float* grad_out, int B,
  *   eamm_op_motion_head               mask = softmax over the K+1 mask logits [n,h,w,ld], deformation = sum_k mask_k T_k,
  *                                     occlusion = sigmoid(logit [n,h,w,ldo] channel 0) (dense_motion.py:98-111; occlusion NULL: none)
  *   eamm_op_motion_head_backward      grad_mask [n,K+1,h,w], grad_deformation [n,h,w,2], grad_occlusion [n,h,w] (any may be NULL)
- *                                     -> grad of the logits (same layouts, unused channels zeroed) and grad_records
+ *                                     -> grad of the logits (same layouts, unused channels zeroed) and grad_records.
+ *                                     Stacked logits (ONE convolution producing mask and occlusion: occlusion_logits =
+ *                                     mask_logits + K + 1, ldo = ld; the same for the two gradient pointers) are recognised: the
+ *                                     occlusion logit's gradient then lands in channel K + 1 of the one gradient tensor
  * `workspace`: eamm_op_motion_workspace_floats(n, K, h, w) floats.
  */
 int eamm_op_antialias_down(int device, const float* source, const float* aa_weight, int B, int H, int W, int inv_scale, float* small,

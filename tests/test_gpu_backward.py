@@ -173,6 +173,37 @@ def test_conv_wgrad_is_deterministic_and_linear():
     assert float((a12 - (a1 + a2)).abs().max()) <= 1e-4 * float(a12.abs().max())
 
 
+def test_conv_wgrad_from_the_forwards_saved_transform_is_bit_identical():
+    """eamm_op_conv_dev in its F(4x4,3x3) form leaves V = B^T x B in its workspace; eamm_op_conv_wgrad_saved starts the F(3x3,4x4)
+    weight gradient from it instead of transforming x again -- the same sums in the same order as eamm_op_conv_wgrad."""
+    B, H, W, cin, cout = 8, 64, 64, 64, 128
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, H, W, cin, generator=g).to(DEV)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV)
+    go = torch.randn(B, H, W, cout, generator=g).to(DEV)
+    L = _lib.lib()
+    off = L.eamm_op_conv_saved_transform_offset(B, H, W, cin, cout, 3, 3)
+    assert off != 2 ** 64 - 1
+    assert L.eamm_op_conv_saved_transform_offset(1, 16, 16, cin, cout, 3, 3) == 2 ** 64 - 1     # too few tiles: direct forward
+    assert L.eamm_op_conv_saved_transform_offset(B, H, W, cin, cout, 7, 7) == 2 ** 64 - 1
+    nfw = L.eamm_op_conv_dev_workspace_floats(B, H, W, cin, cout, 3, 3)
+    fwork = torch.empty(nfw, device=DEV)
+    out = torch.empty(B, H, W, cout, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.eamm_op_conv_dev(0, x.data_ptr(), B, H, W, cin, wt.data_ptr(), None, cout, 3, 3, 0, out.data_ptr(), fwork.data_ptr(), nfw, st), None)
+    nwork = L.eamm_op_conv_wgrad_workspace_floats(B, H, W, cin, cout, 3, 3)
+    work = torch.empty(nwork, device=DEV)
+    dw0, db0 = torch.empty_like(wt), torch.empty(cout, device=DEV)
+    dw1, db1 = torch.full_like(wt, float("nan")), torch.full((cout,), float("nan"), device=DEV)
+    _lib.check(L.eamm_op_conv_wgrad(0, x.data_ptr(), go.data_ptr(), B, H, W, cin, cout, 3, 3, dw0.data_ptr(), db0.data_ptr(),
+                                    work.data_ptr(), nwork, st), None)
+    _lib.check(L.eamm_op_conv_wgrad_saved(0, fwork.data_ptr() + 4 * off, go.data_ptr(), B, H, W, cin, cout, dw1.data_ptr(), db1.data_ptr(),
+                                          work.data_ptr(), nwork, st), None)
+    torch.cuda.synchronize()
+    assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    assert L.eamm_op_conv_wgrad_saved(0, fwork.data_ptr(), go.data_ptr(), 1, 16, 16, cin, cout, dw1.data_ptr(), None, work.data_ptr(), nwork, st) != 0
+
+
 @pytest.mark.parametrize("H,W", [(12, 32), (9, 20)])
 def test_conv_wgrad_7x1_filter(H, W):
     # the path's column convolutions (7x1): filter-row kernel with one tap per row / per-tap kernel, against autograd

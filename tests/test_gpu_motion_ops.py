@@ -98,14 +98,18 @@ def test_kp_records_and_motion_front_against_torch_double(with_jac):
     assert float(sd_in.grad[..., 3].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("with_occ", [True, False])
+@pytest.mark.parametrize("with_occ", [True, False, "stacked"])
 def test_motion_head_against_torch_double(with_occ):
+    """"stacked": one convolution produced both heads -- the occlusion logit is channel K + 1 of the mask logits' rows."""
     from eamm_amd import motion_ops
     n, k, h, w = 2, 10, 16, 16
     gen = torch.Generator().manual_seed(9)
     kd, ks = synthetic_keypoints(n, k, seed=4), synthetic_keypoints(n, k, seed=6)
     lm = torch.randn(n, h, w, 32, generator=gen)
     lo = torch.randn(n, h, w, 32, generator=gen) if with_occ else None
+    stacked = with_occ == "stacked"
+    if stacked:
+        lo[..., 0] = lm[..., k + 1]
     kdr = {a: b.double().requires_grad_() for a, b in kd.items()}
     ksr = {a: b.double().requires_grad_() for a, b in ks.items()}
     lmr = lm.double().requires_grad_()
@@ -124,9 +128,9 @@ def test_motion_head_against_torch_double(with_occ):
     kdd = {a: b.to(DEV).requires_grad_() for a, b in kd.items()}
     ksd = {a: b.to(DEV).requires_grad_() for a, b in ks.items()}
     lmd = lm.to(DEV).requires_grad_()
-    lod = lo.to(DEV).requires_grad_() if with_occ else None
+    lod = lo.to(DEV).requires_grad_() if (with_occ and not stacked) else None
     rec = motion_ops.kp_records(kdd, ksd)
-    mask, defo, occ = motion_ops.motion_head(lmd, lod, rec)
+    mask, defo, occ = motion_ops.motion_head(lmd, lod, rec, stacked=stacked)
     _close(mask, mask_ref, 2e-6, "mask")
     _close(defo, def_ref, 2e-6, "deformation")
     out = (mask * g_m.to(DEV)).sum() + (defo * g_d.to(DEV)).sum()
@@ -137,8 +141,12 @@ def test_motion_head_against_torch_double(with_occ):
         assert occ is None
     out.backward()
     _close(lmd.grad[..., :k + 1], lmr.grad[..., :k + 1], 1e-5, "d mask logits")
-    assert float(lmd.grad[..., k + 1:].abs().max()) == 0.0
-    if with_occ:
+    if stacked:
+        _close(lmd.grad[..., k + 1], lor.grad[..., 0], 1e-5, "d occlusion logit (stacked)")
+        assert float(lmd.grad[..., k + 2:].abs().max()) == 0.0
+    else:
+        assert float(lmd.grad[..., k + 1:].abs().max()) == 0.0
+    if with_occ and not stacked:
         _close(lod.grad[..., 0], lor.grad[..., 0], 1e-5, "d occlusion logits")
         assert float(lod.grad[..., 1:].abs().max()) == 0.0
     for a in kd:
