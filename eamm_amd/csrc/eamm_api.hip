@@ -91,6 +91,21 @@ int pad_norm(eamm_ctx* c, const std::string& norm, int c_r, int c_p) {
     }
     return 0;
 }
+// The chains' side streams are a per-device pool shared by every handle of the process (created on first use, never destroyed):
+// the runtime multiplexes streams onto a few hardware queues (four by default), and a second handle with its own three streams
+// made two chains of one call share a queue -- measured: a 64-frame call's four chains 4199 frames/s alone, 4007 beside another
+// handle's stream.  Handles used from different threads then share the streams' order, never their dependencies (every call
+// forks from and joins to its caller's stream with its own events).
+hipStream_t chain_stream(int device, int k) {
+    constexpr int MAXDEV = 64, MAXCHAIN = 15;
+    static std::mutex mu;
+    static hipStream_t pool[MAXDEV][MAXCHAIN] = {};
+    if (device < 0 || device >= MAXDEV || k < 0 || k >= MAXCHAIN) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pool[device][k] && hipStreamCreateWithFlags(&pool[device][k], hipStreamNonBlocking) != hipSuccess) pool[device][k] = nullptr;
+    return pool[device][k];
+}
+
 int pad_state_dict(eamm_ctx* c) {
     const std::string dm = "dense_motion_network.";
     const int nb = c->nb, nd = c->nd;
@@ -273,7 +288,6 @@ void eamm_destroy(eamm_ctx* c) {
     if (c->ev_stagger) (void)hipEventDestroy(c->ev_stagger);
     if (c->ev_warp) (void)hipEventDestroy(c->ev_warp);
     for (auto& e : c->ev_join) (void)hipEventDestroy(e);
-    for (auto& st : c->side_streams) (void)hipStreamDestroy(st);
     delete c;
 }
 
@@ -558,7 +572,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
             upd1(c->final_conv, f * HW);
         }
         c->partial_elems = need;   // one slab per whole-pass chain
-        const int slabs = c->pass_chains == 0 ? 2 : c->pass_chains;   // (clamped to 0..4 in eamm_create; 0 = automatic = two chains)
+        const int slabs = c->pass_chains == 0 ? (g.max_frames >= 64 ? 4 : 2) : c->pass_chains;   // (clamped to 0..4 in eamm_create; 0 = automatic: two chains, four from 64 frames per call)
         if ((rc = dev_alloc(c, &c->partial, c->partial_elems * (size_t)slabs))) return rc;
     }
 
@@ -582,15 +596,15 @@ int eamm_finalize_weights(eamm_ctx* c) {
         if (c->nb > 0) ff += 9.0 * hwf * c->Cb_r;  // bilinear feature warp + occlusion multiply
         c->flops_frame = ff;
     }
-    const int max_chains = std::max(c->bneck_chains, c->pass_chains == 0 ? 2 : c->pass_chains);
+    const int max_chains = std::max(c->bneck_chains, c->pass_chains == 0 ? (g.max_frames >= 64 ? 4 : 2) : c->pass_chains);
     if (max_chains > 1) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_warp, hipEventDisableTiming));
         for (int k = 1; k < max_chains; ++k) {
-            hipStream_t st = nullptr;
+            hipStream_t st = chain_stream(c->device, k - 1);
             hipEvent_t ev = nullptr;
-            HIP_TRY(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            if (!st) return fail(c, EAMM_ERR_HIP, "hipStreamCreate failed for chain %d", k);
             c->side_streams.push_back(st);
             HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             c->ev_join.push_back(ev);
@@ -770,21 +784,27 @@ static FrameView make_view(const eamm_ctx* c, int f0, int n, int ns_call, int sl
 // GEMM blocks per chain; EAMM_PASS_CHAINS (0 / 1 = off).
 static int pass_chains(const eamm_ctx* c, int n) {
     const bool automatic = c->pass_chains == 0;
-    const int K = automatic ? 2 : c->pass_chains;
-    if (K < 2 || (int)c->side_streams.size() + 1 < K) return 1;
     const int tiles_pf = (c->hf / 4) * (c->wf / 4);
-    if (n < c->pass_chains_min_frames || n < K) return 1;
-    if (automatic) {   // only while a chain's bottleneck GEMM keeps >= 80 one-per-CU blocks (measured 256x256, frames/s off -> on:
-        // 8 frames = 64 blocks per chain 2981 -> 2397; 10: 2695 -> 2794; 12: 3018 -> 3105; 16: 3720 -> 3790; 24: 3716 -> 3864;
-        // 32: 3871 -> 3980; 512x512 x 4: 941 -> 952, x 8: 985 -> 1006)
-        if (((n / K) * tiles_pf / 64) * ((c->Cb + 63) / 64) < c->pass_chains_min_blocks) return 1;
-    }
-    for (int k = 0; k < 2; ++k) {   // both chain sizes (n/K and n/K + 1 when n % K != 0)
-        const int nk = n / K + k;
-        if (k == 1 && n % K == 0) break;
-        if (bottleneck_form(c, nk) != 4 || (nk * tiles_pf) % 64 != 0) return 1;
-    }
-    return K;
+    auto fits = [&](int K) {
+        if (K < 2 || (int)c->side_streams.size() + 1 < K) return false;
+        if (n < c->pass_chains_min_frames || n < K) return false;
+        if (automatic) {   // only while a chain's bottleneck GEMM keeps >= 80 one-per-CU blocks (measured 256x256, frames/s off -> on:
+            // 8 frames = 64 blocks per chain 2981 -> 2397; 10: 2695 -> 2794; 12: 3018 -> 3105; 16: 3720 -> 3790; 24: 3716 -> 3864;
+            // 32: 3871 -> 3980; 512x512 x 4: 941 -> 952, x 8: 985 -> 1006)
+            if (((n / K) * tiles_pf / 64) * ((c->Cb + 63) / 64) < c->pass_chains_min_blocks) return false;
+        }
+        for (int k = 0; k < 2; ++k) {   // both chain sizes (n/K and n/K + 1 when n % K != 0)
+            const int nk = n / K + k;
+            if (k == 1 && n % K == 0) break;
+            if (bottleneck_form(c, nk) != 4 || (nk * tiles_pf) % 64 != 0) return false;
+        }
+        return true;
+    };
+    if (!automatic) return fits(c->pass_chains) ? c->pass_chains : 1;
+    // automatic: two chains; four from 64 frames per call, where every chain still gets 16 (256x256: 4150 -> 4197 frames/s,
+    // profiles/r04_experiments.txt section 16; four chains of 8 at 32 frames gain nothing over two of 16)
+    if (n >= 64 && fits(4)) return 4;
+    return fits(2) ? 2 : 1;
 }
 
 // One launch sequence over the frames of `v` on stream s.  `chained`: another sequence runs beside this one.

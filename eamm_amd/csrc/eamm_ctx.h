@@ -54,7 +54,7 @@ struct eamm_ctx : eamm::CtxBase {
                                            // when each chain's F(4x4) GEMM keeps enough workgroups (pass_chains_min_blocks); otherwise off)
     int pass_chains_min_blocks = 80;       // automatic mode: fewest bottleneck-GEMM workgroups per chain (EAMM_PASS_CHAINS_MIN_BLOCKS)
     int pass_chains_min_frames = 8;        // ... from this many frames per call (EAMM_PASS_CHAINS_MIN_FRAMES)
-    std::vector<hipStream_t> side_streams; // the other chains' streams + fork / join events
+    std::vector<hipStream_t> side_streams; // the other chains' streams (the device's shared pool: chain_stream(), not owned) + fork / join events
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_stagger = nullptr;       // recorded by the first chain after its first bottleneck input transform
     hipEvent_t ev_warp = nullptr;          // recorded by the first chain behind the joint warp launch (EAMM_WARP_JOINT)
