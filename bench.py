@@ -181,9 +181,10 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--clip-frames", type=int, default=2048, help="frames of the configs[3] clip leg (0 = skip)")
-    ap.add_argument("--clip-batch", type=int, default=64,
-                    help="frames per launch sequence of the clip leg (the clip harness is free to batch: 64 frames per call run 5 %% "
-                         "faster than 16; the contract line above stays at --batch)")
+    ap.add_argument("--clip-batch", type=int, default=None,
+                    help="frames per launch sequence of the clip leg (the clip harness is free to batch: 64 frames per call at 256x256 "
+                         "run 5 %% faster than 16; the contract line above stays at --batch).  Default: 64 at 256x256, the same number "
+                         "of pixels per call at other sizes (16 at 512x512: activations stay under the 4 GiB per tensor)")
     ap.add_argument("--clip-gather", action="store_true", help="clip leg: gather uint8 frames on rank 0 inside the timed region")
     ap.add_argument("--train-pairs", type=int, default=8, help="pairs per step of the training-step leg (N = 1 only; 0 = skip)")
     ap.add_argument("--graph", action="store_true",
@@ -349,7 +350,8 @@ def main():
     clip = None
     if args.clip_frames > 0:
         T = args.clip_frames
-        CB = max(1, min(args.clip_batch, -(-T // world)))
+        CB = args.clip_batch if args.clip_batch else max(B, 64 * 256 * 256 // (S * S))
+        CB = max(1, min(CB, -(-T // world)))
         if CB == B:
             gen_clip = gen
         else:   # its own module + engine handle (workspace for CB frames per call); the contract line's handle stays as it is
