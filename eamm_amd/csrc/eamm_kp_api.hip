@@ -19,6 +19,7 @@ struct eamm_kp_ctx : eamm::CtxBase {
     std::vector<LayerSet> hg_enc, hg_dec;
     ConvLayer head;               // kp (K) + jacobian (4*njm) stacked along Cout
     float* aa_w = nullptr;
+    float* img_stage = nullptr;   // num_channels 1 / 2: the image zero-extended to the three planes the anti-alias kernel reads
     float *x_in = nullptr, *logits = nullptr, *partial = nullptr;
     size_t partial_elems = 0;
     std::vector<float*> e_buf, u_buf;
@@ -63,7 +64,7 @@ int eamm_kp_create(const eamm_kp_config* cfg, int device, eamm_kp_ctx** out) {
     if (!cfg || !out) return fail(nullptr, EAMM_ERR_ARG, "null argument");
     *out = nullptr;
     const eamm_kp_config& g = *cfg;
-    if (g.num_channels != 3) return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 3");
+    if (g.num_channels < 1 || g.num_channels > 3) return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 1, 2 or 3 (got %d)", g.num_channels);
     if (g.num_kp < 1 || g.num_kp * (g.estimate_jacobian ? (g.single_jacobian_map ? 1 : 5) : 1) + (g.single_jacobian_map ? 4 : 0) > 64)
         return fail(nullptr, EAMM_ERR_ARG, "num_kp out of range for the 64-channel head");
     if (g.block_expansion % 32 || g.max_features % 32 || g.num_blocks < 1)
@@ -151,10 +152,16 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
         std::vector<float> aa(3 * 169, 0.f);
         if (g.inv_scale != 1) {
             const HostTensor* t = find(c, "down.weight");
-            if (!t || t->numel() != 3 * 169) return fail(c, EAMM_ERR_KEY, "down.weight must be [3,1,13,13]");
-            aa = t->data;
+            if (!t || (int)t->numel() != g.num_channels * 169)
+                return fail(c, EAMM_ERR_KEY, "down.weight must be [%d,1,13,13]", g.num_channels);
+            std::copy(t->data.begin(), t->data.end(), aa.begin());   // (the planes an image does not have keep zero filters)
         }
         if ((rc = upload(c, &c->aa_w, aa))) return rc;
+        if (g.num_channels != 3) {   // one / two image channels: the hourglass's first block has filters for those only (cin above)
+            const size_t n = (size_t)g.max_batch * 3 * c->H * c->W;
+            if ((rc = dev_alloc(c, &c->img_stage, n))) return rc;
+            HIP_TRY(c, hipMemset(c->img_stage, 0, n * sizeof(float)));
+        }
     } else {
         // KPDetector_a: the caller's feature map already is the hourglass output (feat_c channels)
         const int cp = (c->feat_c + 31) / 32 * 32;
@@ -204,6 +211,11 @@ int eamm_kp_detect(eamm_kp_ctx* c, const float* image, int B, const eamm_kp_outp
     if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     const int h = c->h, w = c->w;
+    if (c->img_stage) {   // [B,C,H,W] into the first C planes of [B,3,H,W]
+        const size_t HW = (size_t)c->H * c->W * sizeof(float), C = (size_t)c->cfg.num_channels;
+        HIP_TRY(c, hipMemcpy2DAsync(c->img_stage, 3 * HW, image, C * HW, C * HW, (size_t)B, hipMemcpyDeviceToDevice, s));
+        image = c->img_stage;
+    }
     // x = down(x): anti-aliased, NHWC zero-padded to Cin_pad channels            keypoint_detector.py:79-80
     HIP_TRY(c, antialias_down_launch(image, c->aa_w, B, c->H, c->W, c->cfg.inv_scale, c->Cin_pad, c->x_in, s));
     for (int i = 0; i < c->nb; ++i) {   // hourglass encoder                      util.py:956-960

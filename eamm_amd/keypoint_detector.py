@@ -145,8 +145,9 @@ class KPDetector(_KPBase):
             return self._forward(x)
 
     def _forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
-        if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:
-            raise RuntimeError(f"expected a float32 [B,3,H,W] image batch, got {tuple(x.shape)} {x.dtype}")
+        nc = self._cfg["num_channels"]
+        if x.dim() != 4 or x.shape[1] != nc or x.dtype != torch.float32:
+            raise RuntimeError(f"expected a float32 [B,{nc},H,W] image batch, got {tuple(x.shape)} {x.dtype}")
         b, _, hh, ww = x.shape
         self._ensure(hh, ww, b)
         inv, pad = self._cfg["inv_scale"], self._cfg["pad"]

@@ -160,7 +160,7 @@ int eamm_pass_chains(const eamm_ctx* ctx, int n);
 typedef struct eamm_kp_ctx eamm_kp_ctx;
 typedef struct eamm_kp_config {
     int32_t num_kp;                 /* 10                                                   */
-    int32_t num_channels;           /* 3                                                    */
+    int32_t num_channels;           /* 3 (1 and 2 accepted: the image is zero-extended)      */
     int32_t in_features;            /* hourglass input channels: num_channels (KPDetector) or num_channels_a */
     int32_t block_expansion;        /* 32                                                   */
     int32_t max_features;           /* 1024                                                 */

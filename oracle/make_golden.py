@@ -223,7 +223,7 @@ def emotion_case():
     print("emotion_offsets: wrote", len(blob), "arrays")
 
 
-def kp_detector_cases():
+def kp_detector_cases(only=None):
     """Fixtures for the key-point detectors (modules/keypoint_detector.py): the reference modules driven with
     seeded weights; the oracle must reproduce them; fp32-vs-fp64 noise floor recorded."""
     from eamm_amd.config import kp_detector_a_config, kp_detector_config, tiny_kp_config
@@ -233,7 +233,10 @@ def kp_detector_cases():
     report = {}
     for name, cfg, size, audio in (("kp_tiny64", tiny_kp_config(), 64, False), ("kp_full256", kp_detector_config(), 256, False),
                                    ("kpa_tiny", tiny_kp_config(audio=True), 64, True),
-                                   ("kpa_full", kp_detector_a_config(), 256, True)):
+                                   ("kpa_full", kp_detector_a_config(), 256, True),
+                                   ("kp_tiny64_gray", {**tiny_kp_config(), "num_channels": 1}, 64, False)):
+        if only and name not in only:
+            continue
         sd = synthetic_state_dict(cfg, seed=77, spec=kp_state_dict_spec(cfg))
         mod = (KPDetector_a if audio else KPDetector)(**cfg).eval()
         mod.load_state_dict(sd, strict=True)
@@ -244,7 +247,7 @@ def kp_detector_cases():
             x = torch.from_numpy(rs.standard_normal((b, cfg["block_expansion"] + cfg["num_channels_a"], hh, hh)).astype(np.float32))
             fwd = orc.kp_detector_a_forward
         else:
-            x = synthetic_source(size, seed=3, batch=b)
+            x = synthetic_source(size, seed=3, batch=b, channels=cfg["num_channels"])
             fwd = orc.kp_detector_forward
         with torch.no_grad():
             ref = mod(x)
@@ -264,7 +267,10 @@ def kp_detector_cases():
             blob[k + "_floor"] = np.float64(floor)
         np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **blob)
         print(name, {k: (f"{v['oracle_vs_reference']:.1e}", f"{v['fp32_vs_fp64_floor']:.1e}") for k, v in report[name].items()})
-    with open(os.path.join(GOLDEN, "summary_kp.json"), "w") as f:
+    path = os.path.join(GOLDEN, "summary_kp.json")
+    if only and os.path.exists(path):   # adding a fixture without regenerating the others
+        report = {**json.load(open(path)), **report}
+    with open(path, "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)
 
 
@@ -688,7 +694,7 @@ def main():
         emotion_case()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "kp":
-        kp_detector_cases()
+        kp_detector_cases(only=sys.argv[2:] or None)
         return
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)

@@ -14,14 +14,16 @@ from oracle import eamm_oracle as orc
 # stated tolerances (max abs); the reference's own fp32-vs-fp64 floor is <= 3.6e-6 / 8.4e-6 / 4.5e-6
 TOL_KP = {"value": 5e-5, "jacobian": 1e-4, "heatmap": 5e-5}
 CASES = [("kp_tiny64", lambda: tiny_kp_config(), False), ("kp_full256", kp_detector_config, False),
-         ("kpa_tiny", lambda: tiny_kp_config(audio=True), True), ("kpa_full", kp_detector_a_config, True)]
+         ("kpa_tiny", lambda: tiny_kp_config(audio=True), True), ("kpa_full", kp_detector_a_config, True),
+         ("kp_tiny64_gray", lambda: {**tiny_kp_config(), "num_channels": 1}, False)]   # one image channel (keypoint_detector.py:17-21)
 
 
 def load(name, cfg, audio):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     fx = {k: z[k] for k in z.files}
     sd = synthetic_state_dict(cfg, seed=int(fx["weight_seed"]), spec=kp_state_dict_spec(cfg))
-    x = torch.from_numpy(fx["feature_map"]) if audio else synthetic_source(int(fx["size"]), seed=3, batch=int(fx["batch"]))
+    x = torch.from_numpy(fx["feature_map"]) if audio else synthetic_source(int(fx["size"]), seed=3, batch=int(fx["batch"]),
+                                                                            channels=cfg["num_channels"])
     return fx, sd, x
 
 
@@ -90,8 +92,9 @@ def test_kp_detector_feeds_generator_contract():
     kp, kpa = kp.cuda().eval(), kpa.cuda().eval()
     src = synthetic_source(64, seed=1).cuda()
     fmap = torch.randn(1, 35, 16, 16, generator=torch.Generator().manual_seed(0)).cuda()
-    kp_source, kp_driving = kp(src), kpa(fmap)
-    out = gen(src, kp_source=kp_source, kp_driving=kp_driving)
+    with torch.no_grad():                 # demo.py:195: the whole animation loop runs without autograd
+        kp_source, kp_driving = kp(src), kpa(fmap)
+        out = gen(src, kp_source=kp_source, kp_driving=kp_driving)
     assert out["prediction"].shape == (1, 3, 64, 64) and torch.isfinite(out["prediction"]).all()
     sd_g = synthetic_state_dict(gcfg, seed=1234)
     with torch.no_grad():
