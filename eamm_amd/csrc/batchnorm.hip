@@ -79,8 +79,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_sums_kernel(const float
 // One wave per channel: lane l adds slices l, l + 64, ... and the lanes are folded in a fixed tree -- a fixed order, and no
 // thread walks the (up to 1024) slices of a channel through one dependent chain (23 us average, 108 us at worst, per call
 // when a thread did: 1.2 ms of a training step's 324 calls).
+__device__ __forceinline__ void bn_finalize_channel(int c, float sum, float ssum, double sum_d, double ssum_d, float size, float eps,
+                                                    float momentum, int mode, const float* __restrict__ weight,
+                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                    float* __restrict__ mean_out, float* __restrict__ scale_out,
+                                                    float* __restrict__ inv_std_out);
+__device__ __forceinline__ void bn_bwd_finalize_channel(int c, int C, double local_s1, double local_s2, double s1, double s2, double size,
+                                                        const float* __restrict__ inv_std, const float* __restrict__ weight, float eps,
+                                                        int mode, float* __restrict__ dweight, float* __restrict__ dbias,
+                                                        float* __restrict__ coef);
+
 __global__ __launch_bounds__(64) void bn_combine_kernel(const double* __restrict__ partial, int C, int P, long long count,
-                                                        float* __restrict__ sums) {
+                                                        float* __restrict__ sums, BnFuse fuse) {
     const int c = blockIdx.x, lane = threadIdx.x;
     double a = 0.0, b = 0.0;
     for (int p = lane; p < P; p += 64) {
@@ -95,9 +105,20 @@ __global__ __launch_bounds__(64) void bn_combine_kernel(const double* __restrict
         double* exact = reinterpret_cast<double*>(sums + 2 * C + 2);
         exact[c] = a;
         exact[C + c] = b;
+        const float lo = (float)(count % 4096), hi = (float)(count / 4096);
         if (c == 0) {
-            sums[2 * C] = (float)(count % 4096);
-            sums[2 * C + 1] = (float)(count / 4096);
+            sums[2 * C] = lo;
+            sums[2 * C + 1] = hi;
+        }
+        // One replica: nothing is exchanged between the sums and their finalize step, and that step reads only this channel's
+        // totals -- run it here (the values bn_finalize_kernel / bn_bwd_finalize_kernel would read back: bit-identical)
+        if (fuse.kind == 1) {
+            bn_finalize_channel(c, (float)a, (float)b, a, b, lo + 4096.f * hi, fuse.eps, fuse.momentum, fuse.mode, fuse.weight,
+                                fuse.running_mean, fuse.running_var, fuse.mean, fuse.scale, fuse.inv_std_out);
+        } else if (fuse.kind == 2) {
+            const double size = (double)lo + 4096.0 * (double)hi;
+            bn_bwd_finalize_channel(c, C, a, b, fuse.mode == 1 ? a : (double)(float)a, fuse.mode == 1 ? b : (double)(float)b, size,
+                                    fuse.inv_std, fuse.weight, fuse.eps, fuse.mode, fuse.dweight, fuse.dbias, fuse.coef);
         }
     }
 }
@@ -105,21 +126,13 @@ __global__ __launch_bounds__(64) void bn_combine_kernel(const double* __restrict
 // mode 0: the replicas' path (batchnorm.py:110-125): inv_std = clamp(biased var, eps) ^ -0.5
 // mode 1: the single-replica path F.batch_norm(training=True) (batchnorm.py:48-53): inv_std = 1 / sqrt(biased var + eps)
 // mode 2: evaluation: running statistics, nothing updated
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float eps, float momentum, int mode,
-                                   const float* __restrict__ weight, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ mean_out, float* __restrict__ scale_out,
-                                   float* __restrict__ inv_std_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// one channel of bn_finalize_kernel (modes 0 / 1) from its totals: the float pair the replicas exchange and the double pair behind it
+__device__ __forceinline__ void bn_finalize_channel(int c, float sum, float ssum, double sum_d, double ssum_d, float size, float eps,
+                                                    float momentum, int mode, const float* __restrict__ weight,
+                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                    float* __restrict__ mean_out, float* __restrict__ scale_out,
+                                                    float* __restrict__ inv_std_out) {
     const float w = weight != nullptr ? weight[c] : 1.f;
-    if (mode == 2) {
-        mean_out[c] = running_mean[c];
-        scale_out[c] = w / sqrtf(running_var[c] + eps);
-        if (inv_std_out) inv_std_out[c] = 1.f / sqrtf(running_var[c] + eps);
-        return;
-    }
-    const float size = sums[2 * C] + 4096.f * sums[2 * C + 1];
-    const float sum = sums[c], ssum = sums[C + c];
     float mean, unbias_var, inv_std;
     if (mode == 0) {   // the reference's float32 operations, in its order (batchnorm.py:113-125)
         mean = sum / size;
@@ -128,9 +141,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float 
         const float bias_var = sumvar / size;
         inv_std = powf(fmaxf(bias_var, eps), -0.5f);
     } else {           // ATen accumulates the batch statistics of a float tensor in double: use the double totals
-        const double* exact = reinterpret_cast<const double*>(sums + 2 * C + 2);
-        const double m = exact[c] / (double)size;
-        const double sumvar = exact[C + c] - exact[c] * m;
+        const double m = sum_d / (double)size;
+        const double sumvar = ssum_d - sum_d * m;
         mean = (float)m;
         unbias_var = (float)(sumvar / ((double)size - 1.0));
         inv_std = (float)(1.0 / sqrt(sumvar / (double)size + (double)eps));
@@ -140,6 +152,25 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float 
     mean_out[c] = mean;
     scale_out[c] = inv_std * w;
     if (inv_std_out) inv_std_out[c] = inv_std;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, float eps, float momentum, int mode,
+                                   const float* __restrict__ weight, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ mean_out, float* __restrict__ scale_out,
+                                   float* __restrict__ inv_std_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (mode == 2) {
+        const float w = weight != nullptr ? weight[c] : 1.f;
+        mean_out[c] = running_mean[c];
+        scale_out[c] = w / sqrtf(running_var[c] + eps);
+        if (inv_std_out) inv_std_out[c] = 1.f / sqrtf(running_var[c] + eps);
+        return;
+    }
+    const float size = sums[2 * C] + 4096.f * sums[2 * C + 1];
+    const double* exact = reinterpret_cast<const double*>(sums + 2 * C + 2);
+    bn_finalize_channel(c, sums[c], sums[C + c], exact[c], exact[C + c], size, eps, momentum, mode, weight, running_mean, running_var,
+                        mean_out, scale_out, inv_std_out);
 }
 
 // y = (x - mean[c]) * scale[c] + bias[c]     (batchnorm.py:74-79); grid (N*C planes, slices)
@@ -221,22 +252,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float*
 // local: this replica's packed sums (dweight / dbias); reduced: the same buffer after the caller's all-reduce of its first
 // 2C + 2 floats (may be the same pointer on one replica).  coef[c], coef[C + c], coef[2C + c] = S1 / N, S2 * inv_std^2 / N,
 // weight * inv_std for bn_bwd_apply_kernel.  mode as in bn_finalize_kernel (2 = evaluation: statistics are constants).
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ local, const float* __restrict__ reduced, int C,
-                                       const float* __restrict__ inv_std, const float* __restrict__ weight, float eps, int mode,
-                                       float* __restrict__ dweight, float* __restrict__ dbias, float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double* lex = reinterpret_cast<const double*>(local + 2 * C + 2);
+__device__ __forceinline__ void bn_bwd_finalize_channel(int c, int C, double local_s1, double local_s2, double s1, double s2, double size,
+                                                        const float* __restrict__ inv_std, const float* __restrict__ weight, float eps,
+                                                        int mode, float* __restrict__ dweight, float* __restrict__ dbias,
+                                                        float* __restrict__ coef) {
     const double is = (double)inv_std[c];
-    if (dbias) dbias[c] = (float)lex[c];
-    if (dweight) dweight[c] = (float)(lex[C + c] * is);
+    if (dbias) dbias[c] = (float)local_s1;
+    if (dweight) dweight[c] = (float)(local_s2 * is);
     const float w = weight != nullptr ? weight[c] : 1.f;
     double a = 0.0, b = 0.0;
     if (mode != 2) {
-        const double size = (double)reduced[2 * C] + 4096.0 * (double)reduced[2 * C + 1];
-        // one replica: the double totals (nothing was exchanged); several: the all-reduced floats, as the forward does
-        const double* rex = reinterpret_cast<const double*>(reduced + 2 * C + 2);
-        const double s1 = mode == 1 ? rex[c] : (double)reduced[c], s2 = mode == 1 ? rex[C + c] : (double)reduced[C + c];
         const bool clamped = mode == 0 && inv_std[c] >= powf(eps, -0.5f);   // clamp(var, eps): no gradient through the variance
         a = s1 / size;
         b = clamped ? 0.0 : s2 * is * is / size;
@@ -244,6 +269,23 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ local, const fl
     coef[c] = (float)a;
     coef[C + c] = (float)b;
     coef[2 * C + c] = (float)(is * (double)w);
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ local, const float* __restrict__ reduced, int C,
+                                       const float* __restrict__ inv_std, const float* __restrict__ weight, float eps, int mode,
+                                       float* __restrict__ dweight, float* __restrict__ dbias, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double* lex = reinterpret_cast<const double*>(local + 2 * C + 2);
+    double s1 = 0.0, s2 = 0.0, size = 1.0;
+    if (mode != 2) {
+        size = (double)reduced[2 * C] + 4096.0 * (double)reduced[2 * C + 1];
+        // one replica: the double totals (nothing was exchanged); several: the all-reduced floats, as the forward does
+        const double* rex = reinterpret_cast<const double*>(reduced + 2 * C + 2);
+        s1 = mode == 1 ? rex[c] : (double)reduced[c];
+        s2 = mode == 1 ? rex[C + c] : (double)reduced[C + c];
+    }
+    bn_bwd_finalize_channel(c, C, lex[c], lex[C + c], s1, s2, size, inv_std, weight, eps, mode, dweight, dbias, coef);
 }
 
 template <int VEC>
@@ -290,12 +332,12 @@ hipError_t bn_local_sums_launch(const float* x, int N, int C, int HW, float* sum
         hipLaunchKernelGGL(bn_partial_sums_kernel<4>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, N, C, HW, S, R, part);
     else
         hipLaunchKernelGGL(bn_partial_sums_kernel<1>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, N, C, HW, S, R, part);
-    hipLaunchKernelGGL(bn_combine_kernel, dim3(C), dim3(64), 0, s, part, C, S * R, (long long)N * HW, sums);
+    hipLaunchKernelGGL(bn_combine_kernel, dim3(C), dim3(64), 0, s, part, C, S * R, (long long)N * HW, sums, BnFuse{});
     return hipGetLastError();
 }
 
-hipError_t bn_combine_launch(const double* partial, int C, int P, long long count, float* sums, hipStream_t s) {
-    hipLaunchKernelGGL(bn_combine_kernel, dim3(C), dim3(64), 0, s, partial, C, P, count, sums);
+hipError_t bn_combine_launch(const double* partial, int C, int P, long long count, float* sums, hipStream_t s, const BnFuse* fuse) {
+    hipLaunchKernelGGL(bn_combine_kernel, dim3(C), dim3(64), 0, s, partial, C, P, count, sums, fuse ? *fuse : BnFuse{});
     return hipGetLastError();
 }
 
@@ -328,7 +370,7 @@ hipError_t bn_bwd_sums_launch(const float* x, const float* dy, const float* mean
         hipLaunchKernelGGL(bn_bwd_partial_kernel<4>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, dy, mean, N, C, HW, S, R, part);
     else
         hipLaunchKernelGGL(bn_bwd_partial_kernel<1>, dim3(C, S, R), dim3(BN_THREADS), 0, s, x, dy, mean, N, C, HW, S, R, part);
-    hipLaunchKernelGGL(bn_combine_kernel, dim3(C), dim3(64), 0, s, part, C, S * R, (long long)N * HW, sums);
+    hipLaunchKernelGGL(bn_combine_kernel, dim3(C), dim3(64), 0, s, part, C, S * R, (long long)N * HW, sums, BnFuse{});
     return hipGetLastError();
 }
 

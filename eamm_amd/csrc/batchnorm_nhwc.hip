@@ -186,13 +186,13 @@ size_t bn_nhwc_workspace_floats(long long M, int C) {
     return (size_t)C * nhwc_slices(M, C / 4) * 2 * 2;   // doubles as floats
 }
 
-hipError_t bn_nhwc_sums_launch(const float* x, long long M, int C, float* sums, float* workspace, hipStream_t s) {
+hipError_t bn_nhwc_sums_launch(const float* x, long long M, int C, float* sums, float* workspace, hipStream_t s, const BnFuse* fuse) {
     if (C < 4 || (C & 3) || C / 4 > NB_THREADS || M < 1) return hipErrorInvalidValue;
     const int C4 = C / 4, R = nhwc_slices(M, C4), lanes = NB_THREADS / C4;
     double* part = reinterpret_cast<double*>(workspace);
     const size_t lds = sizeof(double) * (size_t)lanes * C4 * 8;
     hipLaunchKernelGGL(bn_nhwc_partial_kernel, dim3(R), dim3(NB_THREADS), lds, s, reinterpret_cast<const float4*>(x), M, C4, R, part);
-    return bn_combine_launch(part, C, R, M, sums, s);
+    return bn_combine_launch(part, C, R, M, sums, s, fuse);
 }
 
 hipError_t bn_nhwc_apply_launch(const float* x, const float* mean, const float* scale, const float* bias, int B, int H, int W, int C,
@@ -211,7 +211,7 @@ hipError_t bn_nhwc_apply_launch(const float* x, const float* mean, const float* 
 }
 
 hipError_t bn_nhwc_bwd_sums_launch(const float* x, const float* dy, const float* mean, const float* scale, const float* bias, int B, int H,
-                                   int W, int C, int relu, int pool, float* sums, float* workspace, hipStream_t s) {
+                                   int W, int C, int relu, int pool, float* sums, float* workspace, hipStream_t s, const BnFuse* fuse) {
     const long long M = (long long)B * H * W;
     if (C < 4 || (C & 3) || C / 4 > NB_THREADS || M < 1 || (pool && ((H | W) & 1))) return hipErrorInvalidValue;
     const int C4 = C / 4, R = nhwc_slices(M, C4), lanes = NB_THREADS / C4;
@@ -224,7 +224,7 @@ hipError_t bn_nhwc_bwd_sums_launch(const float* x, const float* dy, const float*
     };
     if (pool) launch(bn_nhwc_bwd_partial_kernel<true>);
     else launch(bn_nhwc_bwd_partial_kernel<false>);
-    return bn_combine_launch(part, C, R, M, sums, s);
+    return bn_combine_launch(part, C, R, M, sums, s, fuse);
 }
 
 hipError_t bn_nhwc_bwd_apply_launch(const float* x, const float* dy, const float* mean, const float* scale, const float* bias,

@@ -94,6 +94,46 @@ int eamm_bn_nhwc_local_sums(const float* x, long long M, int C, float* sums, flo
     return bn_check(bn_nhwc_sums_launch(x, M, C, sums, workspace, reinterpret_cast<hipStream_t>(stream)), "bn_nhwc_local_sums");
 }
 
+int eamm_bn_nhwc_local_stats(const float* x, long long M, int C, float eps, float momentum, int mode, const float* weight,
+                             float* running_mean, float* running_var, float* sums, float* mean, float* scale, float* inv_std,
+                             float* workspace, void* stream) {
+    if (!x || !sums || !workspace || !running_mean || !running_var || !mean || !scale) return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (M < 1 || C < 4 || (C & 3) || C > 1024 || M >= (1ll << 36)) return bn_fail(EAMM_ERR_ARG, "bad shape [%lld,%d] (C a multiple of 4, at most 1024)", M, C);
+    if (mode != 0 && mode != 1) return bn_fail(EAMM_ERR_ARG, "mode must be 0 (replicas' formula) or 1 (single replica)");
+    BnFuse f;
+    f.kind = 1;
+    f.mode = mode;
+    f.eps = eps;
+    f.momentum = momentum;
+    f.weight = weight;
+    f.running_mean = running_mean;
+    f.running_var = running_var;
+    f.mean = mean;
+    f.scale = scale;
+    f.inv_std_out = inv_std;
+    return bn_check(bn_nhwc_sums_launch(x, M, C, sums, workspace, reinterpret_cast<hipStream_t>(stream), &f), "bn_nhwc_local_stats");
+}
+
+int eamm_bn_nhwc_backward_local(const float* x, const float* dy, const float* mean, const float* scale, const float* bias, int B, int H,
+                                int W, int C, int relu, int pool, const float* inv_std, const float* weight, float eps, int mode,
+                                float* sums, float* grad_weight, float* grad_bias, float* coef, float* workspace, void* stream) {
+    if (!x || !dy || !mean || !scale || !sums || !workspace || !inv_std || !coef) return bn_fail(EAMM_ERR_ARG, "null argument");
+    if (B < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || C > 1024 || (pool && ((H | W) & 1)))
+        return bn_fail(EAMM_ERR_ARG, "bad shape [%d,%d,%d,%d]", B, H, W, C);
+    if (mode != 0 && mode != 1) return bn_fail(EAMM_ERR_ARG, "mode must be 0 (replicas' formula) or 1 (single replica)");
+    BnFuse f;
+    f.kind = 2;
+    f.mode = mode;
+    f.eps = eps;
+    f.weight = weight;
+    f.inv_std = inv_std;
+    f.dweight = grad_weight;
+    f.dbias = grad_bias;
+    f.coef = coef;
+    return bn_check(bn_nhwc_bwd_sums_launch(x, dy, mean, scale, bias, B, H, W, C, relu, pool, sums, workspace,
+                                            reinterpret_cast<hipStream_t>(stream), &f), "bn_nhwc_backward_local");
+}
+
 int eamm_bn_nhwc_apply(const float* x, const float* mean, const float* scale, const float* bias, int B, int H, int W, int C, int relu,
                        int pool, float* y, void* stream) {
     if (!x || !mean || !scale || !y) return bn_fail(EAMM_ERR_ARG, "null argument");

@@ -205,15 +205,28 @@ hipError_t bn_bwd_apply_launch(const float* x, const float* dy, const float* mea
 hipError_t bn_apply_launch(const float* x, const float* mean, const float* scale, const float* bias, int N, int C, int HW,
                            float* y, hipStream_t s);
 // NHWC variants for the engine's training-mode forward (batchnorm_nhwc.hip); sums / finalize as above
-hipError_t bn_combine_launch(const double* partial /*[C][P][2]*/, int C, int P, long long count, float* sums /*[6C+2]*/, hipStream_t s);
+// The finalize step of one replica folded into bn_combine_kernel (kind 1: bn_finalize_kernel's modes 0 / 1; kind 2:
+// bn_bwd_finalize_kernel's with reduced == local): nothing is exchanged in between and the step reads only its own channel's totals.
+struct BnFuse {
+    int kind = 0, mode = 1;
+    float eps = 0.f, momentum = 0.f;
+    const float* weight = nullptr;
+    float *running_mean = nullptr, *running_var = nullptr, *mean = nullptr, *scale = nullptr, *inv_std_out = nullptr;   // kind 1
+    const float* inv_std = nullptr;                                                                                   // kind 2
+    float *dweight = nullptr, *dbias = nullptr, *coef = nullptr;
+};
+hipError_t bn_combine_launch(const double* partial /*[C][P][2]*/, int C, int P, long long count, float* sums /*[6C+2]*/, hipStream_t s,
+                             const BnFuse* fuse = nullptr);
 size_t bn_nhwc_workspace_floats(long long M, int C);
-hipError_t bn_nhwc_sums_launch(const float* x /*[M,C]*/, long long M, int C, float* sums /*[6C+2]*/, float* workspace, hipStream_t s);
+hipError_t bn_nhwc_sums_launch(const float* x /*[M,C]*/, long long M, int C, float* sums /*[6C+2]*/, float* workspace, hipStream_t s,
+                               const BnFuse* fuse = nullptr);
 hipError_t bn_nhwc_apply_launch(const float* x /*[B,H,W,C]*/, const float* mean, const float* scale, const float* bias, int B, int H,
                                 int W, int C, int relu, int pool, float* y, hipStream_t s);
 // backward of the fused tail y = [avgpool2x2](act(BatchNorm(x))) on NHWC: packed sums like bn_bwd_sums_launch, then dx with
 // bn_bwd_finalize_launch's coefficients (the ReLU mask is recomputed from x)
 hipError_t bn_nhwc_bwd_sums_launch(const float* x, const float* dy, const float* mean, const float* scale, const float* bias, int B, int H,
-                                   int W, int C, int relu, int pool, float* sums, float* workspace, hipStream_t s);
+                                   int W, int C, int relu, int pool, float* sums, float* workspace, hipStream_t s,
+                                   const BnFuse* fuse = nullptr);
 hipError_t bn_nhwc_bwd_apply_launch(const float* x, const float* dy, const float* mean, const float* scale, const float* bias,
                                     const float* coef, int B, int H, int W, int C, int relu, int pool, float* dx, hipStream_t s);
 hipError_t to_u8_launch(const float* pred /*[n,3,H,W]*/, int n, int H, int W, uint8_t* out /*[n,H,W,3]*/,

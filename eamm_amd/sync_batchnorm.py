@@ -181,12 +181,17 @@ class _BatchNormNHWCFunction(torch.autograd.Function):
         parallel = world > 1 if mod.sync is None else bool(mod.sync)
         sums = torch.empty(6 * c + 2, dtype=torch.float32, device=dev)
         work = torch.empty(max(1, L.eamm_bn_nhwc_workspace_floats(m, c)), dtype=torch.float32, device=dev)
+        mode = BN_SYNC if parallel else BN_SINGLE
         with torch.cuda.device(dev):
-            _check(L.eamm_bn_nhwc_local_sums(ptr(x), m, c, ptr(sums), ptr(work), st))
             if world > 1 and parallel:
+                _check(L.eamm_bn_nhwc_local_sums(ptr(x), m, c, ptr(sums), ptr(work), st))
                 mod._all_reduce(sums[:2 * c + 2])
-            mode = BN_SYNC if parallel else BN_SINGLE
-            mean, scale, inv_std = mod._ops.finalize(sums, mod, mode)
+                mean, scale, inv_std = mod._ops.finalize(sums, mod, mode)
+            else:   # one replica: nothing to exchange -- the finalize step runs inside the kernel that adds the slices up
+                mean, scale, inv_std = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(3))
+                _check(L.eamm_bn_nhwc_local_stats(ptr(x), m, c, float(mod.eps), float(mod.momentum), mode, ptr(mod.weight),
+                                                  ptr(mod.running_mean), ptr(mod.running_var), ptr(sums), ptr(mean), ptr(scale),
+                                                  ptr(inv_std), ptr(work), st))
             y = torch.empty((b, h // 2, w // 2, c) if pool else (b, h, w, c), dtype=torch.float32, device=dev)
             _check(L.eamm_bn_nhwc_apply(ptr(x), ptr(mean), ptr(scale), ptr(bias), b, h, w, c, int(relu), int(pool), ptr(y), st))
         ctx.mod, ctx.mode, ctx.relu, ctx.pool = mod, mode, bool(relu), bool(pool)
@@ -206,15 +211,21 @@ class _BatchNormNHWCFunction(torch.autograd.Function):
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         local = torch.empty(6 * c + 2, dtype=torch.float32, device=dev)
         work = torch.empty(max(1, L.eamm_bn_nhwc_workspace_floats(b * h * w, c)), dtype=torch.float32, device=dev)
+        want_wb = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         with torch.cuda.device(dev):
-            _check(L.eamm_bn_nhwc_backward_sums(ptr(x), ptr(dy), ptr(mean), ptr(scale), ptr(bias), b, h, w, c, int(ctx.relu),
-                                                int(ctx.pool), ptr(local), ptr(work), st))
-            reduced = local
             if ctx.reduce:
+                _check(L.eamm_bn_nhwc_backward_sums(ptr(x), ptr(dy), ptr(mean), ptr(scale), ptr(bias), b, h, w, c, int(ctx.relu),
+                                                    int(ctx.pool), ptr(local), ptr(work), st))
                 reduced = local.clone()
                 mod._all_reduce(reduced[:2 * c + 2])
-            want_wb = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-            coef, dw, db = mod._ops.backward_finalize(local, reduced, inv_std, weight, mod.eps, ctx.mode, want_wb)
+                coef, dw, db = mod._ops.backward_finalize(local, reduced, inv_std, weight, mod.eps, ctx.mode, want_wb)
+            else:   # one replica: sums and their finalize step in one call
+                coef = torch.empty(3 * c, dtype=torch.float32, device=dev)
+                dw = torch.empty(c, dtype=torch.float32, device=dev) if want_wb else None
+                db = torch.empty(c, dtype=torch.float32, device=dev) if want_wb else None
+                _check(L.eamm_bn_nhwc_backward_local(ptr(x), ptr(dy), ptr(mean), ptr(scale), ptr(bias), b, h, w, c, int(ctx.relu),
+                                                     int(ctx.pool), ptr(inv_std), ptr(weight), float(mod.eps), ctx.mode, ptr(local),
+                                                     ptr(dw), ptr(db), ptr(coef), ptr(work), st))
             dx = None
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)

@@ -272,6 +272,17 @@ int eamm_bn_nhwc_backward_sums(const float* x, const float* grad_out, const floa
                                int H, int W, int C, int relu, int pool, float* sums, float* workspace, void* stream);
 int eamm_bn_nhwc_backward_apply(const float* x, const float* grad_out, const float* mean, const float* scale, const float* bias,
                                 const float* coef, int B, int H, int W, int C, int relu, int pool, float* grad_x, void* stream);
+/* One replica (nothing to all-reduce between the sums and their finalize step): eamm_bn_nhwc_local_sums + eamm_bn_finalize, and
+ * eamm_bn_nhwc_backward_sums + eamm_bn_backward_finalize (reduced_sums == local_sums), each as ONE call -- the finalize step runs
+ * in the kernel that adds the slices up, on the values the separate entry would read back (bit-identical results, two launches
+ * fewer per BatchNorm site and direction).  mode 0 | 1 as eamm_bn_finalize; `sums` is still written. */
+int eamm_bn_nhwc_local_stats(const float* x, long long M, int C, float eps, float momentum, int mode, const float* weight,
+                             float* running_mean, float* running_var, float* sums, float* mean, float* scale, float* inv_std,
+                             float* workspace, void* stream);
+int eamm_bn_nhwc_backward_local(const float* x, const float* grad_out, const float* mean, const float* scale, const float* bias, int B,
+                                int H, int W, int C, int relu, int pool, const float* inv_std, const float* weight, float eps, int mode,
+                                float* sums, float* grad_weight /*[C] or NULL*/, float* grad_bias /*[C] or NULL*/, float* coef /*[3C]*/,
+                                float* workspace, void* stream);
 int eamm_bn_apply(const float* x, const float* mean, const float* scale, const float* bias, int N, int C, int HW, float* y,
                   void* stream);
 const char* eamm_bn_last_error(void);

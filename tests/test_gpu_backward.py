@@ -267,6 +267,53 @@ def test_fused_nhwc_batchnorm_matches_autograd(relu, pool, sync):
     assert all(v <= 5e-6 for v in errs.values()), errs
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fused_statistics_entries_equal_the_separate_ones_bit_for_bit(mode):
+    """One replica: eamm_bn_nhwc_local_stats = eamm_bn_nhwc_local_sums + eamm_bn_finalize, eamm_bn_nhwc_backward_local =
+    eamm_bn_nhwc_backward_sums + eamm_bn_backward_finalize (the finalize step inside the kernel that adds the slices up)."""
+    L = _lib.lib()
+    B, H, W, C = 4, 16, 24, 96
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.5 + 0.3).to(DEV)
+    dy = torch.randn(B, H // 2, W // 2, C, generator=g).to(DEV)
+    wt, bs = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    M = B * H * W
+    work = torch.empty(L.eamm_bn_nhwc_workspace_floats(M, C), device=DEV)
+    p = lambda t: t.data_ptr()
+    new = lambda n: torch.full((n,), float("nan"), device=DEV)
+
+    def forward(fused):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        sums, mean, scale, inv = new(6 * C + 2), new(C), new(C), new(C)
+        if fused:
+            _lib.check(L.eamm_bn_nhwc_local_stats(p(x), M, C, 1e-5, 0.1, mode, p(wt), p(rm), p(rv), p(sums), p(mean), p(scale), p(inv), p(work), st), None)
+        else:
+            _lib.check(L.eamm_bn_nhwc_local_sums(p(x), M, C, p(sums), p(work), st), None)
+            _lib.check(L.eamm_bn_finalize(p(sums), C, 1e-5, 0.1, mode, p(wt), p(rm), p(rv), p(mean), p(scale), p(inv), st), None)
+        return rm, rv, sums[:2 * C + 2].clone(), mean, scale, inv
+
+    a, b = forward(False), forward(True)
+    torch.cuda.synchronize()
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    mean, scale, inv = a[3], a[4], a[5]
+
+    def backward(fused):
+        sums, coef, dw, db = new(6 * C + 2), new(3 * C), new(C), new(C)
+        if fused:
+            _lib.check(L.eamm_bn_nhwc_backward_local(p(x), p(dy), p(mean), p(scale), p(bs), B, H, W, C, 1, 1, p(inv), p(wt), 1e-5, mode,
+                                                     p(sums), p(dw), p(db), p(coef), p(work), st), None)
+        else:
+            _lib.check(L.eamm_bn_nhwc_backward_sums(p(x), p(dy), p(mean), p(scale), p(bs), B, H, W, C, 1, 1, p(sums), p(work), st), None)
+            _lib.check(L.eamm_bn_backward_finalize(p(sums), p(sums), C, p(inv), p(wt), 1e-5, mode, p(dw), p(db), p(coef), st), None)
+        return coef, dw, db
+
+    a, b = backward(False), backward(True)
+    torch.cuda.synchronize()
+    assert all(torch.equal(u, v) and bool(torch.isfinite(u).all()) for u, v in zip(a, b))
+    assert L.eamm_bn_nhwc_local_stats(p(x), M, C, 1e-5, 0.1, 2, p(wt), p(wt), p(wt), p(work), p(wt), p(wt), p(wt), p(work), st) != 0   # mode 2: no statistics
+
+
 def test_backward_entry_points_reject_bad_arguments():
     L = _lib.lib()
     t = torch.zeros(64, device=DEV)
