@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -87,8 +88,9 @@ def _worker(rank, world, port, total, batch, tmp):
     dist.destroy_process_group()
 
 
-def test_two_rank_clip_equals_single_process(tmp_path):
-    total, batch, world = 5, 2, 2
+@pytest.mark.parametrize("total", [5, 1])     # 1: the second rank's shard is EMPTY (more ranks than frames)
+def test_two_rank_clip_equals_single_process(tmp_path, total):
+    batch, world = 2, 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
