@@ -80,6 +80,45 @@ def measured_traffic(form, size, batch, chains=1):
     return int((rec["fetch_size_kb"] * 2 + rec["write_size_kb"]) * 1024), rec.get("files")
 
 
+FIXTURES = {256: "full256_clip2", 512: "full512_clip1"}   # reference outputs (oracle/make_golden.py) at the two BASELINE sizes
+PARITY_TOL = 1e-4          # max |prediction - reference|, tests/conftest.py TOL["prediction"]
+PLAN_TOL = 2e-5            # the same frames under two launch plans (summation order only), tests/test_gpu_plan64.py
+
+
+def fixture_parity(pred, size):
+    """max |pred[t] - reference| over the frames of the committed reference fixture of this size: frames t = 0.. of a clip whose
+    driving key points are synthetic_keypoints(seed=2), source seed 1, weights seed 1234 -- exactly what the timed launches
+    and the clip leg compute -- at the fixture's sampling stride.  Data only: nothing of the oracle or the reference runs here."""
+    import numpy as np
+    name = FIXTURES.get(size)
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz") if name else None
+    if not path or not os.path.exists(path):
+        return {"fixture": None, "ok": None, "note": f"no committed reference fixture at {size}x{size}"}
+    z = np.load(path)
+    want = torch.from_numpy(z["prediction"])
+    st = int(z["prediction_stride"])
+    n = want.shape[0]
+    got = pred[:n, :, ::st, ::st].float().cpu()
+    err = float((got - want).abs().max())
+    return {"fixture": f"tests/golden/{name}.npz", "frames": n, "stride": st, "max_abs_err": err, "tolerance": PARITY_TOL,
+            "ok": bool(err <= PARITY_TOL)}
+
+
+def knob_record(eng, frames, extra_plans=None):
+    """What the measured library was configured with: every EAMM_* variable in the environment, every knob the library read
+    (value in effect, set or default) and the launch plan it chose for the timed call."""
+    from eamm_amd import _lib
+    from eamm_amd.engine import library_knobs
+    rec = {"env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("EAMM_") and not k.startswith("EAMM_BENCH_")},
+           "library": {k: v["value"] for k, v in library_knobs().items() if v["set"]},
+           "library_defaults_read": len(library_knobs()),
+           "experiments_build": int(_lib.lib().eamm_build_experiments()),
+           "plan": eng.describe_plan(frames)}
+    for name, (e, n) in (extra_plans or {}).items():
+        rec[name] = e.describe_plan(n)
+    return rec
+
+
 def cpu_baseline(cfg, sd, size, frames, passes=5):
     """Reference-equivalent CPU loop (demo.py:251-281) on the oracle: B=1, encoder per frame; median of `passes`."""
     from oracle import eamm_oracle as orc  # checker / baseline only; never on the product path
@@ -268,6 +307,25 @@ def main():
     gen = gen.to(dev).eval()
     B, S = args.batch, args.size
     eng = gen._ensure_engine(S, S, B, 1)
+    from eamm_amd import _lib as _eamm_lib
+    if _eamm_lib.lib().eamm_build_experiments():
+        raise SystemExit("bench.py: this libeamm_hip.so was built with -DEAMM_EXPERIMENTS (timing experiments that compute wrong "
+                         "results are compiled in): refusing to benchmark it -- rebuild with `make -C eamm_amd/csrc`")
+    rccl_warmup_ms = None
+    if use_dist:
+        # communicator set-up (RCCL ring construction, first-call kernel loads) happens HERE, outside every timed region:
+        # one broadcast + one all-reduce + one gather of the kinds the legs use, then a barrier
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wdev = dev if backend == "nccl" else "cpu"
+        w = torch.ones(1 << 20, device=wdev)
+        dist.broadcast(w, src=0)
+        dist.all_reduce(w)
+        bufs = [torch.empty(16, device=wdev) for _ in range(world)] if rank == 0 else None
+        dist.gather(torch.zeros(16, device=wdev), bufs, dst=0)
+        dist.barrier()
+        torch.cuda.synchronize()
+        rccl_warmup_ms = (time.perf_counter() - t0) * 1e3
 
     # once per clip: rank 0 encodes the source, the cached tensors are broadcast (the only collective)
     t_bcast_ms = None
@@ -343,6 +401,11 @@ def main():
     chk = step()["prediction"]
     assert bool(torch.isfinite(chk).all()) and 0.0 < float(chk.min()) and float(chk.max()) < 1.0 and float(chk.std()) > 0.02, \
         "bench.py: the forward pass produced non-finite or degenerate frames"
+    # parity spot check AT THE TIMED GEOMETRY: rank 0's first frames are the committed reference fixture's frames (same seeds);
+    # a build or knob that computes something else does not get a `value` printed
+    parity = fixture_parity(chk, S) if rank == 0 else None
+    if parity is not None and parity["ok"] is False:
+        raise SystemExit(f"bench.py: the timed launches do not reproduce the reference fixture: {json.dumps(parity)}")
     del chk
     dt = max_over_ranks(dt)
 
@@ -366,22 +429,60 @@ def main():
         else:
             c_src = c_kps = c_kpd = None
 
-        def run_clip(timings=None):
+        def run_clip(timings=None, keep=False):
             out, span = animate_clip(be, c_src, c_kps, c_kpd, S, S, uint8=args.clip_gather, gather=args.clip_gather,
                                      timings=timings)
             n = out.shape[0]
+            if keep:
+                return out, span
             del out
             return n, span
 
         run_clip()                        # warm-up pass (allocator, RCCL channels)
         fence()
         t0 = time.perf_counter()
-        n_local, span = run_clip()
+        clip_out, span = run_clip(keep=True)
         fence()
         dt_clip = max_over_ranks(time.perf_counter() - t0)
+        # what the TIMED pass produced, checked (it used to be deleted unseen): (i) rank 0's first frames against the committed
+        # reference fixture, (ii) on every rank three frames of its shard -- first, middle, last -- against the same frames
+        # recomputed by the contract handle (its launch plan: `--batch` frames per call) from this rank's own copy of the
+        # key points, (iii) range.  The clip's plan (64 frames per call = four chains) and the shards are thereby verified
+        # in the run that is reported; a mismatch refuses the line.
+        a_sh, b_sh = (span if not args.clip_gather else shard_bounds(T, world, rank))
+        verify = {"ok": True}
+        if clip_out.shape[0] and not args.clip_gather:
+            assert bool(torch.isfinite(clip_out).all()) and 0.0 < float(clip_out.min()) and float(clip_out.max()) < 1.0
+            if rank == 0:
+                verify["fixture"] = fixture_parity(clip_out, S)
+                verify["ok"] = verify["fixture"]["ok"] is not False
+            spots = sorted({a_sh, (a_sh + b_sh) // 2, b_sh - 1})[:B]   # (the contract handle holds the same source: encoded /
+            # imported before the timed region above)
+            kp_sp = {k: torch.cat([v.to(dev) for v in [synthetic_keypoints(1, cfg["num_kp"], seed=2 + t)[k] for t in spots]])
+                     for k in ("value", "jacobian")}
+            again = eng.forward_frames(kp_sp, kp_s, outputs=("prediction",))["prediction"]
+            worst = float((again - clip_out[[t - a_sh for t in spots]]).abs().max())
+            verify.update({"spot_frames": spots, "vs_contract_plan_max_abs": worst, "plan_tolerance": PLAN_TOL})
+            verify["ok"] = bool(verify["ok"] and worst <= PLAN_TOL)
+            del again
+        ok_all = max_over_ranks(0.0 if verify["ok"] else 1.0) == 0.0
+        if not ok_all:
+            raise SystemExit(f"bench.py: the clip leg's frames failed verification on some rank (rank {rank}: {json.dumps(verify)})")
+        n_local = clip_out.shape[0]
+        del clip_out
         phases = {}
         run_clip(phases)                  # third pass with a device sync at each phase boundary: where the time goes
         fence()
+        # every rank's phases, gathered (one fixed-order float tensor; outside every timed region)
+        PH = ("keypoints_ms", "encode_ms", "broadcast_ms", "compute_ms", "gather_ms")
+        mine = torch.tensor([phases.get(k, 0.0) for k in PH], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if use_dist:
+            allp = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allp, mine)
+        else:
+            allp = [mine]
+        phases_all = [{k: round(float(v), 3) for k, v in zip(PH, t.tolist())} for t in allp]
+        clip_plan = be.engine.describe_plan(min(CB, max(1, b_sh - a_sh))) if rank == 0 else None
         if gen_clip is not gen:
             del be, gen_clip
         torch.cuda.empty_cache()
@@ -391,6 +492,8 @@ def main():
                     "timed": "source encode (rank 0) + broadcast of source cache and key points + compute of every "
                              "shard" + (" + uint8 gather on rank 0" if args.clip_gather else "") + ", max over ranks",
                     "phases_ms_rank0": {k: round(v, 3) for k, v in phases.items()},
+                    "phases_ms_per_rank": phases_all, "verify": verify, "plan": clip_plan,
+                    "collectives_per_clip": 0 if world == 1 else 2 + int(bool(args.clip_gather)),
                     "workload": f"{S}x{S}, {T}-frame clip, contiguous shards of {T}/{world} frames, batch {CB} "
                                 f"(BASELINE.json configs[3])"}
 
@@ -494,7 +597,8 @@ def main():
                                    f"encoded once per clip (BASELINE.json {which})",
                        "frames_per_step_per_gpu": B, "parallelism": f"frame-sharded x{world}",
                        "flops_per_frame": round(eng.flops_per_frame / 1e9, 3)},
-            "roofline": {"bound": "mfma",
+            "roofline": {"bound": "mfma", "flops_basis": "executed (what the kernels' grids issue: Winograd F(4x4) = 1/4 of the reference's "
+                                                         "multiplies); `achieved` / `frac` / `per_launch` / `whole_path.executed_*` all use it",
                          "kernel": {4: f"wino4_gemm_kernel (bottleneck 3x3 {cb}->{cb} @{hf}x{hf} in Winograd F(4x4,3x3) form)",
                                     2: f"wino_gemm_kernel<1,2,4,2> (bottleneck 3x3 {cb}->{cb} @{hf}x{hf} in Winograd F(2x2,3x3) form)",
                                     0: f"conv_mfma_dma_kernel<3,3,...> (bottleneck 3x3 {cb}->{cb} @{hf}x{hf}, direct)"}[form],
@@ -523,6 +627,9 @@ def main():
                                         "algorithmic_tflops": round(fps / world * eng.flops_per_frame / 1e12, 2)},
                          "achieved_algorithmic": round(algo, 2),
                          "frac_algorithmic": round(algo / FP32_MFMA_PEAK_TFLOPS, 4),   # whole stage vs the CHIP peak
+                         "algorithmic_note": "reference-equivalent: the REFERENCE's direct-convolution FLOPs of the stage / the same time; "
+                                             "exceeds 1 by construction (the kernels execute 4x fewer multiplies) -- not a hardware "
+                                             "utilisation figure, see `frac`",
                          "algorithmic_gflop_per_step": round(algo_flop_step / 1e9, 2),
                          "avg_input_transform_ms": round(ms_tr, 4)},
             # the HBM-bound kernel of the path (north_star: ">= 60 % of HBM roofline on the warp"): feature warp x occlusion,
@@ -543,8 +650,12 @@ def main():
             "stage_region_ms_per_step": round(ms_step_prof, 4),   # wall clock of the second (event-instrumented) K steps
             "stage_roofline": stage_roofline,
         }
+        line["parity_check"] = parity
+        line["knobs"] = knob_record(eng, B)
         if t_bcast_ms is not None:
             line["source_broadcast_ms"] = round(t_bcast_ms, 3)
+        if rccl_warmup_ms is not None:
+            line["rccl_warmup_ms"] = round(rccl_warmup_ms, 2)    # communicator set-up, before every timed region
         line["clip"] = clip
         if graph_leg is not None:
             line["graph"] = graph_leg

@@ -79,6 +79,10 @@ SIGNATURES = {
     "eamm_encode_flops": (C.c_double, [C.c_void_p]),
     "eamm_bottleneck_chains": (C.c_int, [C.c_void_p, C.c_int]),
     "eamm_pass_chains": (C.c_int, [C.c_void_p, C.c_int]),
+    "eamm_last_stream_set": (C.c_int, [C.c_void_p]),
+    "eamm_describe_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
+    "eamm_knobs_json": (C.c_int, [C.c_char_p, C.c_int]),
+    "eamm_build_experiments": (C.c_int, []),
     "eamm_kp_create": (C.c_int, [C.POINTER(EammKpConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "eamm_kp_destroy": (None, [C.c_void_p]),
     "eamm_kp_last_error": (C.c_char_p, [C.c_void_p]),

@@ -5,9 +5,10 @@ re-runs the source encoder every time) and copy ``out['prediction']`` to the hos
 frame).  Here: the source is encoded ONCE, frames are processed ``batch`` at a time, results stay on
 the device (optionally as uint8 HWC frames, the format demo.py:507 writes), and -- because the
 generator has no cross-frame dependence -- a clip shards across the GPUs of a node by contiguous
-frame ranges.  The only collective on the data path is one broadcast of the cached source tensors
-(encoder feature map + down-sampled source + full-resolution source, ~5 MB at 256x256) from rank 0
-over RCCL/xGMI, plus the (tiny) key-point tensors; outputs are gathered only if asked for.
+frame ranges.  The data path has TWO collectives per clip, both broadcasts from rank 0 over RCCL/xGMI: a six-integer
+header and one float32 payload = cached source tensors (encoder feature map + down-sampled source +
+full-resolution source, ~5 MB at 256x256) | kp_source | kp_driving (0.5 MB for 2048 frames); outputs are
+gathered only if asked for (one more).
 
 ``torch.distributed`` is used as plumbing: backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the
 CPU tests, which drive this file with a stand-in backend object (tests/test_clip_sharding.py).
@@ -45,6 +46,9 @@ class EngineBackend:
 
     def blob_like(self) -> torch.Tensor:
         return torch.empty(self.engine.source_cache_numel(1), dtype=torch.float32, device=self.device)
+
+    def blob_numel(self) -> int:
+        return self.engine.source_cache_numel(1)
 
     def install(self, blob: torch.Tensor):
         self.engine.import_source_cache(blob, 1)
@@ -95,20 +99,48 @@ def _broadcast(t: torch.Tensor, src: int, group, staged: bool):
         t.copy_(h)
 
 
-def _bcast_kp(kp: Optional[Dict[str, torch.Tensor]], device, src: int, group, staged: bool = False) -> Dict[str, torch.Tensor]:
-    """Broadcast a key-point dict from `src` (shapes first, then payload)."""
+_HEADER_FIELDS = 6   # T, K, driving jacobian present, source jacobian present, source sets, blob elements
+
+
+def _broadcast_clip(blob: Optional[torch.Tensor], kp_source, kp_driving, blob_numel: int, device, src: int, group,
+                    staged: bool):
+    """Everything the ranks need for one clip in TWO collectives: a fixed six-integer header (frame count, key-point count,
+    which jacobians exist, source sets, cache size) and ONE float32 payload = source cache | kp_source | kp_driving.
+    No pickled objects on the data path (a ``broadcast_object_list`` is a host-synchronising pickle round trip per call; the
+    round-4 pipeline issued two of them plus five tensor broadcasts per clip).  Returns (blob, kp_source, kp_driving)."""
     rank = dist.get_rank(group)
-    meta = [None]
+    hdev = torch.device("cpu") if staged else device
     if rank == src:
-        meta = [{k: tuple(v.shape) for k, v in kp.items() if k in ("value", "jacobian")}]
-    dist.broadcast_object_list(meta, src=src, group=group)
-    out = {}
-    for k in sorted(meta[0]):
-        t = kp[k].to(device=device, dtype=torch.float32).contiguous() if rank == src else \
-            torch.empty(meta[0][k], dtype=torch.float32, device=device)
-        _broadcast(t, src, group, staged)
-        out[k] = t
-    return out
+        kv, ksv = kp_driving["value"], kp_source["value"]
+        head = torch.tensor([kv.shape[0], kv.shape[1], int("jacobian" in kp_driving), int("jacobian" in kp_source),
+                             ksv.shape[0], blob.numel()], dtype=torch.int64, device=hdev)
+    else:
+        head = torch.zeros(_HEADER_FIELDS, dtype=torch.int64, device=hdev)
+    dist.broadcast(head, src=src, group=group)
+    T, K, jd, js, S, nblob = (int(v) for v in head.tolist())
+    if nblob != blob_numel:
+        raise RuntimeError(f"rank {rank}: source cache of {blob_numel} floats here, {nblob} on rank {src} (different configurations?)")
+    sizes = [nblob, S * K * 2, S * K * 4 * js, T * K * 2, T * K * 4 * jd]
+    if rank == src:
+        f32 = lambda t: t.to(device=device, dtype=torch.float32).reshape(-1)
+        parts = [blob.reshape(-1), f32(kp_source["value"])]
+        if js:
+            parts.append(f32(kp_source["jacobian"]))
+        parts.append(f32(kp_driving["value"]))
+        if jd:
+            parts.append(f32(kp_driving["jacobian"]))
+        payload = torch.cat(parts)
+    else:
+        payload = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    _broadcast(payload, src, group, staged)
+    blob_o, ksv, ksj, kdv, kdj = torch.split(payload, sizes)
+    ks = {"value": ksv.view(S, K, 2)}
+    kd = {"value": kdv.view(T, K, 2)}
+    if js:
+        ks["jacobian"] = ksj.view(S, K, 2, 2)
+    if jd:
+        kd["jacobian"] = kdj.view(T, K, 2, 2)
+    return blob_o, ks, kd
 
 
 def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optional[Dict[str, torch.Tensor]],
@@ -165,13 +197,12 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
     # 1. frame-invariant source tensors: encode once on rank 0, one broadcast
     if distributed:
         staged = _staged(group, backend.device)
-        blob = backend.encode(source_image) if rank == 0 else backend.blob_like()
+        blob = backend.encode(source_image) if rank == 0 else None
         mark("encode_ms")
-        _broadcast(blob, 0, group, staged)
+        nblob = backend.blob_numel() if hasattr(backend, "blob_numel") else backend.blob_like().numel()
+        blob, kp_source, kp_driving = _broadcast_clip(blob, kp_source, kp_driving, nblob, backend.device, 0, group, staged)
         if rank != 0:
-            backend.install(blob)
-        kp_source = _bcast_kp(kp_source, backend.device, 0, group, staged)
-        kp_driving = _bcast_kp(kp_driving, backend.device, 0, group, staged)
+            backend.install(blob.contiguous())
         mark("broadcast_ms")
     else:
         backend.encode(source_image)

@@ -405,10 +405,7 @@ int launch_up(CtxBase* c, const LayerSet& S, const ConvIO& io, hipStream_t s) {
     return EAMM_OK;
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+int env_int(const char* name, int dflt) { return (int)knob_int(name, dflt); }   // recorded: eamm_knobs_json
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 

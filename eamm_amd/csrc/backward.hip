@@ -468,8 +468,8 @@ size_t conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int k
 namespace {
 // F(3x3,4x4) form: 3x3, map sides multiples of 4, enough tiles for the GEMMs' K (EAMM_WGRAD_WINO4 = 0 turns it off)
 bool wgrad_wino4_applies(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
-    static const int off = [] { const char* e = getenv("EAMM_WGRAD_WINO4"); return e ? atoi(e) == 0 : 0; }();
-    static const long long min_tiles = [] { const char* e = getenv("EAMM_WGRAD_WINO4_MIN_TILES"); return e ? atoll(e) : 512ll; }();
+    static const int off = knob_int("EAMM_WGRAD_WINO4", 1) == 0;
+    static const long long min_tiles = knob_int("EAMM_WGRAD_WINO4_MIN_TILES", 512);
     return !off && kh == 3 && kw == 3 && !(H & 3) && !(W & 3) && !(Cin & 3) && !(Cout & 3) &&
            (long long)B * (H / 4) * (W / 4) >= min_tiles;
 }
@@ -537,7 +537,7 @@ hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int 
     } else {
         a.x = x;
         a.dy = dy;
-        static const int row_off = [] { const char* e = getenv("EAMM_WGRAD_ROW"); return e ? atoi(e) == 0 : 0; }();
+        static const int row_off = knob_int("EAMM_WGRAD_ROW", 1) == 0;
         const bool row = !row_off && W % 32 == 0 && (kw == 1 || kw == 3 || kw == 7);   // one block per filter row (else: per tap)
         const long long tiles = (long long)a.mt * a.nt * (row ? kh : taps);
         const long long splits = wgrad_splits(tiles, a.P, 256);

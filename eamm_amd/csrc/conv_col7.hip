@@ -602,8 +602,12 @@ static hipError_t col7_launch_impl(const float* in, int C, int B, int H, int W, 
     a.out = out;
     a.bias = bias;
     a.final_out = final_out;
-    static const int dbg = [] { const char* e = getenv("EAMM_COL7_DBG"); return e ? atoi(e) : 0; }();
+#ifdef EAMM_EXPERIMENTS   // diagnostic builds only (make EXPERIMENTS=1): the product library never drops the DMA / the epilogue
+    static const int dbg = (int)knob_int("EAMM_COL7_DBG", 0);
     a.dbg = dbg;
+#else
+    a.dbg = 0;
+#endif
     const size_t lds = wb + sizeof(float) * (2 * CPIX * CONV_BK + (fused ? 2 * CT * 6 * 21 : 0));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static lds_once_mask configured{0}, configured_fused{0};
@@ -616,7 +620,7 @@ static hipError_t col7_launch_impl(const float* in, int C, int B, int H, int W, 
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int blocks = std::min(fused ? B * a.tiles_y : a.tiles, cus);
     // EAMM_FINAL_MFMA4 = 0: the fused form on the 32x32x2 MFMA with N padded to 32 (round 3); default: the 4x4x1 multi-block form
-    static const bool mfma4 = [] { const char* e = getenv("EAMM_FINAL_MFMA4"); return e ? atoi(e) != 0 : true; }();
+    static const bool mfma4 = knob_int("EAMM_FINAL_MFMA4", 1) != 0;
     if (fused && mfma4) {
         // (one patch piece of the next unit per tap, six of the seven taps: issuing them twice as densely at the start of the
         // unit measured the same -- 210.4 vs 213.4 us at 8 frames, 3915 vs 3912 frames/s in the pipeline)

@@ -27,6 +27,11 @@
 //   * blockIdx is remapped so that consecutive logical tiles (same M tile, all N tiles) share an XCD
 //     and therefore an L2.
 #include "conv_common.h"
+#include <map>
+#include <mutex>
+#include <string>
+#include <cstdlib>
+#include <algorithm>
 
 #include <algorithm>
 #include <cstring>
@@ -364,6 +369,39 @@ double take_mfma_flops() {
     const double v = g_mfma_flops;
     g_mfma_flops = 0.0;
     return v;
+}
+
+namespace {
+std::mutex g_knob_mu;
+std::map<std::string, std::pair<long long, bool>> g_knobs;
+}
+long long knob_int(const char* name, long long dflt) {
+    const char* v = getenv(name);
+    const long long val = v ? atoll(v) : dflt;
+    std::lock_guard<std::mutex> lock(g_knob_mu);
+    auto it = g_knobs.find(name);
+    if (it == g_knobs.end()) g_knobs.emplace(name, std::make_pair(val, v != nullptr));
+    else if (v != nullptr) it->second = std::make_pair(val, true);   // (a per-handle default may differ between handles: the set value wins)
+    return val;
+}
+int knobs_json(char* buf, int cap) {
+    std::string out = "{";
+    {
+        std::lock_guard<std::mutex> lock(g_knob_mu);
+        bool first = true;
+        for (const auto& kv : g_knobs) {
+            if (!first) out += ", ";
+            first = false;
+            out += "\"" + kv.first + "\": {\"value\": " + std::to_string(kv.second.first) + ", \"set\": " + (kv.second.second ? "1" : "0") + "}";
+        }
+    }
+    out += "}";
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>(out.size(), (size_t)cap - 1);
+        std::memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (int)out.size();
 }
 
 hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream, int force_splits) {

@@ -293,7 +293,7 @@ int patch_poly_splits(const PatchLayer& L, int B, int H, int W, int max_splits, 
     const int cchunks = (L.C0 + L.C1) / CONV_BK;
     // fewest channel chunks per workgroup: 4; calls of one or two frames (128 workgroups per up block on 256 CUs) go down to 2
     // (one frame 1071 -> 1094 frames/s; at 8-frame chains the extra workgroups compete with the other chain: 3848 vs 3837)
-    static const int min_env = [] { const char* e = getenv("EAMM_PATCH_SPLIT_MIN_CHUNKS"); return e ? atoi(e) : 0; }();
+    static const int min_env = (int)knob_int("EAMM_PATCH_SPLIT_MIN_CHUNKS", 0);
     const int min_chunks = min_env > 0 ? min_env : (B <= 2 ? 2 : 4);
     for (int sp : {4, 2})
         if (sp <= max_splits && blocks * sp <= cus && cchunks % sp == 0 && cchunks / sp >= min_chunks) return sp;

@@ -598,8 +598,7 @@ hipError_t wino4_transform_launch(const float* x, const float* s, const float* t
                                   hipStream_t stream) {
     if ((H & 3) || (W & 3) || (C & 3)) return hipErrorInvalidValue;
     static const int vec_env = [] {   // EAMM_WINO4_TR_VEC = 1 | 2 | 4 forces the channels per thread; unset: by launch size
-        const char* e = getenv("EAMM_WINO4_TR_VEC");
-        const int v = e ? atoi(e) : 0;
+        const int v = (int)knob_int("EAMM_WINO4_TR_VEC", 0);
         return (v == 1 || v == 2 || v == 4) ? v : 0;
     }();
     // one 256x256 frame is 64 workgroups of four-channel threads on 256 CUs: one channel per thread fills the chip and shortens
@@ -650,7 +649,7 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     a.mtiles = (a.Mq + BM - 1) / BM;
     a.ntiles = L.ntiles;
     // very few tiles (one 256x256 frame: 4 x 4 x 6 = 96 workgroups): 32-tile blocks of four waves double the grid
-    static const int narrow_max = [] { const char* e = getenv("EAMM_WINO4_NARROW_MAX_BLOCKS"); return e ? atoi(e) : 128; }();
+    static const int narrow_max = (int)knob_int("EAMM_WINO4_NARROW_MAX_BLOCKS", 128);
     const bool narrow = groups == 6 && a.mtiles * a.ntiles * groups <= narrow_max && L.Cin % (4 * CONV_BK) == 0;
     if (narrow) a.mtiles = (a.Mq + 31) / 32;
     a.act = act;
@@ -660,8 +659,14 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     if (groups > 1 && zbuf == nullptr) return hipErrorInvalidValue;
     a.groups = groups;
     a.zout = groups > 1 ? zbuf : nullptr;
+#ifdef EAMM_EXPERIMENTS
     a.epi_scratch = (variant == 50 && groups == 1) ? zbuf : nullptr;
     if (variant == 50 && a.epi_scratch == nullptr) variant = 3;
+#else
+    // variants 10 / 16 / 17 / 50 are timing experiments that compute WRONG results (no DMA in the loop, interval traces, V-sized
+    // extra output): they exist only in a -DEAMM_EXPERIMENTS build (make EXPERIMENTS=1); the product library refuses them
+    if (variant == 10 || variant == 16 || variant == 17 || variant == 50) return hipErrorInvalidValue;
+#endif
     const size_t vb = (size_t)36 * a.Mq * a.C * sizeof(float), ub = wino4_packed_elems(L.Cout, L.Cin, BN) * sizeof(float);
     if (vb >= 0xFFFFF000ull || ub >= 0xFFFFF000ull) return hipErrorInvalidValue;
     a.v_bytes = (unsigned)vb;
@@ -671,16 +676,18 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     if (narrow) variant = 30;
     switch (variant) {   // (chunks per barrier, ring depth, MFMAs per DMA piece)
         case 30: e = wino4_launch_variant<4, 2, 4, 0, 2>(a, stream); break;
+#ifdef EAMM_EXPERIMENTS
         case 50: e = sub4 ? wino4_launch_variant<4, 2, 8, 30>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream); break;
+        case 10: e = wino4_launch_variant<4, 2, 4, 1>(a, stream); break;
+        case 16: e = wino4_launch_variant<4, 2, 4, 8>(a, stream); break;
+        case 17: e = wino4_launch_variant<4, 2, 4, 9>(a, stream); break;
+#endif
         case 0: e = sub4 ? wino4_launch_variant<4, 2, 4>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream); break;
         case 1: e = wino4_launch_variant<2, 2, 4>(a, stream); break;
         case 2: e = wino4_launch_variant<2, 3, 4>(a, stream); break;
         case 3: e = sub4 ? wino4_launch_variant<4, 2, 8>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream); break;
         case 4: e = wino4_launch_variant<2, 4, 4>(a, stream); break;
         case 5: e = sub4 ? wino4_launch_variant<4, 2, 4, 20>(a, stream) : wino4_launch_variant<2, 2, 4, 20>(a, stream); break;
-        case 10: e = wino4_launch_variant<4, 2, 4, 1>(a, stream); break;
-        case 16: e = wino4_launch_variant<4, 2, 4, 8>(a, stream); break;
-        case 17: e = wino4_launch_variant<4, 2, 4, 9>(a, stream); break;
         default: break;
     }
     if (e != hipSuccess || groups == 1) return e;

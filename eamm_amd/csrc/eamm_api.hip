@@ -91,20 +91,68 @@ int pad_norm(eamm_ctx* c, const std::string& norm, int c_r, int c_p) {
     }
     return 0;
 }
-// The chains' side streams are a per-device pool shared by every handle of the process (created on first use, never destroyed):
-// the runtime multiplexes streams onto a few hardware queues (four by default), and a second handle with its own three streams
-// made two chains of one call share a queue -- measured: a 64-frame call's four chains 4199 frames/s alone, 4007 beside another
-// handle's stream.  Handles used from different threads then share the streams' order, never their dependencies (every call
-// forks from and joins to its caller's stream with its own events).
+// The chains' side streams come from a per-device pool shared by every handle of the process (created on first use, never
+// destroyed): the runtime multiplexes streams onto a few hardware queues (four by default), and a second handle with its own
+// three streams made two chains of one call share a queue -- measured: a 64-frame call's four chains 4199 frames/s alone, 4007
+// beside another handle's streams.  The pool is LEASED for the duration of one call's enqueue (StreamLease below): a call that
+// finds it taken by another host thread, or whose caller's stream is being captured into a HIP graph (the side streams join
+// that capture until it ends, so nobody else may touch them meanwhile), runs on the handle's own private streams instead.
+// Calls of different handles that follow one another on the pool share the streams' ORDER, never their dependencies: every
+// call forks from and joins to its caller's stream with its own events.
+constexpr int POOL_MAXDEV = 64, POOL_MAXCHAIN = 15;
+std::mutex g_pool_mu;
+hipStream_t g_pool[POOL_MAXDEV][POOL_MAXCHAIN] = {};
+std::mutex g_pool_lease[POOL_MAXDEV];
+
 hipStream_t chain_stream(int device, int k) {
-    constexpr int MAXDEV = 64, MAXCHAIN = 15;
-    static std::mutex mu;
-    static hipStream_t pool[MAXDEV][MAXCHAIN] = {};
-    if (device < 0 || device >= MAXDEV || k < 0 || k >= MAXCHAIN) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!pool[device][k] && hipStreamCreateWithFlags(&pool[device][k], hipStreamNonBlocking) != hipSuccess) pool[device][k] = nullptr;
-    return pool[device][k];
+    if (device < 0 || device >= POOL_MAXDEV || k < 0 || k >= POOL_MAXCHAIN) return nullptr;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (!g_pool[device][k] && hipStreamCreateWithFlags(&g_pool[device][k], hipStreamNonBlocking) != hipSuccess) g_pool[device][k] = nullptr;
+    return g_pool[device][k];
 }
+
+// Picks the side streams of ONE eamm_forward_frames call (c->side_streams) and holds the pool's lease while the call enqueues.
+struct StreamLease {
+    eamm_ctx* c;
+    bool held = false;
+    int rc = EAMM_OK;
+    StreamLease(eamm_ctx* ctx, hipStream_t caller) : c(ctx) {
+        if (c->pool_streams.empty()) return;   // a handle without chains
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(caller, &cap) != hipSuccess) {
+            (void)hipGetLastError();
+            cap = hipStreamCaptureStatusNone;
+        }
+        const bool capturing = cap != hipStreamCaptureStatusNone;
+        const bool in_range = c->device >= 0 && c->device < POOL_MAXDEV;
+        if (!capturing && !c->private_streams && in_range && g_pool_lease[c->device].try_lock()) {
+            held = true;
+            c->side_streams = c->pool_streams;
+            c->last_streams = 0;
+            return;
+        }
+        if (c->own_streams.size() < c->pool_streams.size()) {
+            // created on first need; inside a capture under the relaxed mode (stream creation is not a captured operation,
+            // but the global capture mode refuses API calls it cannot prove harmless)
+            hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+            if (capturing) (void)hipThreadExchangeStreamCaptureMode(&mode);
+            while (c->own_streams.size() < c->pool_streams.size()) {
+                hipStream_t st = nullptr;
+                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+                    rc = fail(c, EAMM_ERR_HIP, "hipStreamCreate failed for a private chain stream");
+                    break;
+                }
+                c->own_streams.push_back(st);
+            }
+            if (capturing) (void)hipThreadExchangeStreamCaptureMode(&mode);
+        }
+        c->side_streams = c->own_streams;
+        c->last_streams = capturing ? 2 : 1;
+    }
+    ~StreamLease() {
+        if (held) g_pool_lease[c->device].unlock();
+    }
+};
 
 int pad_state_dict(eamm_ctx* c) {
     const std::string dm = "dense_motion_network.";
@@ -262,11 +310,26 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->bneck_stagger = env_int("EAMM_BNECK_STAGGER", c->bneck_stagger);
     c->warp_joint = env_int("EAMM_WARP_JOINT", c->warp_joint);
     c->enc_cus_pct = std::max(1, env_int("EAMM_ENC_CUS_PCT", c->enc_cus_pct));
+    c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
+#ifdef EAMM_EXPERIMENTS
     c->epi_v = env_int("EAMM_WINO4_EPI_V", c->epi_v);
+#else
+    // timing experiments that compute wrong results exist only in a -DEAMM_EXPERIMENTS build (make EXPERIMENTS=1): the product
+    // library refuses to run with their knobs set rather than ignoring them silently (or, worse, obeying them)
+    for (const char* bad : {"EAMM_WINO4_EPI_V", "EAMM_COL7_DBG"})
+        if (getenv(bad) && atoi(getenv(bad)) != 0) {
+            delete c;
+            return fail(nullptr, EAMM_ERR_ARG, "%s is a wrong-results timing experiment: it needs a library built with make EXPERIMENTS=1", bad);
+        }
+    if (c->wino4_variant == 10 || c->wino4_variant == 16 || c->wino4_variant == 17 || c->wino4_variant == 50) {
+        const int v = c->wino4_variant;
+        delete c;
+        return fail(nullptr, EAMM_ERR_ARG, "EAMM_WINO4_VARIANT=%d is a wrong-results timing experiment: it needs make EXPERIMENTS=1", v);
+    }
+#endif
     c->pass_chains_min_frames = env_int("EAMM_PASS_CHAINS_MIN_FRAMES", c->pass_chains_min_frames);
     c->pass_chains_min_blocks = env_int("EAMM_PASS_CHAINS_MIN_BLOCKS", c->pass_chains_min_blocks);
     c->head_col7_min_tiles = env_int("EAMM_HEAD_COL7_MIN_TILES", c->head_col7_min_tiles);
-    c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
     c->enc_wino = env_int("EAMM_ENC_WINO", c->enc_wino);
     c->first7 = env_int("EAMM_FIRST7", c->first7);
     c->enc_wino_min_mflop = env_int("EAMM_ENC_WINO_MIN_MFLOP", c->enc_wino_min_mflop);
@@ -288,6 +351,7 @@ void eamm_destroy(eamm_ctx* c) {
     if (c->ev_stagger) (void)hipEventDestroy(c->ev_stagger);
     if (c->ev_warp) (void)hipEventDestroy(c->ev_warp);
     for (auto& e : c->ev_join) (void)hipEventDestroy(e);
+    for (auto& st : c->own_streams) (void)hipStreamDestroy(st);   // (drains the stream's work first; the pool's streams stay)
     delete c;
 }
 
@@ -597,6 +661,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
         c->flops_frame = ff;
     }
     const int max_chains = std::max(c->bneck_chains, c->pass_chains == 0 ? (g.max_frames >= 64 ? 4 : 2) : c->pass_chains);
+    c->private_streams = env_int("EAMM_PRIVATE_STREAMS", 0);
     if (max_chains > 1) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming));
@@ -605,11 +670,16 @@ int eamm_finalize_weights(eamm_ctx* c) {
             hipStream_t st = chain_stream(c->device, k - 1);
             hipEvent_t ev = nullptr;
             if (!st) return fail(c, EAMM_ERR_HIP, "hipStreamCreate failed for chain %d", k);
-            c->side_streams.push_back(st);
+            c->pool_streams.push_back(st);
             HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             c->ev_join.push_back(ev);
+            // the private twin (StreamLease): created here, outside any graph capture; idle unless a call needs it
+            hipStream_t own = nullptr;
+            HIP_TRY(c, hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+            c->own_streams.push_back(own);
         }
     }
+    c->side_streams = c->pool_streams;   // (plan queries count them; every call picks its set: StreamLease)
     c->sd.clear();
     HIP_TRY(c, hipDeviceSynchronize());
     c->finalized = true;
@@ -1143,6 +1213,8 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
         o = &staged;
     }
 
+    StreamLease lease(c, s);
+    if (lease.rc) return lease.rc;
     hipEvent_t* ev = nullptr;  // stage boundaries (of the main stream's sequence), recorded only while profiling
     hipEvent_t* cev = nullptr; // bottleneck window of every whole-pass chain
     const int chains = pass_chains(c, n);
@@ -1375,6 +1447,44 @@ int eamm_bottleneck_chains(const eamm_ctx* c, int n) {
 int eamm_pass_chains(const eamm_ctx* c, int n) {
     if (!c || n <= 0) return EAMM_ERR_ARG;
     return pass_chains(c, n);
+}
+int eamm_last_stream_set(const eamm_ctx* c) { return c ? c->last_streams : EAMM_ERR_ARG; }
+int eamm_build_experiments(void) {
+#ifdef EAMM_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+int eamm_knobs_json(char* buf, int cap) { return knobs_json(buf, cap); }
+int eamm_describe_plan(const eamm_ctx* c, int n, char* buf, int cap) {
+    if (!c || n <= 0 || n > c->cfg.max_frames || !c->finalized) return EAMM_ERR_ARG;
+    const int pc = pass_chains(c, n), nk = pc > 1 ? n / pc : n;
+    const int form = bottleneck_form(c, nk), bc = pc > 1 ? pc : bottleneck_chains(c, n);
+    std::string enc = "[";
+    for (int i = 0; i < c->nb; ++i) {   // the test forward_view applies per hourglass encoder level, for one chain's frames
+        const int tiles = nk * ((c->h >> i) / 4) * ((c->w >> i) / 4);
+        const bool heavy = i < (int)c->w4enc.size() && 144.0 * c->w4enc[i].Cin * c->w4enc[i].Cout > 100e6;
+        const bool w4 = i < (int)c->w4enc.size() && c->w4enc[i].Cout && tiles >= c->enc_wino_min_tiles * (heavy ? 4 : 1) &&
+                        288e-6 * tiles * c->w4enc[i].Cin * c->w4enc[i].Cout >= (double)c->enc_wino_min_mflop;
+        enc += std::string(i ? ", " : "") + (w4 ? "\"wino4\"" : "\"direct\"");
+    }
+    enc += "]";
+    const bool fused = c->final_w_swz && c->final_fused && nk * ((c->H + 15) / 16) >= c->final_fused_min_rows;
+    char tmp[1024];
+    const int len = snprintf(tmp, sizeof tmp,
+                             "{\"frames\": %d, \"pass_chains\": %d, \"frames_per_chain\": %d, \"bottleneck_form\": %d, \"bottleneck_chains\": %d, "
+                             "\"wino4_groups\": %d, \"wino4_variant\": %d, \"hg_encoder\": %s, \"final\": \"%s\", \"warp_joint\": %d, "
+                             "\"bneck_stagger\": %d, \"side_streams\": %d, \"experiments_build\": %d}",
+                             n, pc, nk, form, bc, (form == 4 && pc == 1 && bc == 1) ? wino4_groups(c, n) : 1, c->wino4_variant, enc.c_str(),
+                             fused ? "col7q fused" : "col7 + shift-sum", c->warp_joint, c->bneck_stagger, (int)c->pool_streams.size(),
+                             eamm_build_experiments());
+    if (buf && cap > 0) {
+        const int m = std::min(len, cap - 1);
+        std::memcpy(buf, tmp, (size_t)m);
+        buf[m] = 0;
+    }
+    return len;
 }
 double eamm_encode_flops(const eamm_ctx* c) { return c ? c->flops_encode : 0.0; }
 
@@ -1730,8 +1840,8 @@ bool conv_dev_plan(int B, int H, int W, int Cin, int Cout, int kh, int kw, ConvD
     if (!((kh == 3 && kw == 3) || (kh == 7 && kw == 7))) return false;
     const long long Mq = (long long)B * (H / 4) * (W / 4);
     // F(4x4,3x3) where the bottleneck's kernel applies and the tile count fills the chip; else the register-staged implicit GEMM
-    static const int wino_off = [] { const char* e = getenv("EAMM_CONV_DEV_WINO4"); return e ? atoi(e) == 0 : 0; }();
-    static const long long wino_min_tiles = [] { const char* e = getenv("EAMM_CONV_DEV_WINO4_MIN_TILES"); return e ? atoll(e) : 2048ll; }();
+    static const int wino_off = knob_int("EAMM_CONV_DEV_WINO4", 1) == 0;
+    static const long long wino_min_tiles = knob_int("EAMM_CONV_DEV_WINO4_MIN_TILES", 2048);
     P->wino4 = !wino_off && kh == 3 && kw == 3 && Cin % (2 * CONV_BK) == 0 && !(H & 3) && !(W & 3) && Mq >= wino_min_tiles &&
                (unsigned long long)36 * Mq * Cin * sizeof(float) < 0xFFFFF000ull &&
                wino4_packed_elems(Cout, Cin, 64) * sizeof(float) < 0xFFFFF000ull;

@@ -54,7 +54,12 @@ struct eamm_ctx : eamm::CtxBase {
                                            // when each chain's F(4x4) GEMM keeps enough workgroups (pass_chains_min_blocks); otherwise off)
     int pass_chains_min_blocks = 80;       // automatic mode: fewest bottleneck-GEMM workgroups per chain (EAMM_PASS_CHAINS_MIN_BLOCKS)
     int pass_chains_min_frames = 8;        // ... from this many frames per call (EAMM_PASS_CHAINS_MIN_FRAMES)
-    std::vector<hipStream_t> side_streams; // the other chains' streams (the device's shared pool: chain_stream(), not owned) + fork / join events
+    std::vector<hipStream_t> side_streams; // the other chains' streams of the call being enqueued: pool_streams or own_streams (StreamLease in eamm_api.hip)
+    std::vector<hipStream_t> pool_streams; // ... the device's shared pool (chain_stream(), not owned)
+    std::vector<hipStream_t> own_streams;  // ... this handle's private set: used while the caller's stream is being captured or another
+                                           // thread holds the pool; created on first need, destroyed with the handle
+    int private_streams = 0;               // EAMM_PRIVATE_STREAMS=1: always the private set
+    int last_streams = 0;                  // which set the last call used: 0 pool, 1 private (pool taken), 2 private (capture)
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_stagger = nullptr;       // recorded by the first chain after its first bottleneck input transform
     hipEvent_t ev_warp = nullptr;          // recorded by the first chain behind the joint warp launch (EAMM_WARP_JOINT)

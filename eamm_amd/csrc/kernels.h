@@ -18,6 +18,12 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
 void note_mfma_flops(double flops);
 double take_mfma_flops();   // returns the counter and resets it
 
+// Tuning knobs: every EAMM_* environment variable the library reads goes through knob_int(), which records the name, the value
+// in effect and whether the environment set it -- eamm_knobs_json() reports the table, so a benchmark line can carry the
+// configuration it was measured under (bench.py `knobs`).  DOCUMENTED knobs are listed in include/eamm_hip.h.
+long long knob_int(const char* name, long long dflt);
+int knobs_json(char* buf, int cap);   // {"EAMM_X": {"value": v, "set": 0|1}, ...}; returns the length needed (excl. NUL)
+
 // One convolution launch. Activations are NHWC fp32; the GEMM view is
 //   M = B*H*W pixels (2x2-quad order), N = Cout, K = taps * (C0 + C1).
 struct ConvArgs {

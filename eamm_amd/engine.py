@@ -47,6 +47,16 @@ def _dev_ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def library_knobs() -> dict:
+    """Every EAMM_* tuning knob the library has read so far in this process: {name: {"value": v, "set": 0|1}}."""
+    import json
+    L = _lib.lib()
+    need = L.eamm_knobs_json(None, 0)
+    buf = C.create_string_buffer(need + 1)
+    L.eamm_knobs_json(buf, len(buf))
+    return json.loads(buf.value.decode())
+
+
 class Engine:
     def __init__(self, cfg: dict, height: int, width: int, max_frames: int = 16, max_sources: int = 1,
                  device: Optional[torch.device] = None, training: bool = False):
@@ -298,6 +308,20 @@ class Engine:
     def pass_chains(self, frames: int) -> int:
         """Of those, the chains that run the whole per-frame pass as independent launch sequences (1 = none)."""
         return self._L.eamm_pass_chains(self._ctx, int(frames))
+
+    def last_stream_set(self) -> int:
+        """Side streams of the last forward_frames call: 0 the device's shared pool, 1 the handle's private streams (another
+        thread held the pool), 2 private because the caller's stream was being captured (include/eamm_hip.h)."""
+        return self._L.eamm_last_stream_set(self._ctx)
+
+    def describe_plan(self, frames: int) -> dict:
+        """The launch plan the library picks for a call of ``frames`` frames (chains, forms, kernels), for benchmark records."""
+        import json
+        buf = C.create_string_buffer(2048)
+        n = self._L.eamm_describe_plan(self._ctx, int(frames), buf, len(buf))
+        if n < 0:
+            raise ValueError(f"no plan for a call of {frames} frames (max_frames={self.max_frames})")
+        return json.loads(buf.value.decode())
 
     @property
     def encode_flops(self) -> float:

@@ -147,6 +147,28 @@ int eamm_bottleneck_chains(const eamm_ctx* ctx, int n);
 /* Of those, the chains that cover the WHOLE per-frame pass (independent launch sequences whose bottleneck launches
  * time-share the chip) rather than the bottleneck alone: 1 = none. */
 int eamm_pass_chains(const eamm_ctx* ctx, int n);
+/* Which side streams the last eamm_forward_frames call ran its chains on: 0 = the device's shared pool, 1 = the handle's private
+ * streams because another host thread held the pool, 2 = private because the caller's stream was being captured into a graph
+ * (side streams join the capture until it ends, so a captured call never touches the shared pool). */
+int eamm_last_stream_set(const eamm_ctx* ctx);
+/* The launch plan of a call of n frames as a JSON object (chains, frames per chain, bottleneck form, hourglass level forms,
+ * final-layer kernel ...), written NUL-terminated into buf[cap]; returns the length needed.  For benchmark records. */
+int eamm_describe_plan(const eamm_ctx* ctx, int n, char* buf, int cap);
+/* Every EAMM_* tuning knob the library has read so far in this process, as a JSON object {"NAME": {"value": v, "set": 0|1}}
+ * (value in effect; set = 1 when the environment supplied it).  Same buffer contract as eamm_describe_plan.
+ * DOCUMENTED knobs (everything else is a per-round tuning aid that may disappear):
+ *   EAMM_PASS_CHAINS / EAMM_BNECK_CHAINS   chains of a call over the whole pass / inside the bottleneck (0 = automatic, 1 = off)
+ *   EAMM_WINO_TILE (4 | 2), EAMM_WINO_MIN_M (< 0: direct bottleneck)   bottleneck form
+ *   EAMM_ENC_WINO (0 | 1)                   hourglass encoder levels in F(4x4) form
+ *   EAMM_FINAL_FUSED, EAMM_FINAL_MFMA4      final-layer kernel
+ *   EAMM_PRIVATE_STREAMS (0 | 1)            never use the shared side-stream pool
+ *   EAMM_WARP_JOINT, EAMM_BNECK_STAGGER     scheduling variants measured in round 4 (off)
+ * All of these compute the same frames up to rounding.  Knobs that compute WRONG results (timing experiments:
+ * EAMM_WINO4_EPI_V, EAMM_COL7_DBG, EAMM_WINO4_VARIANT 10/16/17/50) exist only in a build with -DEAMM_EXPERIMENTS
+ * (make EXPERIMENTS=1); the product library's eamm_create fails when one of them is set. */
+int eamm_knobs_json(char* buf, int cap);
+/* 1 when this library was built with -DEAMM_EXPERIMENTS (never benchmark or ship such a build), else 0. */
+int eamm_build_experiments(void);
 
 /*
  * ---- key-point detectors -----------------------------------------------

@@ -63,6 +63,33 @@ class OracleBackend:
         pass
 
 
+COLLECTIVES = ("broadcast", "broadcast_object_list", "all_reduce", "all_gather", "all_gather_object", "gather", "gather_object",
+               "scatter", "scatter_object_list", "reduce", "all_to_all", "barrier", "send", "recv")
+
+
+class CountedCollectives:
+    """Counts every torch.distributed collective issued while active (the clip pipeline calls them as ``dist.<name>``)."""
+
+    def __init__(self):
+        self.counts = {}
+        self._saved = {}
+
+    def __enter__(self):
+        for name in COLLECTIVES:
+            fn = getattr(dist, name)
+            self._saved[name] = fn
+
+            def counted(*a, __fn=fn, __name=name, **kw):
+                self.counts[__name] = self.counts.get(__name, 0) + 1
+                return __fn(*a, **kw)
+            setattr(dist, name, counted)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._saved.items():
+            setattr(dist, name, fn)
+
+
 def _worker(rank, world, port, total, batch, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -74,11 +101,16 @@ def _worker(rank, world, port, total, batch, tmp):
         src, kp_s, kp_d = synthetic_source(64, seed=1), synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(total, 10, seed=2)
     else:
         src = kp_s = kp_d = None  # only rank 0 holds the clip's inputs
-    local, (a, b) = animate_clip(be, src, kp_s, kp_d, 64, 64, uint8=False)
+    with CountedCollectives() as cc:
+        local, (a, b) = animate_clip(be, src, kp_s, kp_d, 64, 64, uint8=False)
+    # the data path of one clip: a fixed-size header + ONE packed payload (source cache | kp_source | kp_driving), nothing pickled
+    assert cc.counts == {"broadcast": 2}, cc.counts
     assert (a, b) == shard_bounds(total, world, rank) and local.shape[0] == b - a
     assert all(n <= batch for n in be.calls) and sum(be.calls) == b - a
     np.save(os.path.join(tmp, f"shard{rank}.npy"), local.numpy())
-    full, span = animate_clip(be, src, kp_s, kp_d, 64, 64, uint8=True, gather=True)
+    with CountedCollectives() as cc:
+        full, span = animate_clip(be, src, kp_s, kp_d, 64, 64, uint8=True, gather=True)
+    assert cc.counts == {"broadcast": 2, "gather": 1}, cc.counts
     if rank == 0:
         assert span == (0, total) and full.shape == (total, 64, 64, 3) and full.dtype == torch.uint8
         np.save(os.path.join(tmp, "gathered.npy"), full.numpy())

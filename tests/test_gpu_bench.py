@@ -71,7 +71,20 @@ def test_bench_single_gpu_line():
     assert k["frames"] == 2048 and k["n_gpus"] == 1 and abs(k["frames_per_s"] - 2048 / k["seconds"]) < 1.0
     assert k["batch"] == 64          # the clip harness batches 64 frames per call (about 5 % over the contract line's 16)
     assert 0.9 * d["value"] <= k["frames_per_s"] <= 1.12 * d["value"], (k["frames_per_s"], d["value"])
-    assert {"encode_ms", "compute_ms"} <= set(k["phases_ms_rank0"])
+    assert {"encode_ms", "compute_ms"} <= set(k["phases_ms_rank0"]) and len(k["phases_ms_per_rank"]) == 1
+    # the clip leg looks at what its TIMED pass produced: fixture frames + spot frames recomputed under the
+    # contract handle's plan; its own plan is the four-chain one
+    v = k["verify"]
+    assert v["ok"] is True and v["fixture"]["ok"] is True and v["fixture"]["max_abs_err"] <= 1e-4
+    assert v["spot_frames"] == [0, 1024, 2047] and v["vs_contract_plan_max_abs"] <= 2e-5
+    assert k["plan"]["pass_chains"] == 4 and k["plan"]["frames_per_chain"] == 16 and k["collectives_per_clip"] == 0
+    # the line says what it was measured under: parity at the timed geometry, knobs, launch plan
+    pc = d["parity_check"]
+    assert pc["ok"] is True and pc["fixture"] == "tests/golden/full256_clip2.npz" and pc["frames"] == 2 and pc["max_abs_err"] <= 1e-4
+    kn = d["knobs"]
+    assert kn["env"] == {} and kn["library"] == {} and kn["experiments_build"] == 0 and kn["library_defaults_read"] > 20
+    assert kn["plan"]["frames"] == 16 and kn["plan"]["pass_chains"] == 2 and kn["plan"]["bottleneck_form"] == 4
+    assert "executed" in r["flops_basis"] and "reference-equivalent" in r["algorithmic_note"]
     # N4 leg (not part of `value`): one fine-tuning step of 8 pairs, forward with autograd graph + loss.backward()
     t = d["train_step"]
     assert "error" not in t, t
@@ -161,6 +174,10 @@ def test_bench_bare_gpus2_spawns_its_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["clip"]["n_gpus"] == 2 and d["clip"]["shard_rank0"] == [0, 32]
+    k = d["clip"]      # both ranks verified their shard (spot frames under the contract plan), every rank's phases are in the line
+    assert k["verify"]["ok"] is True and k["verify"]["spot_frames"] == [0, 16, 31] and k["collectives_per_clip"] == 2
+    assert len(k["phases_ms_per_rank"]) == 2 and all(p["compute_ms"] > 0 for p in k["phases_ms_per_rank"])
+    assert d["parity_check"]["ok"] is True and "rccl_warmup_ms" in d
     assert abs(d["value"] - 2 * 3 * 16 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01
 
 
@@ -173,4 +190,19 @@ def test_bench_rccl_path_single_rank():
     d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-frames", "0", "--clip-frames", "64"],
             env={"EAMM_BENCH_FORCE_DIST": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
-    assert d["n_gpus"] == 1 and "source_broadcast_ms" in d and d["value"] > 0
+    assert d["n_gpus"] == 1 and "source_broadcast_ms" in d and d["value"] > 0 and d["rccl_warmup_ms"] > 0
+    assert d["clip"]["verify"]["ok"] is True and d["parity_check"]["ok"] is True
+
+
+def test_bench_refuses_a_wrong_results_knob():
+    """EAMM_WINO4_EPI_V=1 (a round-4 timing experiment that makes the bottleneck compute garbage) is compiled out of the product
+    library: with it set, eamm_create fails loudly and bench.py prints no line."""
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--clip-frames", "0",
+                          "--train-pairs", "0"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                         env={**os.environ, "EAMM_WINO4_EPI_V": "1"})
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "EAMM_WINO4_EPI_V" in out.stderr and "EXPERIMENTS" in out.stderr
+    d = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--clip-frames", "0", "--train-pairs", "0"],
+            env={"EAMM_PASS_CHAINS": "1"})
+    assert d["knobs"]["env"] == {"EAMM_PASS_CHAINS": "1"} and d["knobs"]["library"]["EAMM_PASS_CHAINS"] == 1
+    assert d["knobs"]["plan"]["pass_chains"] == 1 and d["knobs"]["plan"]["bottleneck_chains"] == 2 and d["parity_check"]["ok"] is True

@@ -10,6 +10,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eamm_amd import _lib  # noqa: E402
+# diagnostics that compute wrong results live in the experiments build only (make -C eamm_amd/csrc EXPERIMENTS=1)
+_exp = os.path.join(os.path.dirname(_lib.LIB_PATH), "libeamm_hip_exp.so")
+if os.path.exists(_exp):
+    _lib.LIB_PATH = _exp
 
 L = _lib.lib()
 dev = torch.device("cuda:0")
