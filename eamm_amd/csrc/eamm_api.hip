@@ -1774,6 +1774,15 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
     return EAMM_OK;
 }
 
+int eamm_op_one_euro(int device, const float* x, int T, int E, float mincutoff, float beta, float dcutoff, float freq, float scale,
+                     float* out, void* stream_) {
+    if (!x || !out || T < 0 || E < 1) return fail(nullptr, EAMM_ERR_ARG, "eamm_op_one_euro: bad argument");
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
+    const hipError_t e = one_euro_launch(x, T, E, mincutoff, beta, dcutoff, freq, scale, out, reinterpret_cast<hipStream_t>(stream_));
+    return e == hipSuccess ? EAMM_OK : fail(nullptr, EAMM_ERR_HIP, "one_euro_kernel: %s", hipGetErrorString(e));
+}
+
 int eamm_op_warp(int device, const float* feat, const float* deformation, const float* occlusion, int n, int ns, int hf,
                  int wf, int C, int h, int w, float* out, int iters, float* avg_ms, void* stream_) {
     if (!feat || !deformation || !out || n < 1 || (ns != 1 && ns != n) || hf < 1 || wf < 1 || h < 1 || w < 1 || C < 8 || (C & 7))

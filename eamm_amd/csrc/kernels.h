@@ -276,4 +276,8 @@ hipError_t motion_head_backward_launch(const float* mask, const float* occlusion
                                        const float* dmask, const float* ddef, const float* docc, float* dlm, int ld, float* dlo, int ldo,
                                        float* drec, float* workspace, hipStream_t s);
 
+// One-Euro smoothing of [T,E] sequences along T (keypoints.hip; reference filter1.py:13-47 as driven by demo.py:241-250).
+hipError_t one_euro_launch(const float* x, int T, int E, float mincutoff, float beta, float dcutoff, float freq, float scale,
+                           float* out, hipStream_t stream);
+
 }  // namespace eamm

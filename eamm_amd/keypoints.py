@@ -73,35 +73,49 @@ def one_euro_smooth(seq: torch.Tensor, mincutoff: float = 1.0, beta: float = 0.0
                     freq: float = 30.0, scale: float = 1.0) -> torch.Tensor:
     """One-Euro low-pass filter along dim 0 of ``seq`` ([T, ...]), element-wise over the rest -- the reference's
     ``filter1.OneEuroFilter`` (filter1.py:13-47) applied as ``process(x * scale) / scale`` frame after frame
-    (demo.py:237-250).  The recurrence is sequential in T and tiny (K*2 or K*4 values per frame): it runs on the host in
-    float32 in the reference's operation order and returns a tensor on ``seq``'s device."""
-    x_all = (seq.detach().to("cpu", torch.float32) * scale)
-    out = torch.empty_like(x_all)
+    (demo.py:237-250).  The recurrence is sequential in T and independent per element.
+
+    A tensor on the GPU is filtered there by ``eamm_op_one_euro`` (csrc/keypoints.hip: one thread per element walks the
+    frames; a 2048-frame clip takes ~0.15 ms, no host round trip) -- the clip pipeline's path.  A CPU tensor is filtered on
+    the host in float32 in the reference's operation order (numpy; the reference itself filters on the host)."""
+    if seq.is_cuda:
+        import ctypes as C
+        from . import _lib
+        x = seq.detach().to(torch.float32).contiguous()
+        T = x.shape[0]
+        out = torch.empty_like(x)
+        if T:
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().eamm_op_one_euro(x.device.index, C.c_void_p(x.data_ptr()), T, x.numel() // T, float(mincutoff),
+                                                       float(beta), float(dcutoff), float(freq), float(scale), C.c_void_p(out.data_ptr()),
+                                                       C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), None)
+        return out
+    f32 = np.float32
+    x_all = seq.detach().to(torch.float32).numpy().reshape(seq.shape[0], -1) * f32(scale)
+    out = np.empty_like(x_all)
     te = 1.0 / freq
-
-    def alpha_of(cutoff):
-        tau = 1.0 / (2 * np.pi * cutoff)
-        return 1.0 / (1.0 + tau / te)
-
-    a_d = alpha_of(dcutoff)
+    a_dd = 1.0 / (1.0 + (1.0 / (2 * np.pi * dcutoff)) / te)
+    a_d, one_m_ad = f32(a_dd), f32(1.0 - a_dd)
+    two_pi, inv_te, one, fq, mc, bt = f32(2 * np.pi), f32(1.0) / f32(te), f32(1.0), f32(freq), f32(mincutoff), f32(beta)
     prev_x = prev_s = prev_edx = None
     for t in range(x_all.shape[0]):
         x = x_all[t]
         if prev_x is None:                      # first sample: dx = 0, both low-pass filters pass their input through
-            edx = torch.zeros_like(x)
+            edx = np.zeros_like(x)
             s = x
         else:
-            dx = (x - prev_x) * freq
-            edx = a_d * dx + (1.0 - a_d) * prev_edx
-            a = alpha_of(mincutoff + beta * edx.abs())
-            s = a * x + (1.0 - a) * prev_s
+            dx = (x - prev_x) * fq
+            edx = a_d * dx + one_m_ad * prev_edx
+            tau = one / ((mc + bt * np.abs(edx)) * two_pi)
+            a = one / (one + tau * inv_te)
+            s = a * x + (one - a) * prev_s
         prev_x, prev_s, prev_edx = x, s, edx
         out[t] = s
-    return (out / scale).to(seq.device)
+    return torch.from_numpy(out * (f32(1.0) / f32(scale))).reshape(seq.shape)
 
 
 def smooth_keypoints(kp_seq: Dict[str, torch.Tensor], mincutoff: float = 0.05, beta: float = 8.0, dcutoff: float = 1.0,
                      freq: float = 100.0, scale: float = 10.0) -> Dict[str, torch.Tensor]:
     """Temporal smoothing of a clip's driving key points, defaults = the reference's (demo.py:241-250: one filter for
     the values, one for the jacobians, inputs scaled by 10).  ``kp_seq``: {'value': [T,K,2], 'jacobian': [T,K,2,2]}."""
-    return {k: one_euro_smooth(v, mincutoff, beta, dcutoff, freq, scale) for k, v in kp_seq.items()}
+    return {k: one_euro_smooth(v, mincutoff, beta, dcutoff, freq, scale) for k, v in kp_seq.items() if k in ("value", "jacobian")}
