@@ -225,6 +225,8 @@ def main():
                          "run 5 %% faster than 16; the contract line above stays at --batch).  Default: 64 at 256x256, the same number "
                          "of pixels per call at other sizes (16 at 512x512: activations stay under the 4 GiB per tensor)")
     ap.add_argument("--clip-gather", action="store_true", help="clip leg: gather uint8 frames on rank 0 inside the timed region")
+    ap.add_argument("--e2e-frames", type=int, default=2048,
+                    help="frames of the end-to-end leg (make_animation_smooth: LSTM features -> uint8 frames in host memory; 0 = skip)")
     ap.add_argument("--train-pairs", type=int, default=8, help="pairs per step of the training-step leg (N = 1 only; 0 = skip)")
     ap.add_argument("--graph", action="store_true",
                     help="after the contract's timed region: capture one step into a HIP graph and time `--steps` replays (extra key "
@@ -497,6 +499,65 @@ def main():
                     "workload": f"{S}x{S}, {T}-frame clip, contiguous shards of {T}/{world} frames, batch {CB} "
                                 f"(BASELINE.json configs[3])"}
 
+    # ---- end-to-end leg: the reference's make_animation_smooth (demo.py:194-282) whole -- KPDetector on the
+    # source, DeconvTail + KPDetector_a per frame, One-Euro smoothing, normalize_kp, generator, uint8 frames in pinned HOST memory
+    e2e = None
+    if args.e2e_frames > 0 and S == 256:
+        from eamm_amd import DeconvTail, KPDetector, KPDetector_a, animate_from_features, kp_detector_a_config, kp_detector_config
+        from eamm_amd.weights import deconv_state_dict_spec, synthetic_lstm_features, trained_like_kp_state_dict
+        T2 = args.e2e_frames
+        CB2 = max(1, min(64, -(-T2 // world)))
+        gen_e = OcclusionAwareGenerator(**cfg, max_frames=CB2)
+        gen_e.load_state_dict(sd, strict=True)
+        gen_e = gen_e.to(dev).eval()
+        ck, ca = kp_detector_config(), kp_detector_a_config()
+        m_kp, m_kpa, m_tail = KPDetector(**ck), KPDetector_a(**ca), DeconvTail()
+        m_kp.load_state_dict(trained_like_kp_state_dict(ck, 78), strict=True)
+        m_kpa.load_state_dict(trained_like_kp_state_dict(ca, 77), strict=True)
+        m_tail.load_state_dict(synthetic_state_dict(None, seed=3, spec=deconv_state_dict_spec()), strict=True)
+        m_kp, m_kpa, m_tail = m_kp.to(dev).eval(), m_kpa.to(dev).eval(), m_tail.to(dev).eval()
+        be2 = EngineBackend(gen_e, batch=CB2)
+        e_src = synthetic_source(S, seed=1).to(dev) if rank == 0 else None
+        e_feat = synthetic_lstm_features(T2, seed=5).to(dev) if rank == 0 else None
+
+        def run_e2e(timings=None, keys=False):
+            return animate_from_features(gen_e, m_kp, m_tail, m_kpa, e_src, e_feat, batch=CB2, uint8=True, to_host=True, backend=be2,
+                                         timings=timings, return_keypoints=keys, size=(S, S))
+
+        run_e2e()                          # warm-up: engines, pinned buffer, allocator
+        fence()
+        t0 = time.perf_counter()
+        e_frames, e_span = run_e2e()
+        fence()
+        dt_e2e = max_over_ranks(time.perf_counter() - t0)
+        e_ph = {}
+        e_frames2, _, e_kps = run_e2e(e_ph, keys=True)
+        fence()
+        # verification of what was delivered: the host frames of the timed pass == the instrumented pass (deterministic), and on
+        # rank 0 three frames recomputed by the contract handle from the harness's own normalised key points, to one uint8 level
+        e_ok = bool(torch.equal(e_frames, e_frames2)) and e_frames.dtype == torch.uint8 and e_frames.is_pinned()
+        e_worst = None
+        if rank == 0 and e_frames.shape[0]:
+            a2, b2 = e_span
+            spots = sorted({a2, (a2 + b2) // 2, b2 - 1})[:B]
+            again = eng.forward_frames({k: v[spots].contiguous() for k, v in e_kps["kp_norm"].items()},
+                                       {k: v.contiguous() for k, v in e_kps["kp_source"].items()}, outputs=("prediction",))["prediction"]
+            want = torch.clamp(torch.round(again * 255), 0, 255).permute(0, 2, 3, 1).cpu()
+            e_worst = float((e_frames[[t - a2 for t in spots]].float() - want).abs().max())
+            e_ok = e_ok and e_worst <= 1
+        if max_over_ranks(0.0 if e_ok else 1.0) != 0.0:
+            raise SystemExit(f"bench.py: the end-to-end leg's frames failed verification (rank {rank}, uint8 levels {e_worst})")
+        if rank == 0:
+            e2e = {"frames": T2, "frames_per_s": round(T2 / dt_e2e, 2), "seconds": round(dt_e2e, 4), "n_gpus": world, "batch": CB2,
+                   "phases_ms_rank0": {k: round(v, 3) for k, v in e_ph.items()},
+                   "delivered": "uint8 [T,H,W,3] frames in pinned host memory (non_blocking copies on a copy stream, overlapped with the next batch)",
+                   "host_bytes": int(e_frames.numel()), "verify": {"ok": True, "uint8_levels_vs_contract_plan": e_worst},
+                   "timed": "LSTM features + source on the device -> KPDetector, DeconvTail + KPDetector_a, One-Euro smoothing, "
+                            "normalize_kp (relative, adapt_movement_scale), source encode, generator, D2H of every frame; max over ranks",
+                   "workload": f"make_animation_smooth (reference demo.py:194-282) on a {T2}-frame clip at {S}x{S}, synthetic LSTM features and weights"}
+        del e_frames, e_frames2, be2, gen_e, m_kp, m_kpa, m_tail
+        torch.cuda.empty_cache()
+
     # isolated launch of the HBM-bound warp kernel at the step's full batch (in the pipeline a launch covers one chain's frames
     # and runs beside the other chain's kernels): C-ABI op entry, HIP events on the launch stream
     warp_iso_ms = None
@@ -657,6 +718,7 @@ def main():
         if rccl_warmup_ms is not None:
             line["rccl_warmup_ms"] = round(rccl_warmup_ms, 2)    # communicator set-up, before every timed region
         line["clip"] = clip
+        line["e2e_clip"] = e2e
         if graph_leg is not None:
             line["graph"] = graph_leg
         if world == 1 and args.cpu_frames > 0:

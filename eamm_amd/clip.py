@@ -60,6 +60,26 @@ class EngineBackend:
     def finish(self):
         self.engine.check_numeric()
 
+    # -- device -> host delivery (the reference copies every frame to the host, demo.py:281) -----------------------------
+    def host_buffer(self, frames: int, tail, dtype) -> torch.Tensor:
+        """A pinned host tensor [frames, *tail] (grow-only, reused from clip to clip: pinning 400 MB costs ~100 ms)."""
+        need = int(frames)
+        for d in tail:
+            need *= int(d)
+        key = (dtype, tuple(tail))
+        buf = self._host.get(key) if hasattr(self, "_host") else None
+        if buf is None or buf.numel() < need:
+            if not hasattr(self, "_host"):
+                self._host = {}
+            buf = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
+            self._host[key] = buf
+        return buf[:need].view((frames,) + tuple(tail))
+
+    def copy_stream(self):
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        return self._copy_stream
+
 
 @torch.no_grad()
 def driving_keypoints(deconv_tail, kp_detector_a, lstm_features: torch.Tensor, batch: int = 64) -> Dict[str, torch.Tensor]:
@@ -148,7 +168,7 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
                  group=None, gather: bool = False, kp_driving_initial: Optional[Dict[str, torch.Tensor]] = None,
                  relative: bool = False, adapt_movement_scale: bool = False,
                  emo_driving: Optional[Dict[str, torch.Tensor]] = None, emo_type: str = "linear_3",
-                 timings: Optional[Dict[str, float]] = None) -> Tuple[torch.Tensor, Tuple[int, int]]:
+                 timings: Optional[Dict[str, float]] = None, to_host: bool = False) -> Tuple[torch.Tensor, Tuple[int, int]]:
     """Animate one clip; returns (frames of this rank's shard, (start, stop)).
 
     ``emo_driving`` ({'value': [T,E,2], 'jacobian': [T,E,2,2]}, the emotion network's per-frame displacements) adds the
@@ -159,6 +179,11 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
     Single process: all T frames.  Under torch.distributed: rank 0 supplies ``source_image`` and the
     key points (other ranks may pass None), every rank returns its contiguous shard; with
     ``gather=True`` rank 0 instead returns all T frames (others an empty tensor).
+
+    ``to_host=True`` delivers this rank's frames in PINNED HOST memory (what demo.py:281 does per frame with a blocking
+    ``.cpu()``): every batch's frames are copied ``non_blocking`` on a copy stream behind an event, so the copy of batch i
+    overlaps the kernels of batch i + 1 (the device buffers are the caching allocator's: a batch's buffer is reused only after
+    its copy has finished -- ``record_stream``); one synchronisation at the end.  Not combined with ``gather``.
 
     ``timings`` (a dict, filled in place): wall-clock milliseconds of the phases -- ``keypoints_ms``, ``encode_ms``,
     ``broadcast_ms``, ``compute_ms``, ``gather_ms`` -- with a device synchronisation at each phase boundary (only when
@@ -213,14 +238,44 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
     total = kp_driving["value"].shape[0]
     start, stop = shard_bounds(total, world, rank)
     chunks: List[torch.Tensor] = []
-    for s in range(start, stop, backend.batch):
-        e = min(stop, s + backend.batch)
-        chunks.append(backend.run({k: v[s:e] for k, v in kp_driving.items()}, kp_source, uint8))
-    backend.finish()
     channels = int(getattr(getattr(backend, "generator", None), "num_channels", 3))   # (test backends without a generator: RGB)
     shape_tail = (height, width, channels) if uint8 else (channels, height, width)
     dtype = torch.uint8 if uint8 else torch.float32
+    host = copier = None
+    if to_host:
+        if distributed and gather:
+            raise ValueError("to_host delivers every rank's own shard; it cannot be combined with gather")
+        if torch.device(backend.device).type == "cuda":
+            host = backend.host_buffer(stop - start, shape_tail, dtype)
+            copier = backend.copy_stream()
+    for s in range(start, stop, backend.batch):
+        e = min(stop, s + backend.batch)
+        out = backend.run({k: v[s:e] for k, v in kp_driving.items()}, kp_source, uint8)
+        if host is None:
+            chunks.append(out)
+            continue
+        done = torch.cuda.Event()
+        done.record()                                  # on the stream the batch's kernels were enqueued on
+        copier.wait_event(done)
+        with torch.cuda.stream(copier):
+            host[s - start:e - start].copy_(out, non_blocking=True)
+        out.record_stream(copier)                      # its memory is reusable only after the copy
+    backend.finish()
+    if host is not None:
+        if timings is not None:
+            torch.cuda.current_stream(backend.device).synchronize()
+            mark_no_sync = _time.perf_counter()
+            timings["compute_ms"] = timings.get("compute_ms", 0.0) + (mark_no_sync - _t[0]) * 1e3
+            _t[0] = mark_no_sync
+        copier.synchronize()
+        if timings is not None:
+            now = _time.perf_counter()
+            timings["d2h_tail_ms"] = timings.get("d2h_tail_ms", 0.0) + (now - _t[0]) * 1e3   # what the copies add BEHIND the last kernel
+            _t[0] = now
+        return host, (start, stop)
     local = torch.cat(chunks, dim=0) if chunks else torch.empty((0,) + shape_tail, dtype=dtype, device=backend.device)
+    if to_host:                                        # (a CPU stand-in backend: already host memory)
+        return local, (start, stop)
     mark("compute_ms")
     if not (distributed and gather):
         return local, (start, stop)

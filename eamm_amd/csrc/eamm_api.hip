@@ -308,6 +308,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->pass_chains = c->pass_chains < 0 ? 1 : std::min(c->pass_chains, 4);
     c->bneck_chains = std::max(1, std::min(c->bneck_chains, 16));
     c->bneck_stagger = env_int("EAMM_BNECK_STAGGER", c->bneck_stagger);
+    c->bneck_sub = std::max(1, std::min(env_int("EAMM_BNECK_SUB", c->bneck_sub), (int)eamm_ctx::MAXSUB));
     c->warp_joint = env_int("EAMM_WARP_JOINT", c->warp_joint);
     c->enc_cus_pct = std::max(1, env_int("EAMM_ENC_CUS_PCT", c->enc_cus_pct));
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
@@ -351,6 +352,8 @@ void eamm_destroy(eamm_ctx* c) {
     if (c->ev_stagger) (void)hipEventDestroy(c->ev_stagger);
     if (c->ev_warp) (void)hipEventDestroy(c->ev_warp);
     for (auto& e : c->ev_join) (void)hipEventDestroy(e);
+    for (auto& e : c->sub_fork) (void)hipEventDestroy(e);
+    for (auto& e : c->sub_join) (void)hipEventDestroy(e);
     for (auto& st : c->own_streams) (void)hipStreamDestroy(st);   // (drains the stream's work first; the pool's streams stay)
     delete c;
 }
@@ -660,7 +663,20 @@ int eamm_finalize_weights(eamm_ctx* c) {
         if (c->nb > 0) ff += 9.0 * hwf * c->Cb_r;  // bilinear feature warp + occlusion multiply
         c->flops_frame = ff;
     }
-    const int max_chains = std::max(c->bneck_chains, c->pass_chains == 0 ? (g.max_frames >= 64 ? 4 : 2) : c->pass_chains);
+    int max_chains = std::max(c->bneck_chains, c->pass_chains == 0 ? (g.max_frames >= 64 ? 4 : 2) : c->pass_chains);
+    if (c->bneck_sub > 1) {   // two whole-pass chains, each with its bottleneck split: 1 + 2 (sub - 1) side streams
+        max_chains = std::max(max_chains, 2 + 2 * (c->bneck_sub - 1));
+        for (int k = 0; k < 4; ++k) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->sub_fork.push_back(ev);
+        }
+        for (int k = 0; k < 4 * (eamm_ctx::MAXSUB - 1); ++k) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->sub_join.push_back(ev);
+        }
+    }
     c->private_streams = env_int("EAMM_PRIVATE_STREAMS", 0);
     if (max_chains > 1) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -785,6 +801,24 @@ static int bottleneck_chains(const eamm_ctx* c, int n) {
     const int tiles_pf = (c->hf / 4) * (c->wf / 4);
     while (chains > 1 && (n < chains || ((n / chains) * tiles_pf) % 64 != 0 || ((n / chains + 1) * tiles_pf) % 64 != 0)) --chains;
     return chains;
+}
+
+// Sub-chains of ONE whole-pass chain's bottleneck (EAMM_BNECK_SUB; 1 = off).  Only while the chain's own GEMM cannot fill the
+// chip (<= half the CUs: the other whole-pass chain holds the other half) and with whole 64-tile blocks per sub-chain.
+static int bottleneck_subchains(const eamm_ctx* c, int n, int P) {
+    const int sub = c->bneck_sub;
+    if (sub < 2 || sub > eamm_ctx::MAXSUB || P < 2 || n < sub || c->sub_fork.empty()) return 1;
+    if ((P - 1) + P * (sub - 1) > (int)c->side_streams.size()) return 1;
+    const int tiles_pf = (c->hf / 4) * (c->wf / 4);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    if (((n * tiles_pf + 63) / 64) * ((c->Cb + 63) / 64) > cus / 2) return 1;
+    for (int k = 0; k < 2; ++k) {
+        const int nk = n / sub + k;
+        if (k == 1 && n % sub == 0) break;
+        if ((nk * tiles_pf) % 64 != 0) return 1;
+    }
+    return sub;
 }
 
 // The slice of the per-frame workspace one launch sequence works on: frames [f0, f0 + n) of a call (every per-frame
@@ -1038,15 +1072,24 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
     } while (0)
     const bool wino4 = form == 4;
     const int w4g = (wino4 && !chained) ? wino4_groups(c, n) : 1;   // a chained view shares the chip: never split the point rows
-    const int chains = chained ? 1 : bottleneck_chains(c, n);
+    // a whole-pass chain may split ITS bottleneck once more (bottleneck_subchains): sub-chains of fewer frames have shorter input
+    // transforms, and the CUs of a sub-chain that is in its transform phase are the only ones the matrix pipes lose
+    const int nsubc = (chained && wino4) ? bottleneck_subchains(c, n, c->cur_pass_chains) : 1;
+    const int chains = chained ? nsubc : bottleneck_chains(c, n);
+    // streams / events of the split: the call's own (un-chained call) or this whole-pass chain's private set
+    auto split_stream = [&](int k) {
+        return !chained ? c->side_streams[k - 1] : c->side_streams[(c->cur_pass_chains - 1) + chain_idx * (nsubc - 1) + (k - 1)];
+    };
+    hipEvent_t split_fork = chained ? c->sub_fork[chain_idx] : c->ev_fork;
+    auto split_join = [&](int k) { return chained ? c->sub_join[chain_idx * (eamm_ctx::MAXSUB - 1) + (k - 1)] : c->ev_join[k - 1]; };
     if (chains > 1) {
         const size_t per_frame = (size_t)hf * wf * c->Cb;
         const int nbase = n / chains, nrem = n % chains;   // the first nrem chains take one more frame
-        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-        for (int k = 1; k < chains; ++k) HIP_TRY(c, hipStreamWaitEvent(c->side_streams[k - 1], c->ev_fork, 0));
+        HIP_TRY(c, hipEventRecord(split_fork, s));
+        for (int k = 1; k < chains; ++k) HIP_TRY(c, hipStreamWaitEvent(split_stream(k), split_fork, 0));
         for (int i = 0; i < nr; ++i) {
             for (int k = 0; k < chains; ++k) {
-                hipStream_t sk = k ? c->side_streams[k - 1] : s;
+                hipStream_t sk = k ? split_stream(k) : s;
                 const int nk = nbase + (k < nrem ? 1 : 0);
                 const size_t f0 = (size_t)k * nbase + std::min(k, nrem);
                 float* xk = x + f0 * per_frame;
@@ -1068,8 +1111,8 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         }
         SUB_MARK();
         for (int k = 1; k < chains; ++k) {
-            HIP_TRY(c, hipEventRecord(c->ev_join[k - 1], c->side_streams[k - 1]));
-            HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0));
+            HIP_TRY(c, hipEventRecord(split_join(k), split_stream(k)));
+            HIP_TRY(c, hipStreamWaitEvent(s, split_join(k), 0));
         }
     }
     for (int i = 0; i < nr && wino && chains == 1; ++i) {
@@ -1218,6 +1261,7 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     hipEvent_t* ev = nullptr;  // stage boundaries (of the main stream's sequence), recorded only while profiling
     hipEvent_t* cev = nullptr; // bottleneck window of every whole-pass chain
     const int chains = pass_chains(c, n);
+    c->cur_pass_chains = chains;
     if (c->profiling && c->prof_used < eamm_ctx::PROF_CALLS) {
         ev = c->prof_events.data() + (size_t)c->prof_used * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB);
         cev = c->prof_chain_ev.data() + (size_t)c->prof_used * eamm_ctx::MAXCHAIN * 2;
@@ -1475,9 +1519,10 @@ int eamm_describe_plan(const eamm_ctx* c, int n, char* buf, int cap) {
     const int len = snprintf(tmp, sizeof tmp,
                              "{\"frames\": %d, \"pass_chains\": %d, \"frames_per_chain\": %d, \"bottleneck_form\": %d, \"bottleneck_chains\": %d, "
                              "\"wino4_groups\": %d, \"wino4_variant\": %d, \"hg_encoder\": %s, \"final\": \"%s\", \"warp_joint\": %d, "
-                             "\"bneck_stagger\": %d, \"side_streams\": %d, \"experiments_build\": %d}",
+                             "\"bneck_stagger\": %d, \"bneck_subchains\": %d, \"side_streams\": %d, \"experiments_build\": %d}",
                              n, pc, nk, form, bc, (form == 4 && pc == 1 && bc == 1) ? wino4_groups(c, n) : 1, c->wino4_variant, enc.c_str(),
-                             fused ? "col7q fused" : "col7 + shift-sum", c->warp_joint, c->bneck_stagger, (int)c->pool_streams.size(),
+                             fused ? "col7q fused" : "col7 + shift-sum", c->warp_joint, c->bneck_stagger,
+                             (pc > 1 && form == 4) ? bottleneck_subchains(c, nk, pc) : 1, (int)c->pool_streams.size(),
                              eamm_build_experiments());
     if (buf && cap > 0) {
         const int m = std::min(len, cap - 1);
@@ -1894,7 +1939,7 @@ bool conv_dev_plan(int B, int H, int W, int Cin, int Cout, int kh, int kw, ConvD
 
 namespace {
 // A per-device vector of zeros (never written after its allocation): the bias of the convolutions that have none.
-const float* device_zeros(int device, size_t n) {
+const float* device_zeros(int device, size_t n, hipStream_t stream) {
     constexpr size_t CAP = 16384;
     constexpr int MAXDEV = 64;
     static std::mutex mu;
@@ -1902,6 +1947,13 @@ const float* device_zeros(int device, size_t n) {
     if (n > CAP || device < 0 || device >= MAXDEV) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
     if (!zeros[device]) {
+        // first use: hipMalloc + a synchronous hipMemset -- neither is legal while `stream` is being captured into a graph (they
+        // would invalidate the capture): the caller then pads its bias with a kernel instead, and a later eager call allocates
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
         void* p = nullptr;
         if (hipMalloc(&p, CAP * sizeof(float)) != hipSuccess) return nullptr;
         if (hipMemset(p, 0, CAP * sizeof(float)) != hipSuccess) {   // synchronous: visible to every stream that follows
@@ -1936,7 +1988,7 @@ int eamm_op_conv_dev(int device, const float* x, int B, int H, int W, int Cin, c
     const int nbias = P.ntiles * P.BN;
     if (bias && nbias == Cout) {
         bp = const_cast<float*>(bias);
-    } else if (const float* z = bias ? nullptr : device_zeros(device, (size_t)nbias)) {
+    } else if (const float* z = bias ? nullptr : device_zeros(device, (size_t)nbias, s)) {
         bp = const_cast<float*>(z);
     } else {
         e = bias_pad_dev_launch(bias, Cout, nbias, bp, s);

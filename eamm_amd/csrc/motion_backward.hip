@@ -10,7 +10,10 @@
 //   * motion_head_forward / backward  -- softmax over the K+1 mask logits, deformation = sum_k mask_k T_k, sigmoid occlusion
 //     (:98-111) on the two convolutions' NHWC outputs.
 // All of it is HBM-bound element-wise / gather work on the 64x64 motion grid (a few MB per batch): one thread per pixel, the
-// per-key-point sums reduced per workgroup and then in a FIXED order over the workgroups (deterministic gradients).
+// per-key-point sums reduced per workgroup and then in a FIXED order over the workgroups (the key-point / record gradients are
+// deterministic).  NOT deterministic: the gradient of the down-sampled SOURCE image in motion_front_backward_kernel, which is
+// accumulated with float atomicAdd over the pixels and the K+1 motions that sampled a source pixel (as ATen's grid_sample
+// backward does): it varies in the last bits from run to run; the gradient tests' tolerances cover that.
 #include "kernels.h"
 
 #include <algorithm>

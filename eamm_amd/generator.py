@@ -37,55 +37,102 @@ from .weights import antialias_kernel, generator_channels, hourglass_channels
 
 _VERSION_OF = operator.attrgetter("_version")
 
-# Structure epoch: bumped whenever ANY module in the process registers a parameter, buffer or sub-module (attribute
-# assignment of a Parameter / Module, add_module, register_buffer, ModuleList / Sequential item assignment).  The
-# generator's cached list of tensor slots is rebuilt when the epoch has moved, so a replaced sub-module
-# (``gen.bottleneck[0] = ...``) or a tensor registered later is seen -- at the cost of one integer compare per forward.
-_STRUCTURE_EPOCH = [0]
+class _Epoch:
+    """Structure epoch of ONE generator: bumped whenever a module of its tree registers, replaces or deletes a parameter,
+    buffer or sub-module.  The generator's cached list of tensor slots is rebuilt when the epoch has moved, so a replaced
+    sub-module (``gen.bottleneck[0] = ...``) or a tensor registered later is seen -- at the cost of one integer compare per
+    forward.  (Round 4 counted with torch's process-global module-registration hooks, installed at import and never removed:
+    every module of the process paid for them.  Now the counting is done by the tree's own classes.)"""
+    __slots__ = ("n",)
+
+    def __init__(self):
+        self.n = 0
 
 
-def _bump_epoch(*_args):
-    _STRUCTURE_EPOCH[0] += 1
-    return None
+class _Tracked:
+    """Mixin (in front of an nn.Module class in the MRO): structural changes bump the owning generator's epoch.  A module that
+    belongs to no generator (the key-point detectors use the holders too) has no cell and pays one dict lookup."""
+
+    def _bump(self):
+        cell = self.__dict__.get("_eamm_epoch")
+        if cell is not None:
+            cell.n += 1
+
+    def __setattr__(self, name, value):
+        d = self.__dict__
+        if (isinstance(value, (nn.Parameter, nn.Module)) or name in ("_parameters", "_buffers", "_modules")
+                or name in d.get("_parameters", ()) or name in d.get("_buffers", ()) or name in d.get("_modules", ())):
+            self._bump()
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        self._bump()
+        super().__delattr__(name)
+
+    def register_parameter(self, name, param):
+        self._bump()
+        super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent=True):
+        self._bump()
+        super().register_buffer(name, tensor, persistent=persistent)
+
+    def add_module(self, name, module):
+        self._bump()
+        super().add_module(name, module)
+
+    def register_module(self, name, module):
+        self._bump()
+        super().add_module(name, module)
 
 
-def _install_registration_hooks():
-    from torch.nn.modules import module as _m
-    for name in ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook",
-                 "register_module_module_registration_hook"):
-        getattr(_m, name)(_bump_epoch)
+class _Conv2d(_Tracked, nn.Conv2d):
+    pass
 
 
-_install_registration_hooks()
+class _BatchNorm2d(_Tracked, nn.BatchNorm2d):
+    pass
 
 
-class _ConvNorm(nn.Module):
+class _ModuleList(_Tracked, nn.ModuleList):
+    pass
+
+
+class _Sequential(_Tracked, nn.Sequential):
+    pass
+
+
+class _Holder(_Tracked, nn.Module):
+    pass
+
+
+class _ConvNorm(_Holder):
     """Parameter holder named like DownBlock2d / UpBlock2d / SameBlock2d (util.py:883-938)."""
 
     def __init__(self, cin, cout, k):
         super().__init__()
-        self.conv = nn.Conv2d(cin, cout, kernel_size=k, padding=k // 2)
-        self.norm = nn.BatchNorm2d(cout, affine=True)
+        self.conv = _Conv2d(cin, cout, kernel_size=k, padding=k // 2)
+        self.norm = _BatchNorm2d(cout, affine=True)
 
 
-class _ResHolder(nn.Module):
+class _ResHolder(_Holder):
     """Parameter holder named like ResBlock2d (util.py:858-870)."""
 
     def __init__(self, c):
         super().__init__()
-        self.conv1 = nn.Conv2d(c, c, kernel_size=3, padding=1)
-        self.conv2 = nn.Conv2d(c, c, kernel_size=3, padding=1)
-        self.norm1 = nn.BatchNorm2d(c, affine=True)
-        self.norm2 = nn.BatchNorm2d(c, affine=True)
+        self.conv1 = _Conv2d(c, c, kernel_size=3, padding=1)
+        self.conv2 = _Conv2d(c, c, kernel_size=3, padding=1)
+        self.norm1 = _BatchNorm2d(c, affine=True)
+        self.norm2 = _BatchNorm2d(c, affine=True)
 
 
-class _Stack(nn.Module):
+class _Stack(_Holder):
     def __init__(self, name, blocks):
         super().__init__()
-        setattr(self, name, nn.ModuleList(blocks))
+        setattr(self, name, _ModuleList(blocks))
 
 
-class _AntiAlias(nn.Module):
+class _AntiAlias(_Holder):
     """Holder of the 13x13 Gaussian buffer of AntiAliasInterpolation2d (util.py:1005-1042)."""
 
     def __init__(self, channels):
@@ -93,7 +140,7 @@ class _AntiAlias(nn.Module):
         self.register_buffer("weight", antialias_kernel(channels))
 
 
-class _DenseMotionHolder(nn.Module):
+class _DenseMotionHolder(_Holder):
     """Parameters of DenseMotionNetwork under the reference's names (dense_motion.py:12-30)."""
 
     def __init__(self, block_expansion, num_blocks, max_features, num_kp, num_channels,
@@ -101,18 +148,18 @@ class _DenseMotionHolder(nn.Module):
         super().__init__()
         enc, dec, out_filters = hourglass_channels(block_expansion, (num_kp + 1) * (num_channels + 1), num_blocks,
                                                    max_features)
-        hg = nn.Module()
+        hg = _Holder()
         hg.encoder = _Stack("down_blocks", [_ConvNorm(ci, co, 3) for ci, co in enc])
         hg.decoder = _Stack("up_blocks", [_ConvNorm(ci, co, 3) for ci, co in dec])
         self.hourglass = hg
-        self.mask = nn.Conv2d(out_filters, num_kp + 1, kernel_size=(7, 7), padding=(3, 3))
-        self.occlusion = nn.Conv2d(out_filters, 1, kernel_size=(7, 7), padding=(3, 3)) if estimate_occlusion_map else None
+        self.mask = _Conv2d(out_filters, num_kp + 1, kernel_size=(7, 7), padding=(3, 3))
+        self.occlusion = _Conv2d(out_filters, 1, kernel_size=(7, 7), padding=(3, 3)) if estimate_occlusion_map else None
         if scale_factor != 1:
             self.down = _AntiAlias(num_channels)
         self.num_kp, self.scale_factor, self.kp_variance = num_kp, scale_factor, kp_variance
 
 
-class OcclusionAwareGenerator(nn.Module):
+class OcclusionAwareGenerator(_Tracked, nn.Module):
     """MI355X-native stand-in for reference modules/generator.py:OcclusionAwareGenerator."""
 
     def __init__(self, num_channels, num_kp, block_expansion, max_features, num_down_blocks,
@@ -132,12 +179,12 @@ class OcclusionAwareGenerator(nn.Module):
             self.dense_motion_network = None
         down, up, bott = generator_channels(self._cfg)
         self.first = _ConvNorm(num_channels, block_expansion, 7)
-        self.down_blocks = nn.ModuleList([_ConvNorm(ci, co, 3) for ci, co in down])
-        self.up_blocks = nn.ModuleList([_ConvNorm(ci, co, 3) for ci, co in up])
-        self.bottleneck = nn.Sequential()
+        self.down_blocks = _ModuleList([_ConvNorm(ci, co, 3) for ci, co in down])
+        self.up_blocks = _ModuleList([_ConvNorm(ci, co, 3) for ci, co in up])
+        self.bottleneck = _Sequential()
         for i in range(num_bottleneck_blocks):
             self.bottleneck.add_module("r" + str(i), _ResHolder(bott))
-        self.final = nn.Conv2d(block_expansion, num_channels, kernel_size=(7, 7), padding=(3, 3))
+        self.final = _Conv2d(block_expansion, num_channels, kernel_size=(7, 7), padding=(3, 3))
         self.estimate_occlusion_map = estimate_occlusion_map
         self.num_channels = num_channels
         self.max_frames = int(max_frames)
@@ -187,12 +234,33 @@ class OcclusionAwareGenerator(nn.Module):
         return state
 
     # -- engine management ---------------------------------------------------------------------------
+    def _epoch(self) -> "_Epoch":
+        cell = self.__dict__.get("_eamm_epoch")
+        if cell is None:
+            cell = self.__dict__["_eamm_epoch"] = _Epoch()
+        return cell
+
+    def _adopt(self):
+        """Hand every tracked module of the tree this generator's epoch cell; note whether the tree holds modules of other
+        classes (a user's replacement block): their internal changes raise no epoch, so the fast path then also compares
+        tensor identities."""
+        cell = self._epoch()
+        foreign = False
+        for mod in self.modules():
+            if isinstance(mod, _Tracked):
+                mod.__dict__["_eamm_epoch"] = cell
+            else:
+                foreign = True
+        self.__dict__["_foreign"] = foreign
+
     def _tensor_slots(self):
         """(owner dict, key, state_dict name) of every parameter and buffer, collected once: reading the LIVE dicts each call
         sees replaced tensors (``.cuda()``, ``load_state_dict(assign=True)``, attribute assignment) without rebuilding a
         ``state_dict`` per forward (340 us for the 196 tensors of the shipped configuration -- a third of a one-frame call)."""
         slots = self.__dict__.get("_slots")
-        if slots is None or self.__dict__.get("_slots_epoch") != _STRUCTURE_EPOCH[0]:
+        epoch = self._epoch()
+        if slots is None or self.__dict__.get("_slots_epoch") != epoch.n:
+            self._adopt()
             slots = []
             for prefix, mod in self.named_modules():
                 for store, skip in ((mod._parameters, ()), (mod._buffers, mod._non_persistent_buffers_set)):
@@ -200,7 +268,7 @@ class OcclusionAwareGenerator(nn.Module):
                         if key not in skip:
                             slots.append((store, key, (prefix + "." if prefix else "") + key))
             self.__dict__["_slots"] = slots
-            self.__dict__["_slots_epoch"] = _STRUCTURE_EPOCH[0]
+            self.__dict__["_slots_epoch"] = epoch.n
         return slots
 
     def _weights_version(self):
@@ -208,26 +276,32 @@ class OcclusionAwareGenerator(nn.Module):
         replaces).  The full tuple costs 40 us for the 224 tensors of the shipped configuration -- 4 % of a one-frame call -- so
         the hot path (``_weights_unchanged``) only adds up the version counters of the tensors seen last time: they never
         decrease, so an equal sum means no in-place write, and a REPLACED tensor shows as a changed structure epoch (attribute
-        assignment, ``load_state_dict``: overridden below to bump it) or a changed identity on the slow path."""
+        assignment in any module of the tree, ``load_state_dict`` / ``_apply``: overridden below to bump it) or a changed identity
+        on the slow path."""
         ts = [t for t in (store[key] for store, key, _ in self._tensor_slots()) if t is not None]
         return tuple(map(id, ts)) + tuple(map(_VERSION_OF, ts))
 
     def _weights_unchanged(self) -> bool:
         fast = self.__dict__.get("_fast_key")
-        return (fast is not None and fast[0] == _STRUCTURE_EPOCH[0] and sum(map(_VERSION_OF, fast[1])) == fast[2])
+        if fast is None or fast[0] != self._epoch().n or sum(map(_VERSION_OF, fast[1])) != fast[2]:
+            return False
+        if self.__dict__.get("_foreign"):      # modules of other classes in the tree: their tensors may have been swapped silently
+            live = [t for t in (store[key] for store, key, _ in self.__dict__["_slots"]) if t is not None]
+            return len(live) == len(fast[1]) and all(a is b for a, b in zip(live, fast[1]))
+        return True
 
     def _remember_weights(self):
         ts = [t for t in (store[key] for store, key, _ in self._tensor_slots()) if t is not None]
-        self.__dict__["_fast_key"] = (_STRUCTURE_EPOCH[0], ts, sum(map(_VERSION_OF, ts)))
+        self.__dict__["_fast_key"] = (self._epoch().n, ts, sum(map(_VERSION_OF, ts)))
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
-        _bump_epoch()          # assign=True swaps buffers without a registration hook; copies bump the version counters anyway
+        self._bump()           # assign=True swaps buffers without a registration call; copies bump the version counters anyway
         return out
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
-        _bump_epoch()          # .cuda() / .to() / .float(): `param.data = fn(param.data)` changes neither identity nor version
+        self._epoch().n += 1   # .cuda() / .to() / .float(): `param.data = fn(param.data)` changes neither identity nor version
         return out
 
     def _ensure_engine(self, height: int, width: int, frames: int, sources: int) -> Engine:

@@ -16,6 +16,18 @@ def _hull_area(points: torch.Tensor) -> float:
     return float(ConvexHull(points.detach().cpu().numpy()).volume)
 
 
+def _inverse_2x2(m: torch.Tensor) -> torch.Tensor:
+    """Inverse of [...,2,2] matrices in closed form (adjugate / determinant) -- the reference calls ``torch.inverse``
+    (demo.py:128), which on a GPU tensor is a solver-library call (handle creation + LU) for ten 2x2 matrices; the closed form
+    is a handful of element-wise operations where the tensors live and agrees with the LU result to rounding.  A singular
+    matrix gives inf / nan here where torch.inverse raises; the generator's own check (eamm_check_numeric) still raises."""
+    if m.shape[-2:] != (2, 2):
+        return torch.inverse(m)
+    a, b, c, d = m[..., 0, 0], m[..., 0, 1], m[..., 1, 0], m[..., 1, 1]
+    det = a * d - b * c
+    return torch.stack([torch.stack([d, -b], -1), torch.stack([-c, a], -1)], -2) / det[..., None, None]
+
+
 def normalize_kp(kp_source: Dict[str, torch.Tensor], kp_driving: Dict[str, torch.Tensor],
                  kp_driving_initial: Dict[str, torch.Tensor], adapt_movement_scale: bool = False,
                  use_relative_movement: bool = False, use_relative_jacobian: bool = False) -> Dict[str, torch.Tensor]:
@@ -35,7 +47,7 @@ def normalize_kp(kp_source: Dict[str, torch.Tensor], kp_driving: Dict[str, torch
         diff = (kp_driving["value"] - kp_driving_initial["value"]) * scale
         out["value"] = diff + kp_source["value"]
         if use_relative_jacobian:
-            jd = torch.matmul(kp_driving["jacobian"], torch.inverse(kp_driving_initial["jacobian"]))
+            jd = torch.matmul(kp_driving["jacobian"], _inverse_2x2(kp_driving_initial["jacobian"]))
             out["jacobian"] = torch.matmul(jd, kp_source["jacobian"])
     return out
 

@@ -63,6 +63,9 @@ def antialias_down(source: torch.Tensor, weight: Optional[torch.Tensor], scale_f
     return _AntiAliasDownFunction.apply(source.contiguous(), None if weight is None else weight.contiguous(), inv)
 
 
+_SINGULAR = "kp_records: a driving jacobian is singular (torch.inverse would raise, dense_motion.py:56)"
+
+
 class _KpRecordsFunction(torch.autograd.Function):
     """(kp_driving value, jacobian, kp_source value, jacobian) -> records [n,K,8]: kd.xy, ks.xy, J = Js inverse(Jd)."""
 
@@ -74,14 +77,22 @@ class _KpRecordsFunction(torch.autograd.Function):
         with torch.cuda.device(kd_val.device):
             _check(_lib.lib().eamm_op_kp_records(kd_val.device.index, _ptr(kd_val), _ptr(kd_jac), _ptr(ks_val), _ptr(ks_jac), n, k,
                                                  _ptr(rec), _ptr(flag), _stream(kd_val.device)))
-        if kd_jac is not None and int(flag.item()):      # torch.inverse raises (and synchronises) on a singular matrix too
-            raise RuntimeError("kp_records: a driving jacobian is singular (torch.inverse would raise, dense_motion.py:56)")
+        # torch.inverse raises (and synchronises) on a singular matrix too -- but a host read is illegal while the stream is being
+        # captured into a graph: there the flag stays on the device and backward() (or the replay's caller) reads it
+        ctx.flag = None
+        if kd_jac is not None:
+            if torch.cuda.is_current_stream_capturing():
+                ctx.flag = flag
+            elif int(flag.item()):
+                raise RuntimeError(_SINGULAR)
         ctx.save_for_backward(kd_jac, ks_jac)
         return rec
 
     @staticmethod
     def backward(ctx, grad_rec):
         kd_jac, ks_jac = ctx.saved_tensors
+        if ctx.flag is not None and not torch.cuda.is_current_stream_capturing() and int(ctx.flag.item()):
+            raise RuntimeError(_SINGULAR)
         n, k = grad_rec.shape[:2]
         grad_rec = grad_rec.contiguous()
         need = ctx.needs_input_grad

@@ -191,6 +191,92 @@ def synthetic_state_dict(cfg, seed: int = 1234, spec=None) -> "OrderedDict[str, 
     return sd
 
 
+def adversarial_state_dict(cfg, seed: int = 1234, bn_stats=None) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded synthetic generator weights with the statistics of a badly conditioned TRAINED checkpoint (VERDICT r04 item 6;
+    the benign `synthetic_state_dict` keeps BatchNorm variance and gain in [0.75, 1.25]):
+      * every convolution in front of a BatchNorm has per-output-channel scales 10^U(-2, 0.5) (pre-normalisation standard
+        deviations 0.01 .. 3.2, variances 1e-4 .. 10) and twice the He gain in the weights (a gain of 4 in variance);
+      * 3 % of those channels are DEAD: weights x 1e-3 with the bias kept, i.e. a constant plus a fluctuation a thousand times
+        smaller, which BatchNorm then amplifies by gamma / sqrt(var + eps) ~ 100 .. 300 (reference batchnorm.py:48-53);
+      * BatchNorm gains 10^U(-0.6, 0.6) = 0.25 .. 4, one in ten negative; shifts 0.3 N(0, 1).
+    The running statistics cannot be drawn at random -- activations would explode or vanish through 30 layers; a trained
+    network's statistics are those of its own activations -- so they come from ``bn_stats`` ({norm prefix: (mean, var)}):
+    the fixture generator (make_golden.py) calibrates them with one batch-statistics pass of the reference-equivalent forward on the fixture's
+    inputs, perturbs the variances by 10^U(-0.3, 0.3) and stores them IN the fixture (a few hundred kB), so that the GPU box
+    rebuilds exactly these weights from the seed + the fixture.  Without ``bn_stats``: mean 0, variance 1 (calibration input)."""
+    sd = synthetic_state_dict(cfg, seed=seed)
+    rs = np.random.RandomState(seed + 4242)
+    pairs = []   # (convolution prefix, norm prefix)
+    for key in sd:
+        if key.endswith(".conv.weight"):
+            pairs.append((key[:-len(".weight")], key[:-len(".conv.weight")] + ".norm"))
+        elif key.endswith(".conv1.weight"):
+            pairs.append((key[:-len(".weight")], key[:-len(".conv1.weight")] + ".norm2"))
+    for conv, norm in pairs:
+        w, b = sd[conv + ".weight"], sd[conv + ".bias"]
+        co = w.shape[0]
+        scale = 10.0 ** rs.uniform(-2.0, 0.5, co)
+        dead = rs.uniform(size=co) < 0.03
+        wscale = np.where(dead, 1e-3, 2.0 * scale).astype(np.float32)
+        sd[conv + ".weight"] = w * torch.from_numpy(wscale)[:, None, None, None]
+        sd[conv + ".bias"] = b * torch.from_numpy(np.where(dead, 1.0, scale).astype(np.float32))
+    for key in list(sd):
+        if key.endswith(".running_var"):
+            norm = key[:-len(".running_var")]
+            c = sd[key].numel()
+            gamma = 10.0 ** rs.uniform(-0.6, 0.6, c) * np.where(rs.uniform(size=c) < 0.1, -1.0, 1.0)
+            sd[norm + ".weight"] = torch.from_numpy(gamma.astype(np.float32))
+            sd[norm + ".bias"] = torch.from_numpy((0.3 * rs.standard_normal(c)).astype(np.float32))
+            if bn_stats is None:
+                sd[norm + ".running_mean"] = torch.zeros(c)
+                sd[norm + ".running_var"] = torch.ones(c)
+            else:
+                mean, var = bn_stats[norm]
+                sd[norm + ".running_mean"] = torch.as_tensor(mean, dtype=torch.float32).clone()
+                sd[norm + ".running_var"] = torch.as_tensor(var, dtype=torch.float32).clone()
+    return sd
+
+
+def adversarial_inputs(size: int, frames: int, num_kp: int = 10, channels: int = 3):
+    """Inputs for the adversarial fixtures: a SATURATED source (every pixel exactly 0 or 1) and key points on or just inside the
+    frame border (|coordinate| in [0.9, 1.0]; a few at exactly +-1), jacobians I + 0.3 N(0,1)."""
+    rs = np.random.RandomState(77)
+    src = torch.from_numpy((rs.uniform(size=(1, channels, size, size)) > 0.5).astype(np.float32))
+
+    def kps(n, seed):
+        r = np.random.RandomState(seed)
+        v = r.uniform(0.9, 1.0, (n, num_kp, 2)) * np.where(r.uniform(size=(n, num_kp, 2)) < 0.5, -1.0, 1.0)
+        v[:, 0] = np.sign(v[:, 0])                       # key point 0 sits exactly in a corner
+        v[:, 1:4] *= r.uniform(0.0, 1.0, (n, 3, 2))      # a few stay inside, or nothing of the source would be sampled
+        j = np.eye(2)[None, None] + 0.3 * r.standard_normal((n, num_kp, 2, 2))
+        return {"value": torch.from_numpy(v.astype(np.float32)), "jacobian": torch.from_numpy(j.astype(np.float32))}
+    return src, kps(1, 300), kps(frames, 301)
+
+
+def trained_like_kp_state_dict(cfg, seed: int) -> "OrderedDict[str, torch.Tensor]":
+    """Synthetic key-point-detector weights with the jacobian head near its trained shape: the reference initialises that head to
+    zero weights and an identity bias (modules/keypoint_detector.py:27-28) and training keeps the jacobians near I; He-scaled
+    random weights instead give jacobians with |det| ~ 0.01, whose inverse (normalize_kp, demo.py:128; dense_motion.py:56)
+    amplifies every rounding difference a hundredfold -- fine for a detector's own parity test, useless for a chain through the
+    generator.  Here: the seeded random head scaled by 0.05 plus bias = identity + 0.05 N(0,1)."""
+    sd = synthetic_state_dict(cfg, seed=seed, spec=kp_state_dict_spec(cfg))
+    if "jacobian.weight" in sd:
+        rs = np.random.RandomState(seed + 1000)
+        n = sd["jacobian.bias"].numel() // 4
+        sd["jacobian.weight"] = sd["jacobian.weight"] * 0.05
+        sd["jacobian.bias"] = torch.from_numpy((np.tile([1.0, 0.0, 0.0, 1.0], n) + 0.05 * rs.standard_normal(4 * n)).astype(np.float32))
+    return sd
+
+
+def synthetic_lstm_features(frames: int, channels: int = 256, seed: int = 5) -> torch.Tensor:
+    """[T,C] stand-in for the audio network's LSTM output (AT_net2, util.py:600-607): a random pose plus a slow random walk,
+    so that consecutive frames' key points move like a talking head's (the One-Euro filter then has something to smooth)."""
+    rs = np.random.RandomState(seed)
+    base = 0.3 * rs.standard_normal((1, channels))
+    walk = 0.05 * np.cumsum(rs.standard_normal((frames, channels)), axis=0)
+    return torch.from_numpy((base + walk).astype(np.float32))
+
+
 def synthetic_source(size: int, seed: int = 1, batch: int = 1, channels: int = 3) -> torch.Tensor:
     """uniform[0,1) RGB source, float32 [batch,3,size,size]; ``channels``: grey-scale / two-channel variants."""
     rs = np.random.RandomState(seed)

@@ -273,6 +273,101 @@ def animate_clip(sd, cfg, source_image, kp_source, kp_driving_seq):
     return frames
 
 
+# ----------------------------------------------------------------------------------------------
+# clip harness ("next" row N2) -- reference demo.py:112-132, 194-282, filter1.py:13-47
+# ----------------------------------------------------------------------------------------------
+class _LowPass:
+    """filter1.py:13-26."""
+
+    def __init__(self):
+        self.prev_raw = None
+        self.prev_filtered = None
+
+    def process(self, value, alpha):
+        s = value if self.prev_raw is None else alpha * value + (1.0 - alpha) * self.prev_filtered
+        self.prev_raw, self.prev_filtered = value, s
+        return s
+
+
+class OneEuro:
+    """filter1.py:29-47, statement for statement (tensor in, tensor out; one call per frame)."""
+
+    def __init__(self, mincutoff=1.0, beta=0.0, dcutoff=1.0, freq=30):
+        self.freq, self.mincutoff, self.beta, self.dcutoff = freq, mincutoff, beta, dcutoff
+        self.x_filter, self.dx_filter = _LowPass(), _LowPass()
+
+    def compute_alpha(self, cutoff):
+        import numpy as np
+        te = 1.0 / self.freq
+        tau = 1.0 / (2 * np.pi * cutoff)
+        return 1.0 / (1.0 + tau / te)
+
+    def process(self, x):
+        prev_x = self.x_filter.prev_raw
+        dx = 0.0 if prev_x is None else (x - prev_x) * self.freq
+        edx = self.dx_filter.process(dx, self.compute_alpha(self.dcutoff))
+        cutoff = self.mincutoff + self.beta * abs(edx)
+        return self.x_filter.process(x, self.compute_alpha(cutoff))
+
+
+def smooth_sequence(seq, mincutoff, beta, dcutoff, freq, scale):
+    """demo.py:241-250 (and :231-239 for the emotion displacements): `process(x * scale) / scale`, frame after frame."""
+    f = OneEuro(mincutoff=mincutoff, beta=beta, dcutoff=dcutoff, freq=freq)
+    return torch.stack([f.process(seq[t] * scale) / scale for t in range(seq.shape[0])])
+
+
+def normalize_kp(kp_source, kp_driving, kp_driving_initial, adapt_movement_scale=False, use_relative_movement=False,
+                 use_relative_jacobian=False):
+    """demo.py:112-132 for ONE driving frame (the reference calls it per frame, demo.py:276)."""
+    import numpy as np
+    from scipy.spatial import ConvexHull
+    scale = 1
+    if adapt_movement_scale:
+        source_area = ConvexHull(kp_source["value"][0].numpy()).volume
+        driving_area = ConvexHull(kp_driving_initial["value"][0].numpy()).volume
+        scale = np.sqrt(source_area) / np.sqrt(driving_area)
+    new = dict(kp_driving)
+    if use_relative_movement:
+        diff = (kp_driving["value"] - kp_driving_initial["value"])
+        diff = diff * scale
+        new["value"] = diff + kp_source["value"]
+        if use_relative_jacobian:
+            jd = torch.matmul(kp_driving["jacobian"], torch.inverse(kp_driving_initial["jacobian"]))
+            new["jacobian"] = torch.matmul(jd, kp_source["jacobian"])
+    return new
+
+
+def animation_keypoints(sd_kp, cfg_kp, sd_decon, sd_kpa, cfg_kpa, source_image, lstm_features, emo_driving=None,
+                        relative=True, adapt_movement_scale=True):
+    """The key-point side of make_animation_smooth (demo.py:194-277), per frame as the reference runs it:
+    kp_source = kp_detector(source) (:206); kp_driving_initial = kp_detector_a(deco_out[:, 0]) (:207); per frame
+    kp_detector_a(deco_out[:, t]) (:219) with deco_out[:, t] = decon(lstm_out[:, t]) (util.py:603-607); One-Euro smoothing of
+    the emotion displacements (:231-239) and of the key points (:241-250); emotion offsets (:263-271); normalize_kp (:276).
+    ``emo_driving``: the emotion network's per-frame output {'value': [T,E,2], 'jacobian': [T,E,2,2]} (that network is outside
+    this path) or None.  Returns (kp_source, [normalised key points of frame t], raw key points, smoothed key points)."""
+    with torch.no_grad():
+        kp_source = {k: v for k, v in kp_detector_forward(sd_kp, cfg_kp, source_image).items() if k != "heatmap"}
+        T = lstm_features.shape[0]
+        frames = [kp_detector_a_forward(sd_kpa, cfg_kpa, deconv_tail(sd_decon, lstm_features[t:t + 1])) for t in range(T)]
+        raw = {k: torch.cat([f[k] for f in frames]) for k in ("value", "jacobian")}
+        kp_initial = {k: raw[k][:1] for k in raw}
+        if emo_driving is not None:
+            emo = {k: smooth_sequence(emo_driving[k], 1, 0.2, 1.0, 100, 100) for k in ("value", "jacobian")}
+        smooth = {k: smooth_sequence(raw[k], 0.05, 8, 1.0, 100, 10) for k in raw}
+        out = []
+        for t in range(T):
+            kp = {k: smooth[k][t:t + 1].clone() for k in smooth}
+            if emo_driving is not None:                                  # opt.type == 'linear_3'
+                for key in ("value", "jacobian"):
+                    kp[key][:, 1] = kp[key][:, 1] + emo[key][t:t + 1][:, 0] * 0.2
+                    kp[key][:, 4] = kp[key][:, 4] + emo[key][t:t + 1][:, 1]
+                    kp[key][:, 6] = kp[key][:, 6] + emo[key][t:t + 1][:, 2]
+            out.append(normalize_kp(kp_source, kp, kp_initial, adapt_movement_scale=adapt_movement_scale,
+                                    use_relative_movement=relative, use_relative_jacobian=relative))
+    return kp_source, out, raw, smooth
+
+
+
 def sync_batchnorm_forward(shards, weight, bias, running_mean, running_var, eps=1e-5, momentum=0.1, training=True,
                            parallel=None):
     """`_SynchronizedBatchNorm.forward` (reference sync_batchnorm/batchnorm.py:46-125) for the list of per-replica

@@ -108,6 +108,60 @@ def case(OAG, name, cfg, size, n_frames, seed_w, stride, with_jacobian=True, per
     return report
 
 
+def adversarial_case(OAG, name, cfg, size, n_frames, stride, seed_w=1234):
+    """the reference's outputs on a badly conditioned network -- eamm_amd.weights.adversarial_state_dict
+    (BatchNorm variances 1e-4 .. 10, gains 0.25 .. 4 of either sign, dead channels, conv gain x 4) with running statistics
+    calibrated to its own activations, a saturated 0 / 1 source and key points on the frame border.  The calibrated statistics
+    travel in the fixture; the weights are rebuilt from the seed."""
+    from eamm_amd.weights import adversarial_inputs, adversarial_state_dict
+    source, kp_s, kp_d = adversarial_inputs(size, n_frames, cfg["num_kp"], cfg["num_channels"])
+    src_b = source.expand(n_frames, -1, -1, -1).contiguous()
+    kp_s_b = {k: v.expand(n_frames, *v.shape[1:]).contiguous() for k, v in kp_s.items()}
+    # calibration: one batch-statistics pass (every BatchNorm normalises with the batch's own statistics, so the activations stay
+    # in range whatever the gains); running statistics := those, variances perturbed by 10^U(-0.3, 0.3)
+    sd0 = adversarial_state_dict(cfg, seed_w)
+    with torch.no_grad():
+        _, st = orc.generator_forward_train({k: (v.double() if v.is_floating_point() else v) for k, v in sd0.items()}, cfg,
+                                            src_b.double(), {k: v.double() for k, v in kp_d.items()},
+                                            {k: v.double() for k, v in kp_s_b.items()})
+    rs = np.random.RandomState(seed_w + 99)
+    bn = {}
+    for norm, (rm, rv) in sorted(st.items()):      # momentum 0.1 from running (0, 1): batch mean = rm / 0.1, unbiased var = (rv - 0.9) / 0.1
+        mean = (rm / 0.1).float().numpy()
+        var = np.maximum(((rv - 0.9) / 0.1).float().numpy(), 1e-12) * (10.0 ** rs.uniform(-0.3, 0.3, rv.numel())).astype(np.float32)
+        bn[norm] = (mean, var.astype(np.float32))
+    sd = adversarial_state_dict(cfg, seed_w, bn_stats=bn)
+    gen = OAG(**cfg).eval()
+    gen.load_state_dict(sd, strict=True)
+    ref = run_reference(gen, src_b, kp_d, kp_s_b)
+    with torch.no_grad():
+        mine = orc.generator_forward(sd, cfg, src_b, kp_d, kp_s_b)
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        ref64 = orc.generator_forward(sd64, cfg, src_b.double(), {k: v.double() for k, v in kp_d.items()},
+                                      {k: v.double() for k, v in kp_s_b.items()})
+    report = {}
+    blob = {"weight_seed": np.int64(seed_w), "size": np.int64(size), "stride": np.int64(stride), "frames": np.int64(n_frames)}
+    allvar = np.concatenate([v for _, v in bn.values()])
+    blob["running_var_range"] = np.asarray([allvar.min(), np.median(allvar), allvar.max()], dtype=np.float64)
+    for norm, (mean, var) in bn.items():
+        blob["bn_mean/" + norm] = mean
+        blob["bn_var/" + norm] = var
+    for k in KEYS:
+        d = float((mine[k] - ref[k]).abs().max())
+        floor = float((ref[k].double() - ref64[k]).abs().max())
+        report[k] = {"oracle_vs_reference": d, "fp32_vs_fp64_floor": floor, "stats": stats(ref[k])}
+        assert torch.isfinite(ref[k]).all(), (name, k)
+        assert d <= max(2e-6, 2 * floor), (name, k, d, floor)
+        t = ref[k]
+        s = stride if k in ("prediction", "deformed") else (max(1, stride // 4) if k == "sparse_deformed" else 1)
+        blob[k] = (t[:, ::s, ::s] if k == "deformation" else t[..., ::s, ::s]).contiguous().numpy()
+        blob[k + "_stride"] = np.int64(s)
+        blob[k + "_floor"] = np.float64(floor)         # the reference's own fp32-vs-fp64 distance on this network
+        blob[k + "_stats"] = np.asarray(report[k]["stats"], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **blob)
+    return report
+
+
 def no_motion_case(OAG):
     """The reference generator built WITHOUT a motion network (dense_motion_params=None, generator.py:18-23): forward is
     encoder -> bottleneck -> up blocks -> final, 'prediction' is the only output and the key points are never read."""
@@ -654,6 +708,21 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "eval_backward":
         train_backward_case(import_reference(), "tiny64_eval_backward", tiny_config(), 64, 2, training=False)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "adversarial":   # badly conditioned statistics (added without regenerating the rest)
+        torch.set_num_threads(os.cpu_count() or 1)
+        OAG = import_reference()
+        path = os.path.join(GOLDEN, "summary.json")
+        summary = json.load(open(path))
+        for name, cfg, size, n, stride in (("tiny64_adversarial", tiny_config(), 64, 3, 1), ("full256_adversarial", hot_path_config(), 256, 2, 4)):
+            rep = adversarial_case(OAG, name, cfg, size, n, stride)
+            summary["cases"][name] = rep
+            print(name)
+            for k, r in rep.items():
+                print(f"   {k:16s} oracle-vs-ref {r['oracle_vs_reference']:.2e}  fp64 floor {r['fp32_vs_fp64_floor']:.2e}"
+                      f"  mean/std/min/max {r['stats'][0]:.3f} {r['stats'][1]:.3f} {r['stats'][2]:.3f} {r['stats'][3]:.3f}")
+        with open(path, "w") as f:
+            json.dump(summary, f, indent=1, sort_keys=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "channels":   # num_channels 1 and 2 (generator.py:14,25,46; dense_motion.py:17-18,27)
         OAG = import_reference()
         for name, ch in (("tiny64_gray", 1), ("tiny64_two_channels", 2)):
@@ -709,6 +778,8 @@ def main():
     summary["full512_clip1"] = case(OAG, "full512_clip1", full, 512, 1, 1234, 8)
     summary["tiny64_gray"] = case(OAG, "tiny64_gray", {**tiny, "num_channels": 1}, 64, 2, 1234, 1)
     summary["tiny64_two_channels"] = case(OAG, "tiny64_two_channels", {**tiny, "num_channels": 2}, 64, 2, 1234, 1, per_frame_source=True)
+    summary["tiny64_adversarial"] = adversarial_case(OAG, "tiny64_adversarial", tiny, 64, 3, 1)
+    summary["full256_adversarial"] = adversarial_case(OAG, "full256_adversarial", full, 256, 2, 4)
     no_motion_case(OAG)
     normalize_kp_case()
     emotion_case()

@@ -78,6 +78,13 @@ def test_bench_single_gpu_line():
     assert v["ok"] is True and v["fixture"]["ok"] is True and v["fixture"]["max_abs_err"] <= 1e-4
     assert v["spot_frames"] == [0, 1024, 2047] and v["vs_contract_plan_max_abs"] <= 2e-5
     assert k["plan"]["pass_chains"] == 4 and k["plan"]["frames_per_chain"] == 16 and k["collectives_per_clip"] == 0
+    # end-to-end leg: make_animation_smooth whole, frames delivered to pinned host memory
+    e = d["e2e_clip"]
+    assert e["frames"] == 2048 and e["verify"]["ok"] is True and e["verify"]["uint8_levels_vs_contract_plan"] <= 1
+    ph = e["phases_ms_rank0"]
+    assert {"front_ms", "smooth_ms", "normalize_ms", "encode_ms", "compute_ms", "d2h_tail_ms"} <= set(ph)
+    assert ph["smooth_ms"] <= 2.0, ph                  # the round-4 host loop: 608 ms
+    assert e["host_bytes"] == 2048 * 256 * 256 * 3 and 0.5 * k["frames_per_s"] <= e["frames_per_s"] <= 1.05 * k["frames_per_s"]
     # the line says what it was measured under: parity at the timed geometry, knobs, launch plan
     pc = d["parity_check"]
     assert pc["ok"] is True and pc["fixture"] == "tests/golden/full256_clip2.npz" and pc["frames"] == 2 and pc["max_abs_err"] <= 1e-4
@@ -152,7 +159,7 @@ def test_bench_two_ranks_share_one_gpu():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-             "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--clip-frames", "70", "--clip-gather"],
+             "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--clip-frames", "70", "--clip-gather", "--e2e-frames", "0"],
             env={"EAMM_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and "source_broadcast_ms" in d
     k = d["clip"]    # 70 frames over 2 ranks: 35 each, broadcast + compute + uint8 gather timed
@@ -167,7 +174,7 @@ def test_bench_bare_gpus2_spawns_its_ranks():
     runs one rank per GPU over RCCL."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["EAMM_BENCH_BACKEND"] = "gloo"
-    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--clip-frames", "64"],
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--clip-frames", "64", "--e2e-frames", "40"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -178,6 +185,7 @@ def test_bench_bare_gpus2_spawns_its_ranks():
     assert k["verify"]["ok"] is True and k["verify"]["spot_frames"] == [0, 16, 31] and k["collectives_per_clip"] == 2
     assert len(k["phases_ms_per_rank"]) == 2 and all(p["compute_ms"] > 0 for p in k["phases_ms_per_rank"])
     assert d["parity_check"]["ok"] is True and "rccl_warmup_ms" in d
+    assert d["e2e_clip"]["frames"] == 40 and d["e2e_clip"]["n_gpus"] == 2 and d["e2e_clip"]["verify"]["ok"] is True
     assert abs(d["value"] - 2 * 3 * 16 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01
 
 
@@ -187,7 +195,7 @@ def test_bench_rccl_path_single_rank():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-frames", "0", "--clip-frames", "64"],
+    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-frames", "0", "--clip-frames", "64", "--e2e-frames", "0"],
             env={"EAMM_BENCH_FORCE_DIST": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     assert d["n_gpus"] == 1 and "source_broadcast_ms" in d and d["value"] > 0 and d["rccl_warmup_ms"] > 0
@@ -198,11 +206,11 @@ def test_bench_refuses_a_wrong_results_knob():
     """EAMM_WINO4_EPI_V=1 (a round-4 timing experiment that makes the bottleneck compute garbage) is compiled out of the product
     library: with it set, eamm_create fails loudly and bench.py prints no line."""
     out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--clip-frames", "0",
-                          "--train-pairs", "0"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                          "--train-pairs", "0", "--e2e-frames", "0"], cwd=ROOT, capture_output=True, text=True, timeout=600,
                          env={**os.environ, "EAMM_WINO4_EPI_V": "1"})
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "EAMM_WINO4_EPI_V" in out.stderr and "EXPERIMENTS" in out.stderr
-    d = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--clip-frames", "0", "--train-pairs", "0"],
+    d = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--clip-frames", "0", "--train-pairs", "0", "--e2e-frames", "0"],
             env={"EAMM_PASS_CHAINS": "1"})
     assert d["knobs"]["env"] == {"EAMM_PASS_CHAINS": "1"} and d["knobs"]["library"]["EAMM_PASS_CHAINS"] == 1
     assert d["knobs"]["plan"]["pass_chains"] == 1 and d["knobs"]["plan"]["bottleneck_chains"] == 2 and d["parity_check"]["ok"] is True

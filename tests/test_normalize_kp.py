@@ -73,3 +73,39 @@ def test_emotion_offsets_match_reference_loop():
         apply_emotion_offsets(kp_d, emo, kind="linear_4")
     with pytest.raises(RuntimeError):
         apply_emotion_offsets(kp_d, {"value": emo["value"][:, :2], "jacobian": emo["jacobian"][:, :2]})
+
+
+def test_oracle_clip_harness_restatements_match_the_reference_fixtures():
+    """oracle/eamm_oracle.py restates filter1.OneEuroFilter and demo.py:normalize_kp statement for statement (the checker of the
+    end-to-end GPU test, tests/test_gpu_pipeline.py): both against the fixtures the reference's own code produced."""
+    from oracle import eamm_oracle as orc
+    z = np.load(os.path.join(GOLDEN, "one_euro.npz"))
+    for name, p in (("kp", (0.05, 8, 1.0, 100, 10)), ("emo", (1, 0.2, 1.0, 100, 100))):
+        for k in ("value", "jacobian"):
+            out = orc.smooth_sequence(torch.from_numpy(z[k]), *p)
+            assert torch.equal(out, torch.from_numpy(z[f"{name}_{k}"])), (name, k)      # same statements, same floats
+    z = np.load(os.path.join(GOLDEN, "normalize_kp.npz"))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    kp_s = {"value": g["kp_source_value"], "jacobian": g["kp_source_jacobian"]}
+    kp_i = {"value": g["kp_initial_value"], "jacobian": g["kp_initial_jacobian"]}
+    for a in (0, 1):
+        for r in (0, 1):
+            for j in (0, 1):
+                for t in range(g["kp_driving_value"].shape[0]):
+                    kd = {"value": g["kp_driving_value"][t:t + 1], "jacobian": g["kp_driving_jacobian"][t:t + 1]}
+                    o = orc.normalize_kp(kp_s, kd, kp_i, bool(a), bool(r), bool(j))
+                    assert torch.equal(o["value"], g[f"value_a{a}r{r}j{j}"][t:t + 1])
+                    assert torch.equal(o["jacobian"], g[f"jacobian_a{a}r{r}j{j}"][t:t + 1])
+
+
+def test_trained_like_detector_weights_give_well_conditioned_jacobians():
+    from eamm_amd import kp_detector_a_config
+    from eamm_amd.weights import deconv_state_dict_spec, synthetic_lstm_features, synthetic_state_dict, trained_like_kp_state_dict
+    from oracle import eamm_oracle as orc
+    cfg = kp_detector_a_config()
+    sd = trained_like_kp_state_dict(cfg, 77)
+    sd_d = synthetic_state_dict(None, seed=3, spec=deconv_state_dict_spec())
+    with torch.no_grad():
+        kp = orc.kp_detector_a_forward(sd, cfg, orc.deconv_tail(sd_d, synthetic_lstm_features(4)))
+    assert float(torch.linalg.cond(kp["jacobian"]).max()) < 2.0 and float(torch.det(kp["jacobian"]).min()) > 0.5
+    assert float((kp["value"][1:] - kp["value"][:-1]).abs().max()) > 1e-3        # consecutive frames move
