@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 table = {}
 if os.path.exists(os.path.join(P, "pmc_traffic.json")):
