@@ -168,7 +168,8 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
                  group=None, gather: bool = False, kp_driving_initial: Optional[Dict[str, torch.Tensor]] = None,
                  relative: bool = False, adapt_movement_scale: bool = False,
                  emo_driving: Optional[Dict[str, torch.Tensor]] = None, emo_type: str = "linear_3",
-                 timings: Optional[Dict[str, float]] = None, to_host: bool = False) -> Tuple[torch.Tensor, Tuple[int, int]]:
+                 timings: Optional[Dict[str, float]] = None, to_host: bool = False,
+                 replicated: bool = False) -> Tuple[torch.Tensor, Tuple[int, int]]:
     """Animate one clip; returns (frames of this rank's shard, (start, stop)).
 
     ``emo_driving`` ({'value': [T,E,2], 'jacobian': [T,E,2,2]}, the emotion network's per-frame displacements) adds the
@@ -179,6 +180,10 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
     Single process: all T frames.  Under torch.distributed: rank 0 supplies ``source_image`` and the
     key points (other ranks may pass None), every rank returns its contiguous shard; with
     ``gather=True`` rank 0 instead returns all T frames (others an empty tensor).
+
+    ``replicated=True``: every rank already holds the source image and all key points (eamm_amd.animate_from_features with its
+    sharded front end): no broadcast at all -- each rank encodes the source itself (0.25 ms at 256x256, less than moving the 5 MB
+    cache) and computes its contiguous shard.
 
     ``to_host=True`` delivers this rank's frames in PINNED HOST memory (what demo.py:281 does per frame with a blocking
     ``.cpu()``): every batch's frames are copied ``non_blocking`` on a copy stream behind an event, so the copy of batch i
@@ -220,7 +225,13 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
     backend.prepare(height, width)
     mark("keypoints_ms")
     # 1. frame-invariant source tensors: encode once on rank 0, one broadcast
-    if distributed:
+    if distributed and replicated:
+        staged = _staged(group, backend.device)
+        backend.encode(source_image)
+        mark("encode_ms")
+        kp_source = {k: v.to(backend.device) for k, v in kp_source.items() if k in ("value", "jacobian")}
+        kp_driving = {k: v.to(backend.device) for k, v in kp_driving.items() if k in ("value", "jacobian")}
+    elif distributed:
         staged = _staged(group, backend.device)
         blob = backend.encode(source_image) if rank == 0 else None
         mark("encode_ms")

@@ -17,7 +17,9 @@ LSTM features in, the clip's frames in host memory out -- every step of the refe
 
 The emotion network (``emo_detector``) and the audio LSTM are outside this path (out of scope / "stays in
 PyTorch-ROCm"): their outputs are inputs here -- ``lstm_features`` [T,256] and, optionally, ``emo_driving``.
-Under torch.distributed the front end runs on rank 0 and the generator's frames are sharded over the ranks (animate_clip).
+Under torch.distributed BOTH loops shard by frames: rank 0's inputs are broadcast (header + one payload), every rank runs the
+detectors on its frames, one all-gather gives every rank the whole key-point sequence (the One-Euro recurrence needs it; 0.2 ms,
+computed redundantly), and every rank animates its shard from its own encoding of the source -- three collectives per clip.
 """
 from __future__ import annotations
 
@@ -27,7 +29,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-from .clip import EngineBackend, animate_clip, driving_keypoints
+from .clip import EngineBackend, _broadcast, _staged, animate_clip, driving_keypoints, shard_bounds
 from .keypoints import apply_emotion_offsets, normalize_kp, smooth_keypoints
 
 # the reference's two filter parameter sets (demo.py:232-233 and :241-242)
@@ -52,50 +54,106 @@ def animate_from_features(generator, kp_detector, deconv_tail, kp_detector_a, so
     ``emo_driving``: None or {'value': [T,E,2], 'jacobian': [T,E,2,2]} (``--add_emo``, type 'linear_3').  ``relative`` /
     ``adapt_movement_scale``: the reference's defaults (True, True).  Returns ``(frames, (start, stop))`` -- this rank's frames
     [n,H,W,3] uint8 (``uint8=True``; what demo.py:507 writes) or [n,3,H,W] float32, in pinned host memory when ``to_host`` --
-    plus, with ``return_keypoints``, a dict of the intermediate key points (rank 0).  Rank > 0 of a process group may pass
-    None for the inputs and then gives the frame ``size`` (H, W) instead (no collective is spent on it).  ``timings`` is filled with the phases' wall-clock milliseconds (a device synchronisation at each
+    plus, with ``return_keypoints``, a dict of the intermediate key points.  Rank > 0 of a process group may pass None for
+    the inputs (they are broadcast from rank 0).  ``timings`` is filled with the phases' wall-clock milliseconds (a device synchronisation at each
     boundary, only when asked for): front_ms (detectors), smooth_ms, normalize_ms, then animate_clip's own."""
-    dev = next(generator.parameters()).device
+    dev = backend.device if backend is not None else next(generator.parameters()).device
+    on_gpu = torch.device(dev).type == "cuda"
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     rank = dist.get_rank(group) if distributed else 0
+    world = dist.get_world_size(group) if distributed else 1
     t_last = [time.perf_counter()]
 
     def mark(name):
         if timings is None:
             return
-        torch.cuda.synchronize(dev)
+        if on_gpu:
+            torch.cuda.synchronize(dev)
         now = time.perf_counter()
         timings[name] = timings.get(name, 0.0) + (now - t_last[0]) * 1e3
         t_last[0] = now
 
-    kps: Dict[str, Dict[str, torch.Tensor]] = {}
-    kp_source = kp_norm = None
-    if rank == 0:
-        src = source_image.to(dev)
-        kp_source = _kp_only(kp_detector(src))                                              # demo.py:206
-        raw = driving_keypoints(deconv_tail, kp_detector_a, lstm_features.to(dev), batch=front_batch)   # demo.py:212-219
-        kp_initial = {k: v[:1].clone() for k, v in raw.items()}                             # demo.py:207 (never smoothed)
-        mark("front_ms")
-        kp_d = smooth_keypoints(raw, **KP_FILTER) if smooth else raw                        # demo.py:241-250
-        if emo_driving is not None:
-            emo = {k: v.to(dev) for k, v in _kp_only(emo_driving).items()}
-            emo = smooth_keypoints(emo, **EMO_FILTER) if smooth else emo                    # demo.py:231-239
-            kp_d = apply_emotion_offsets(kp_d, emo)                                         # demo.py:263-271
-        mark("smooth_ms")
-        kp_norm = normalize_kp(kp_source, kp_d, kp_initial, adapt_movement_scale=adapt_movement_scale,
-                               use_relative_movement=relative, use_relative_jacobian=relative)   # demo.py:276
-        mark("normalize_ms")
-        if return_keypoints:
-            kps = {"kp_source": kp_source, "kp_driving_raw": raw, "kp_driving_smoothed": kp_d, "kp_norm": kp_norm}
-    else:
-        src = None
     if backend is None:
         backend = EngineBackend(generator, batch=batch)
-    if size is None:
-        if source_image is None:
-            raise ValueError("a rank without the source image must be given the frame size (H, W)")
-        size = (int(source_image.shape[-2]), int(source_image.shape[-1]))
-    H, W = size
+    if distributed:
+        # every rank gets the clip's INPUTS (source image, LSTM features, emotion displacements: 2.9 MB for 2048 frames at
+        # 256x256) in two broadcasts -- fixed header + one payload -- and runs the front end on ITS frames; one all-gather of the
+        # raw key points (T x 60 floats) later every rank holds the whole sequence, smooths and normalises it (0.2 ms, redundant)
+        # and animates its shard.  Three collectives per clip; nothing of the front end's 23 us per frame stays serial.
+        source_image, lstm_features, emo_driving = _broadcast_inputs(source_image, lstm_features, emo_driving, dev, group)
+        mark("broadcast_ms")
+    src = source_image.to(dev)
+    if lstm_features.dim() == 3 and lstm_features.shape[0] == 1:
+        lstm_features = lstm_features[0]
+    T = lstm_features.shape[0]
+    kp_source = _kp_only(kp_detector(src))                                                   # demo.py:206
+    a, b = shard_bounds(T, world, rank)
+    raw = driving_keypoints(deconv_tail, kp_detector_a, lstm_features[a:b].to(dev), batch=front_batch) if b > a else None   # demo.py:212-219
+    if distributed:
+        raw = _all_gather_keypoints(raw, T, kp_source["value"].shape[1], dev, group)
+    kp_initial = {k: v[:1].clone() for k, v in raw.items()}                                  # demo.py:207 (never smoothed)
+    mark("front_ms")
+    kp_d = smooth_keypoints(raw, **KP_FILTER) if smooth else raw                             # demo.py:241-250
+    if emo_driving is not None:
+        emo = {k: v.to(dev) for k, v in _kp_only(emo_driving).items()}
+        emo = smooth_keypoints(emo, **EMO_FILTER) if smooth else emo                         # demo.py:231-239
+        kp_d = apply_emotion_offsets(kp_d, emo)                                              # demo.py:263-271
+    mark("smooth_ms")
+    kp_norm = normalize_kp(kp_source, kp_d, kp_initial, adapt_movement_scale=adapt_movement_scale,
+                           use_relative_movement=relative, use_relative_jacobian=relative)    # demo.py:276
+    mark("normalize_ms")
+    kps = {"kp_source": kp_source, "kp_driving_raw": raw, "kp_driving_smoothed": kp_d, "kp_norm": kp_norm} if return_keypoints else {}
+    H, W = (int(src.shape[-2]), int(src.shape[-1])) if size is None else size
     frames, span = animate_clip(backend, src, kp_source, kp_norm, H, W, uint8=uint8, group=group, to_host=to_host,
-                                timings=timings)
+                                timings=timings, replicated=distributed)
     return (frames, span, kps) if return_keypoints else (frames, span)
+
+
+_IN_HEADER = 8   # T, feature channels, emotion points E (0: none), image channels, H, W, features given as [1,T,C], reserved
+
+
+def _broadcast_inputs(source_image, lstm_features, emo_driving, dev, group):
+    """Rank 0's clip inputs to every rank: a fixed eight-integer header, then ONE float32 payload
+    source | features | emo value | emo jacobian."""
+    rank = dist.get_rank(group)
+    staged = _staged(group, dev)
+    hdev = torch.device("cpu") if staged else dev
+    if rank == 0:
+        feats = lstm_features[0] if (lstm_features.dim() == 3 and lstm_features.shape[0] == 1) else lstm_features
+        E = 0 if emo_driving is None else int(emo_driving["value"].shape[1])
+        head = torch.tensor([feats.shape[0], feats.shape[1], E, source_image.shape[1], source_image.shape[2], source_image.shape[3], 0, 0],
+                            dtype=torch.int64, device=hdev)
+    else:
+        head = torch.zeros(_IN_HEADER, dtype=torch.int64, device=hdev)
+    dist.broadcast(head, src=0, group=group)
+    T, C, E, ch, H, W, _, _ = (int(v) for v in head.tolist())
+    sizes = [ch * H * W, T * C, T * E * 2, T * E * 4]
+    if rank == 0:
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).reshape(-1)
+        parts = [f32(source_image), f32(feats)]
+        if E:
+            parts += [f32(emo_driving["value"]), f32(emo_driving["jacobian"])]
+        payload = torch.cat(parts)
+    else:
+        payload = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    _broadcast(payload, 0, group, staged)
+    s_img, s_feat, s_ev, s_ej = torch.split(payload, sizes)
+    emo = {"value": s_ev.view(T, E, 2), "jacobian": s_ej.view(T, E, 2, 2)} if E else None
+    return s_img.view(1, ch, H, W), s_feat.view(T, C), emo
+
+
+def _all_gather_keypoints(local, T: int, K: int, dev, group):
+    """Every rank's raw key points of its contiguous frame shard -> the whole clip's on every rank: ONE all-gather of
+    [longest shard, K * 6] floats per rank (shards padded to the longest, trimmed after)."""
+    world, staged = dist.get_world_size(group), _staged(group, dev)
+    longest = shard_bounds(T, world, 0)[1]
+    cdev = torch.device("cpu") if staged else dev
+    mine = torch.zeros(longest, K * 6, dtype=torch.float32, device=cdev)
+    if local is not None:
+        n = local["value"].shape[0]
+        mine[:n, :K * 2] = local["value"].reshape(n, -1).to(cdev)
+        mine[:n, K * 2:] = local["jacobian"].reshape(n, -1).to(cdev)
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine, group=group)
+    rows = torch.cat([bufs[r][: shard_bounds(T, world, r)[1] - shard_bounds(T, world, r)[0]] for r in range(world)]).to(dev)
+    return {"value": rows[:, :K * 2].reshape(T, K, 2).contiguous(), "jacobian": rows[:, K * 2:].reshape(T, K, 2, 2).contiguous()}

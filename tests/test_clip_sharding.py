@@ -141,6 +141,73 @@ def test_two_rank_clip_equals_single_process(tmp_path, total):
     assert np.abs(u8.astype(int) - want.astype(int)).max() <= 1
 
 
+def _chain_parts():
+    """Oracle-backed stand-ins for the three front-end modules of make_animation_smooth (tiny shapes) + the clip backend."""
+    from eamm_amd.config import tiny_kp_config
+    from eamm_amd.weights import deconv_state_dict_spec, synthetic_lstm_features, trained_like_kp_state_dict
+    cfg = tiny_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    ck, ca = tiny_kp_config(), tiny_kp_config(audio=True)
+    sd_k, sd_a = trained_like_kp_state_dict(ck, 78), trained_like_kp_state_dict(ca, 77)
+    ch = (64, 32, 32, 35)                                   # 1x1 -> 4x4 -> 8x8 -> 16x16 feature maps of 32 + 3 channels
+    sd_d = synthetic_state_dict(None, seed=3, spec=deconv_state_dict_spec(ch))
+    with torch.no_grad():
+        kp = lambda x: orc.kp_detector_forward(sd_k, ck, x)
+        tail = lambda x: orc.deconv_tail(sd_d, x)
+        kpa = lambda f: orc.kp_detector_a_forward(sd_a, ca, f)
+    return cfg, sd, kp, tail, kpa, synthetic_source(64, seed=1), synthetic_lstm_features(7, channels=64, seed=5)
+
+
+def _chain_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from eamm_amd import animate_from_features
+    cfg, sd, kp, tail, kpa, src, feats = _chain_parts()
+    be = OracleBackend(cfg, sd, 2, 64)
+    emo = {"value": 0.02 * torch.ones(7, 3, 2), "jacobian": 0.01 * torch.ones(7, 3, 2, 2)}
+    args = (src, feats, emo) if rank == 0 else (None, None, None)     # only rank 0 holds the clip's inputs
+    with CountedCollectives() as cc:
+        frames, (a, b), kps = animate_from_features(None, kp, tail, kpa, args[0], args[1], emo_driving=args[2], backend=be, uint8=False,
+                                                    to_host=True, front_batch=2, return_keypoints=True)
+    # inputs: header + payload; key points: one all-gather; the generator's frames: no collective at all
+    assert cc.counts == {"broadcast": 2, "all_gather": 1}, cc.counts
+    assert (a, b) == shard_bounds(7, world, rank) and frames.shape[0] == b - a
+    np.save(os.path.join(tmp, f"chain{rank}.npy"), frames.numpy())
+    np.save(os.path.join(tmp, f"kpnorm{rank}.npy"), kps["kp_norm"]["value"].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_end_to_end_chain_shards_the_front_end_too(tmp_path):
+    """animate_from_features under a process group: both of the reference's loops shard by frames (demo.py:212-228 and :251-281);
+    three collectives per clip; the result equals the single-process run."""
+    from eamm_amd import animate_from_features
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_chain_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    cfg, sd, kp, tail, kpa, src, feats = _chain_parts()
+    emo = {"value": 0.02 * torch.ones(7, 3, 2), "jacobian": 0.01 * torch.ones(7, 3, 2, 2)}
+    ref, span, kps = animate_from_features(None, kp, tail, kpa, src, feats, emo_driving=emo, backend=OracleBackend(cfg, sd, 2, 64),
+                                           uint8=False, to_host=True, front_batch=3, return_keypoints=True)
+    assert span == (0, 7) and ref.shape == (7, 3, 64, 64)
+    got = np.concatenate([np.load(tmp_path / f"chain{r}.npy") for r in range(world)])
+    for r in range(world):     # every rank ended up with the whole clip's normalised key points
+        assert np.abs(np.load(tmp_path / f"kpnorm{r}.npy") - kps["kp_norm"]["value"].numpy()).max() <= 1e-6
+    assert np.abs(got - ref.numpy()).max() <= 1e-5
+    # and the chain is the oracle's own (reference statements frame by frame), here on the host filter
+    from eamm_amd.config import tiny_kp_config
+    from eamm_amd.weights import deconv_state_dict_spec, trained_like_kp_state_dict
+    ck, ca = tiny_kp_config(), tiny_kp_config(audio=True)
+    _, norm, _, _ = orc.animation_keypoints(trained_like_kp_state_dict(ck, 78), ck,
+                                            synthetic_state_dict(None, seed=3, spec=deconv_state_dict_spec((64, 32, 32, 35))),
+                                            trained_like_kp_state_dict(ca, 77), ca, src, feats, emo_driving=emo)
+    want = torch.cat([n["value"] for n in norm])
+    assert float((kps["kp_norm"]["value"] - want).abs().max()) <= 2e-5
+
+
 def test_bare_bench_gpus_n_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE in the environment (the command shape the driver uses)
     must become the launcher: two ranks of bench.py under torch.distributed.run that find each other on 127.0.0.1.
