@@ -180,11 +180,13 @@ def train_step_leg(cfg, sd, size, pairs, steps=4):
     kp_s = {k: v.to(dev) for k, v in synthetic_keypoints(pairs, cfg["num_kp"], seed=0).items()}
     kp_d = {k: v.to(dev).requires_grad_() for k, v in synthetic_keypoints(pairs, cfg["num_kp"], seed=2).items()}
     target = train_step_target(pairs, size).to(dev)
-    fwd, bwd = [], []
+    from eamm_amd import _lib as _L
+    fwd, bwd, gflop = [], [], []
     for it in range(steps + 1):
         for p in list(gen.parameters()) + list(kp_d.values()):
             p.grad = None
         torch.cuda.synchronize()
+        f0 = _L.lib().eamm_total_mfma_flops()
         t0 = time.perf_counter()
         loss = (gen(src, kp_driving=kp_d, kp_source=kp_s)["prediction"] - target).abs().mean()
         torch.cuda.synchronize()
@@ -195,6 +197,7 @@ def train_step_leg(cfg, sd, size, pairs, steps=4):
         if it:
             fwd.append((t1 - t0) * 1e3)
             bwd.append((t2 - t1) * 1e3)
+            gflop.append((_L.lib().eamm_total_mfma_flops() - f0) * 1e-9)
     best = min(f + b for f, b in zip(fwd, bwd))
     finite = all(bool(torch.isfinite(p.grad).all()) for p in gen.parameters())
     # deterministic inputs (seeds above): the loss and three gradient checksums of the last step, checked against the oracle's
@@ -207,6 +210,10 @@ def train_step_leg(cfg, sd, size, pairs, steps=4):
     torch.cuda.empty_cache()
     return {"pairs": pairs, "size": size, "step_ms": round(best, 3), "forward_ms": round(min(fwd), 3), "backward_ms": round(min(bwd), 3),
             "pairs_per_s": round(pairs / best * 1e3, 1), "gradients_finite": finite, "checks": checks,
+            "roofline": {"bound": "mfma", "executed_gflop_per_step": round(gflop[-1], 1), "achieved": round(gflop[-1] / best, 2),
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gflop[-1] / best / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "note": "executed matrix-core GFLOP of one step (forward + backward, library-side count of what every launched "
+                                 "grid issues, all host threads) / step time / chip fp32 matrix peak"},
             "note": "generator .train() forward with autograd graph + loss.backward() (L1 to a random target), HIP operators of "
                     "eamm_amd/train_graph.py; batch-statistics BatchNorm; not part of `value`"}
 

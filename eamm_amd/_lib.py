@@ -85,6 +85,7 @@ SIGNATURES = {
     "eamm_describe_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "eamm_knobs_json": (C.c_int, [C.c_char_p, C.c_int]),
     "eamm_build_experiments": (C.c_int, []),
+    "eamm_total_mfma_flops": (C.c_double, []),
     "eamm_kp_create": (C.c_int, [C.POINTER(EammKpConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "eamm_kp_destroy": (None, [C.c_void_p]),
     "eamm_kp_last_error": (C.c_char_p, [C.c_void_p]),

@@ -530,6 +530,7 @@ hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int 
         a.per_split = ((Mq + splits - 1) / splits + 63) / 64 * 64;
         a.splits = (int)((Mq + a.per_split - 1) / a.per_split);
         a.partial = partial;
+        note_mfma_flops(2.0 * 36.0 * (double)Mq * (a.mt * 64.0) * (a.nt * 64.0));      // 36 transform-point GEMMs over the tiles
         hipLaunchKernelGGL(conv_wgrad_kernel<32>, dim3((unsigned)(tiles * a.splits)), dim3(256), 0, s, a);
         const size_t pairs = (size_t)Cout * Cin;
         hipLaunchKernelGGL(wino4_wgrad_output_kernel, dim3((unsigned)std::min<size_t>((pairs + 255) / 256, 65535)), dim3(256), 0, s, partial,
@@ -545,6 +546,7 @@ hipError_t conv_wgrad_launch(const float* x, const float* dy, int B, int H, int 
         a.splits = (int)((a.P + a.per_split - 1) / a.per_split);
         a.partial = workspace;
         const dim3 grid((unsigned)(tiles * a.splits));
+        note_mfma_flops(2.0 * taps * (double)a.P * (a.mt * 64.0) * (a.nt * 64.0));            // one GEMM over the pixels per tap
         if (row && kw == 1) hipLaunchKernelGGL(conv_wgrad_row_kernel<1>, grid, dim3(256), 0, s, a);
         else if (row && kw == 3) hipLaunchKernelGGL(conv_wgrad_row_kernel<3>, grid, dim3(256), 0, s, a);
         else if (row) hipLaunchKernelGGL(conv_wgrad_row_kernel<7>, grid, dim3(256), 0, s, a);

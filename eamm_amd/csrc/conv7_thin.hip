@@ -216,6 +216,7 @@ hipError_t conv7_thin_in_launch(const float* thin, const float* w, const float* 
     hipLaunchKernelGGL(conv7_thin_pack_kernel, dim3((T7_K * N + 255) / 256), dim3(256), 0, s, w, N, transposed, workspace);
     const size_t lds = sizeof(float) * ((size_t)T7_K * (N + 4) + T7_PH * T7_PW * 4);
     const int blocks = std::min(a.nstrips, 2048);
+    note_mfma_flops(2.0 * T7_K * (double)N * B * H * W);        // K = (tap, channel) = 196 per output pixel and wide channel
     hipError_t e;
     if (N == 64) {
         static lds_once_mask configured{0};
@@ -244,6 +245,7 @@ hipError_t conv7_thin_wgrad_launch(const float* thin, const float* wide, int B, 
     a.nstrips = B * a.strips_x * a.strips_y;
     const int blocks = thin7_blocks(a.nstrips);
     const size_t lds = sizeof(float) * ((size_t)64 * (N + 4) + T7_PH * T7_PW * 4);
+    note_mfma_flops(2.0 * T7_K * (double)N * B * H * W);
     if (N == 64) hipLaunchKernelGGL(conv7_thin_wgrad_kernel<2>, dim3(blocks), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(conv7_thin_wgrad_kernel<1>, dim3(blocks), dim3(256), lds, s, a);
     hipLaunchKernelGGL(conv7_thin_wgrad_reduce_kernel, dim3((N * 147 + 255) / 256), dim3(256), 0, s, workspace, blocks, N, thin_is_input, dw);

@@ -363,8 +363,18 @@ static hipError_t launch_tile(int BN, const ConvArgs& a, int blocks, hipStream_t
 
 namespace {
 thread_local double g_mfma_flops = 0.0;
+std::mutex g_mfma_total_mu;
+double g_mfma_total = 0.0;        // process-wide, monotonic (autograd runs backward launches on its own thread)
 }
-void note_mfma_flops(double flops) { g_mfma_flops += flops; }
+void note_mfma_flops(double flops) {
+    g_mfma_flops += flops;
+    std::lock_guard<std::mutex> lock(g_mfma_total_mu);
+    g_mfma_total += flops;
+}
+double total_mfma_flops() {
+    std::lock_guard<std::mutex> lock(g_mfma_total_mu);
+    return g_mfma_total;
+}
 double take_mfma_flops() {
     const double v = g_mfma_flops;
     g_mfma_flops = 0.0;

@@ -1501,6 +1501,7 @@ int eamm_build_experiments(void) {
 #endif
 }
 int eamm_knobs_json(char* buf, int cap) { return knobs_json(buf, cap); }
+double eamm_total_mfma_flops(void) { return total_mfma_flops(); }
 int eamm_describe_plan(const eamm_ctx* c, int n, char* buf, int cap) {
     if (!c || n <= 0 || n > c->cfg.max_frames || !c->finalized) return EAMM_ERR_ARG;
     const int pc = pass_chains(c, n), nk = pc > 1 ? n / pc : n;

@@ -17,6 +17,7 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
 // per-host-thread counter; eamm_forward_frames folds it into the profile totals while profiling is on.
 void note_mfma_flops(double flops);
 double take_mfma_flops();   // returns the counter and resets it
+double total_mfma_flops();  // process-wide monotonic total (all host threads)
 
 // Tuning knobs: every EAMM_* environment variable the library reads goes through knob_int(), which records the name, the value
 // in effect and whether the environment set it -- eamm_knobs_json() reports the table, so a benchmark line can carry the

@@ -167,6 +167,11 @@ int eamm_describe_plan(const eamm_ctx* ctx, int n, char* buf, int cap);
  * EAMM_WINO4_EPI_V, EAMM_COL7_DBG, EAMM_WINO4_VARIANT 10/16/17/50) exist only in a build with -DEAMM_EXPERIMENTS
  * (make EXPERIMENTS=1); the product library's eamm_create fails when one of them is set. */
 int eamm_knobs_json(char* buf, int cap);
+/* Executed matrix-core flops (what the launched grids really issue: padded tiles, Winograd / polyphase point counts -- not the
+ * reference convolution's) of every kernel enqueued through the library in this PROCESS so far, all host threads (autograd runs
+ * the backward operators on its own thread): a monotonic total; difference two readings around a step (bench.py
+ * `train_step.roofline`).  eamm_forward_frames keeps its own per-call count for the profile keys. */
+double eamm_total_mfma_flops(void);
 /* 1 when this library was built with -DEAMM_EXPERIMENTS (never benchmark or ship such a build), else 0. */
 int eamm_build_experiments(void);
 
