@@ -110,7 +110,8 @@ def knob_record(eng, frames, extra_plans=None):
     from eamm_amd import _lib
     from eamm_amd.engine import library_knobs
     rec = {"env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("EAMM_") and not k.startswith("EAMM_BENCH_")},
-           "library": {k: v["value"] for k, v in library_knobs().items() if v["set"]},
+           "library": {k: v["value"] for k, v in library_knobs().items() if v["set"] == 1},
+           "ignored": sorted(k for k, v in library_knobs().items() if v["set"] == 2),   # tuning aids present without EAMM_TUNING=1
            "library_defaults_read": len(library_knobs()),
            "experiments_build": int(_lib.lib().eamm_build_experiments()),
            "plan": eng.describe_plan(frames)}

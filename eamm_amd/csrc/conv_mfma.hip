@@ -383,15 +383,32 @@ double take_mfma_flops() {
 
 namespace {
 std::mutex g_knob_mu;
-std::map<std::string, std::pair<long long, bool>> g_knobs;
+std::map<std::string, std::pair<long long, int>> g_knobs;   // value in effect; 0 default, 1 set, 2 set but ignored
+}
+// The DOCUMENTED knobs (include/eamm_hip.h): selectors of a computation form or of the launch plan; every setting computes the
+// same frames up to rounding.  Everything else the sources read through knob_int() is a TUNING aid (tile thresholds, pipeline
+// variants, split sizes): honoured only when EAMM_TUNING=1 is set as well, so that a stray variable in a deployment's environment
+// cannot change the plan silently; such a variable is recorded with "set": 2 (present, ignored).
+static bool knob_documented(const char* name) {
+    static const char* const names[] = {"EAMM_PASS_CHAINS", "EAMM_BNECK_CHAINS", "EAMM_WINO_TILE", "EAMM_WINO_MIN_M", "EAMM_WINO4_MIN_M",
+                                        "EAMM_ENC_WINO", "EAMM_FINAL_FUSED", "EAMM_FINAL_MFMA4", "EAMM_COL7", "EAMM_FIRST7",
+                                        "EAMM_PRIVATE_STREAMS", "EAMM_WARP_JOINT", "EAMM_BNECK_STAGGER", "EAMM_HEAD_ROWSPLIT",
+                                        "EAMM_PATCH_POLY", "EAMM_WGRAD_WINO4", "EAMM_WGRAD_ROW", "EAMM_CONV_DEV_WINO4",
+                                        "EAMM_WINO4_EPI_V", "EAMM_COL7_DBG", "EAMM_WINO4_VARIANT"};   // (the last three: refused / experiments build)
+    for (const char* n : names)
+        if (!strcmp(n, name)) return true;
+    return false;
 }
 long long knob_int(const char* name, long long dflt) {
     const char* v = getenv(name);
-    const long long val = v ? atoll(v) : dflt;
+    static const bool tuning = [] { const char* t = getenv("EAMM_TUNING"); return t && atoi(t) != 0; }();
+    const bool honoured = v != nullptr && (tuning || knob_documented(name));
+    const long long val = honoured ? atoll(v) : dflt;
     std::lock_guard<std::mutex> lock(g_knob_mu);
     auto it = g_knobs.find(name);
-    if (it == g_knobs.end()) g_knobs.emplace(name, std::make_pair(val, v != nullptr));
-    else if (v != nullptr) it->second = std::make_pair(val, true);   // (a per-handle default may differ between handles: the set value wins)
+    const int state = v == nullptr ? 0 : (honoured ? 1 : 2);
+    if (it == g_knobs.end()) g_knobs.emplace(name, std::make_pair(val, state));
+    else if (state) it->second = std::make_pair(val, state);   // (a per-handle default may differ between handles: the set value wins)
     return val;
 }
 int knobs_json(char* buf, int cap) {
@@ -402,7 +419,7 @@ int knobs_json(char* buf, int cap) {
         for (const auto& kv : g_knobs) {
             if (!first) out += ", ";
             first = false;
-            out += "\"" + kv.first + "\": {\"value\": " + std::to_string(kv.second.first) + ", \"set\": " + (kv.second.second ? "1" : "0") + "}";
+            out += "\"" + kv.first + "\": {\"value\": " + std::to_string(kv.second.first) + ", \"set\": " + std::to_string(kv.second.second) + "}";
         }
     }
     out += "}";

@@ -143,112 +143,6 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
     }
 }
 
-// Streaming form of the input transform (round 5): PERSISTENT threads walk the (tile, channel group) items with a grid stride and
-// keep the loads of item n + 1 in flight while item n is transformed and stored (two register images of VEC = 2 channels = the
-// 144 data registers the one-shot VEC = 4 form holds).  The one-shot form runs as bulk rounds -- every wave of a round loads, then
-// every wave computes and stores; at 8 frames the 128 CUs a chain has take two such rounds (the register file of 128 CUs holds
-// about one launch's patches) -- so the memory system idles while the waves compute and the SIMDs idle while they wait.  Same
-// arithmetic, same order: bit-identical V.
-template <int VEC>
-__device__ __forceinline__ void wino4_item_geometry(unsigned idx, unsigned cvn, unsigned Hq, unsigned Wq, int H, int W, unsigned* cv,
-                                                    unsigned* q, unsigned* b, int yo[6], int xo[6], unsigned* okmask) {
-    *cv = idx % cvn;
-    *q = idx / cvn;
-    const int qx = (int)(*q % Wq);
-    const unsigned r = *q / Wq;
-    const int qy = (int)(r % Hq);
-    *b = r / Hq;
-    unsigned m = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int yy = 4 * qy - 1 + i, xx = 4 * qx - 1 + i;
-        m |= ((unsigned)yy < (unsigned)H ? 1u : 0u) << i;
-        m |= ((unsigned)xx < (unsigned)W ? 1u : 0u) << (8 + i);
-        yo[i] = min(max(yy, 0), H - 1) * W;
-        xo[i] = min(max(xx, 0), W - 1);
-    }
-    *okmask = m;
-}
-
-// (launcher: total items < 2^31; every index below is 32-bit -- a 64-bit division costs a branchy slow path per item)
-template <int VEC>
-__global__ __launch_bounds__(256) void wino4_input_transform_stream_kernel(const float* __restrict__ x, const float* __restrict__ s,
-                                                                           const float* __restrict__ t, int B, int H, int W, int C,
-                                                                           float* __restrict__ V) {
-    typedef typename vec_of<VEC>::type T;
-    const unsigned cvn = C / VEC;
-    const unsigned Hq = H >> 2, Wq = W >> 2;
-    const unsigned Mq = (unsigned)B * Hq * Wq;
-    const unsigned total = Mq * cvn, stride = gridDim.x * blockDim.x;
-    const size_t plane = (size_t)Mq * cvn;
-    unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const bool act = s != nullptr;      // (wave-uniform)
-    T a[6][6], n[6][6];
-    unsigned cv, b, q, ok;
-    int yo[6], xo[6];
-    wino4_item_geometry<VEC>(idx, cvn, Hq, Wq, H, W, &cv, &q, &b, yo, xo, &ok);
-    // the item's pre-activation scale / shift travel WITH its patch (loaded before it): a load issued after the next item's
-    // patch loads would be the youngest outstanding one, and waiting for it waits for everything
-    T sc = T(1.f), sh = T(0.f);
-    if (act) {
-        sc = reinterpret_cast<const T*>(s)[cv];
-        sh = reinterpret_cast<const T*>(t)[cv];
-    }
-    {
-        const T* img = reinterpret_cast<const T*>(x) + (size_t)b * H * W * cvn + cv;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) a[i][j] = img[(size_t)(yo[i] + xo[j]) * cvn];
-    }
-    // one step: issue the loads of the NEXT item into `nx` -- unconditionally: past the end the last item is loaded again and
-    // dropped, so that no branch separates these loads from the stores below (a merge point makes the compiler wait for ALL
-    // outstanding loads) -- then transform and store the item held in `cu`
-    auto step = [&](T (&cu)[6][6], T (&nx)[6][6]) {
-        const unsigned cv0 = cv, q0 = q, ok0 = ok;
-        const unsigned nidx = idx + stride;
-        const bool more = nidx < total;
-        const T sc0 = sc, sh0 = sh;
-        wino4_item_geometry<VEC>(more ? nidx : total - 1, cvn, Hq, Wq, H, W, &cv, &q, &b, yo, xo, &ok);
-        if (act) {
-            sc = reinterpret_cast<const T*>(s)[cv];
-            sh = reinterpret_cast<const T*>(t)[cv];
-        }
-        {
-            const T* img = reinterpret_cast<const T*>(x) + (size_t)b * H * W * cvn + cv;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) nx[i][j] = img[(size_t)(yo[i] + xo[j]) * cvn];
-        }
-        __builtin_amdgcn_sched_barrier(0);   // the next item's loads are issued BEFORE the first wait on this item's data
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                T v = cu[i][j];
-                if (act) v = vrelu_affine(v, sc0, sh0);
-                cu[i][j] = (((ok0 >> i) & 1u) && ((ok0 >> (8 + j)) & 1u)) ? v : T(0.f);
-            }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) bt6(cu[0][j], cu[1][j], cu[2][j], cu[3][j], cu[4][j], cu[5][j]);
-        T* out = reinterpret_cast<T*>(V) + (size_t)q0 * cvn + cv0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            bt6(cu[i][0], cu[i][1], cu[i][2], cu[i][3], cu[i][4], cu[i][5]);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) out[(size_t)(i * 6 + j) * plane] = cu[i][j];
-        }
-        idx = nidx;
-        return more;
-    };
-    for (;;) {
-        if (!step(a, n)) break;
-        if (!step(n, a)) break;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // GEMM over the 36 transform points + in-register output transform
 // ---------------------------------------------------------------------------------------------------------
@@ -707,24 +601,12 @@ hipError_t wino4_transform_launch(const float* x, const float* s, const float* t
         const int v = (int)knob_int("EAMM_WINO4_TR_VEC", 0);
         return (v == 1 || v == 2 || v == 4) ? v : 0;
     }();
+    // (round 5: a PERSISTENT double-buffered form -- two register images of two channels, the next item's loads in flight while
+    //  this one is transformed and stored -- was built, bit-identical, and measured 0 - 10 % SLOWER per launch in the pipeline
+    //  at every grid size: profiles/r05_experiments.txt section 3, git 9500c6c)
     // one 256x256 frame is 64 workgroups of four-channel threads on 256 CUs: one channel per thread fills the chip and shortens
     // each thread's 36-load / 36-store chain (12.0 -> 10.6 us per launch, one-frame call 1.069 -> 1.052 ms)
     const int vec = vec_env ? vec_env : ((size_t)B * (H / 4) * (W / 4) * (C / 4) <= 64 * 256 ? 1 : 4);
-    // EAMM_WINO4_TR_STREAM = N > 0: the persistent double-buffered form (VEC = 2) on N workgroups per CU for launches of at
-    // least four items per thread-slot; 0 = the one-shot form
-    static const int stream_wgs = (int)knob_int("EAMM_WINO4_TR_STREAM", 0);
-    if (stream_wgs > 0 && !vec_env && (C & 1) == 0) {
-        const size_t items = (size_t)B * (H / 4) * (W / 4) * (C / 2);
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        static const int cu_pct = (int)knob_int("EAMM_WINO4_TR_STREAM_CU_PCT", 50);   // a chain has about half the chip
-        const size_t slots = (size_t)std::max(1, cus * cu_pct / 100) * stream_wgs * 256;
-        if (items >= 2 * slots && items < (1ull << 31)) {
-            hipLaunchKernelGGL(wino4_input_transform_stream_kernel<2>, dim3((unsigned)(slots / 256)), dim3(256), 0, stream, x, s, t, B, H, W, C, V);
-            return hipGetLastError();
-        }
-    }
     const size_t total = (size_t)B * (H / 4) * (W / 4) * (C / vec);
     const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)1 << 20);
     if (vec == 1)

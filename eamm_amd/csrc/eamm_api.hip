@@ -308,7 +308,6 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->pass_chains = c->pass_chains < 0 ? 1 : std::min(c->pass_chains, 4);
     c->bneck_chains = std::max(1, std::min(c->bneck_chains, 16));
     c->bneck_stagger = env_int("EAMM_BNECK_STAGGER", c->bneck_stagger);
-    c->bneck_sub = std::max(1, std::min(env_int("EAMM_BNECK_SUB", c->bneck_sub), (int)eamm_ctx::MAXSUB));
     c->warp_joint = env_int("EAMM_WARP_JOINT", c->warp_joint);
     c->enc_cus_pct = std::max(1, env_int("EAMM_ENC_CUS_PCT", c->enc_cus_pct));
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
@@ -352,8 +351,6 @@ void eamm_destroy(eamm_ctx* c) {
     if (c->ev_stagger) (void)hipEventDestroy(c->ev_stagger);
     if (c->ev_warp) (void)hipEventDestroy(c->ev_warp);
     for (auto& e : c->ev_join) (void)hipEventDestroy(e);
-    for (auto& e : c->sub_fork) (void)hipEventDestroy(e);
-    for (auto& e : c->sub_join) (void)hipEventDestroy(e);
     for (auto& st : c->own_streams) (void)hipStreamDestroy(st);   // (drains the stream's work first; the pool's streams stay)
     delete c;
 }
@@ -663,20 +660,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
         if (c->nb > 0) ff += 9.0 * hwf * c->Cb_r;  // bilinear feature warp + occlusion multiply
         c->flops_frame = ff;
     }
-    int max_chains = std::max(c->bneck_chains, c->pass_chains == 0 ? (g.max_frames >= 64 ? 4 : 2) : c->pass_chains);
-    if (c->bneck_sub > 1) {   // two whole-pass chains, each with its bottleneck split: 1 + 2 (sub - 1) side streams
-        max_chains = std::max(max_chains, 2 + 2 * (c->bneck_sub - 1));
-        for (int k = 0; k < 4; ++k) {
-            hipEvent_t ev = nullptr;
-            HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            c->sub_fork.push_back(ev);
-        }
-        for (int k = 0; k < 4 * (eamm_ctx::MAXSUB - 1); ++k) {
-            hipEvent_t ev = nullptr;
-            HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            c->sub_join.push_back(ev);
-        }
-    }
+    const int max_chains = std::max(c->bneck_chains, c->pass_chains == 0 ? (g.max_frames >= 64 ? 4 : 2) : c->pass_chains);
     c->private_streams = env_int("EAMM_PRIVATE_STREAMS", 0);
     if (max_chains > 1) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -801,24 +785,6 @@ static int bottleneck_chains(const eamm_ctx* c, int n) {
     const int tiles_pf = (c->hf / 4) * (c->wf / 4);
     while (chains > 1 && (n < chains || ((n / chains) * tiles_pf) % 64 != 0 || ((n / chains + 1) * tiles_pf) % 64 != 0)) --chains;
     return chains;
-}
-
-// Sub-chains of ONE whole-pass chain's bottleneck (EAMM_BNECK_SUB; 1 = off).  Only while the chain's own GEMM cannot fill the
-// chip (<= half the CUs: the other whole-pass chain holds the other half) and with whole 64-tile blocks per sub-chain.
-static int bottleneck_subchains(const eamm_ctx* c, int n, int P) {
-    const int sub = c->bneck_sub;
-    if (sub < 2 || sub > eamm_ctx::MAXSUB || P < 2 || n < sub || c->sub_fork.empty()) return 1;
-    if ((P - 1) + P * (sub - 1) > (int)c->side_streams.size()) return 1;
-    const int tiles_pf = (c->hf / 4) * (c->wf / 4);
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    if (((n * tiles_pf + 63) / 64) * ((c->Cb + 63) / 64) > cus / 2) return 1;
-    for (int k = 0; k < 2; ++k) {
-        const int nk = n / sub + k;
-        if (k == 1 && n % sub == 0) break;
-        if ((nk * tiles_pf) % 64 != 0) return 1;
-    }
-    return sub;
 }
 
 // The slice of the per-frame workspace one launch sequence works on: frames [f0, f0 + n) of a call (every per-frame
@@ -1072,16 +1038,13 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
     } while (0)
     const bool wino4 = form == 4;
     const int w4g = (wino4 && !chained) ? wino4_groups(c, n) : 1;   // a chained view shares the chip: never split the point rows
-    // a whole-pass chain may split ITS bottleneck once more (bottleneck_subchains): sub-chains of fewer frames have shorter input
-    // transforms, and the CUs of a sub-chain that is in its transform phase are the only ones the matrix pipes lose
-    const int nsubc = (chained && wino4) ? bottleneck_subchains(c, n, c->cur_pass_chains) : 1;
-    const int chains = chained ? nsubc : bottleneck_chains(c, n);
-    // streams / events of the split: the call's own (un-chained call) or this whole-pass chain's private set
-    auto split_stream = [&](int k) {
-        return !chained ? c->side_streams[k - 1] : c->side_streams[(c->cur_pass_chains - 1) + chain_idx * (nsubc - 1) + (k - 1)];
-    };
-    hipEvent_t split_fork = chained ? c->sub_fork[chain_idx] : c->ev_fork;
-    auto split_join = [&](int k) { return chained ? c->sub_join[chain_idx * (eamm_ctx::MAXSUB - 1) + (k - 1)] : c->ev_join[k - 1]; };
+    // (round 5: splitting a whole-pass chain's bottleneck once more -- 2 x 2 sub-chains of 4 frames -- was built and measured
+    //  neutral, 3917 vs 3958 frames/s: the input transform is latency-bound and does not shrink with the frames per launch;
+    //  profiles/r05_experiments.txt section 2, git 9500c6c)
+    const int chains = chained ? 1 : bottleneck_chains(c, n);
+    auto split_stream = [&](int k) { return c->side_streams[k - 1]; };
+    hipEvent_t split_fork = c->ev_fork;
+    auto split_join = [&](int k) { return c->ev_join[k - 1]; };
     if (chains > 1) {
         const size_t per_frame = (size_t)hf * wf * c->Cb;
         const int nbase = n / chains, nrem = n % chains;   // the first nrem chains take one more frame
@@ -1520,10 +1483,9 @@ int eamm_describe_plan(const eamm_ctx* c, int n, char* buf, int cap) {
     const int len = snprintf(tmp, sizeof tmp,
                              "{\"frames\": %d, \"pass_chains\": %d, \"frames_per_chain\": %d, \"bottleneck_form\": %d, \"bottleneck_chains\": %d, "
                              "\"wino4_groups\": %d, \"wino4_variant\": %d, \"hg_encoder\": %s, \"final\": \"%s\", \"warp_joint\": %d, "
-                             "\"bneck_stagger\": %d, \"bneck_subchains\": %d, \"side_streams\": %d, \"experiments_build\": %d}",
+                             "\"bneck_stagger\": %d, \"side_streams\": %d, \"experiments_build\": %d}",
                              n, pc, nk, form, bc, (form == 4 && pc == 1 && bc == 1) ? wino4_groups(c, n) : 1, c->wino4_variant, enc.c_str(),
-                             fused ? "col7q fused" : "col7 + shift-sum", c->warp_joint, c->bneck_stagger,
-                             (pc > 1 && form == 4) ? bottleneck_subchains(c, nk, pc) : 1, (int)c->pool_streams.size(),
+                             fused ? "col7q fused" : "col7 + shift-sum", c->warp_joint, c->bneck_stagger, (int)c->pool_streams.size(),
                              eamm_build_experiments());
     if (buf && cap > 0) {
         const int m = std::min(len, cap - 1);

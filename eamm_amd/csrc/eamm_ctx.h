@@ -71,10 +71,7 @@ struct eamm_ctx : eamm::CtxBase {
     int bneck_stagger = 0;                 // EAMM_BNECK_STAGGER=1: the other whole-pass chains start their bottleneck stage behind that event, so the
                                            // chains' HBM-bound input transforms run beside the other chain's GEMM instead of beside each other
     std::vector<hipEvent_t> ev_join;
-    static constexpr int MAXSUB = 4;
-    int bneck_sub = 1;                     // EAMM_BNECK_SUB: each whole-pass chain splits ITS bottleneck into this many sub-chains of frames
     int cur_pass_chains = 1;               // whole-pass chains of the call being enqueued
-    std::vector<hipEvent_t> sub_fork, sub_join;   // per whole-pass chain: fork event, MAXSUB - 1 join events
     int wino_tile = 4;                     // preferred output tile (EAMM_WINO_TILE): 4 -> F(4x4) where it applies, 2 -> F(2x2)
     int wino4_variant = 3;                 // wino4_gemm_kernel pipeline variant (3: one DMA piece per 8 MFMAs; 2.062 -> 2.047 ms per step vs one per 4)
     float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] (F(2x2)) or [36][F*hf*wf/16][Cb] transformed activations

@@ -154,18 +154,21 @@ int eamm_last_stream_set(const eamm_ctx* ctx);
 /* The launch plan of a call of n frames as a JSON object (chains, frames per chain, bottleneck form, hourglass level forms,
  * final-layer kernel ...), written NUL-terminated into buf[cap]; returns the length needed.  For benchmark records. */
 int eamm_describe_plan(const eamm_ctx* ctx, int n, char* buf, int cap);
-/* Every EAMM_* tuning knob the library has read so far in this process, as a JSON object {"NAME": {"value": v, "set": 0|1}}
- * (value in effect; set = 1 when the environment supplied it).  Same buffer contract as eamm_describe_plan.
- * DOCUMENTED knobs (everything else is a per-round tuning aid that may disappear):
+/* Every EAMM_* knob the library has read so far in this process, as a JSON object {"NAME": {"value": v, "set": 0|1|2}}
+ * (value in effect; set = 1: the environment supplied it; 2: present in the environment but IGNORED).  Same buffer contract as
+ * eamm_describe_plan.
+ * DOCUMENTED knobs -- selectors of a computation form or of the launch plan; every setting computes the same frames up to rounding:
  *   EAMM_PASS_CHAINS / EAMM_BNECK_CHAINS   chains of a call over the whole pass / inside the bottleneck (0 = automatic, 1 = off)
- *   EAMM_WINO_TILE (4 | 2), EAMM_WINO_MIN_M (< 0: direct bottleneck)   bottleneck form
- *   EAMM_ENC_WINO (0 | 1)                   hourglass encoder levels in F(4x4) form
- *   EAMM_FINAL_FUSED, EAMM_FINAL_MFMA4      final-layer kernel
- *   EAMM_PRIVATE_STREAMS (0 | 1)            never use the shared side-stream pool
- *   EAMM_WARP_JOINT, EAMM_BNECK_STAGGER     scheduling variants measured in round 4 (off)
- * All of these compute the same frames up to rounding.  Knobs that compute WRONG results (timing experiments:
- * EAMM_WINO4_EPI_V, EAMM_COL7_DBG, EAMM_WINO4_VARIANT 10/16/17/50) exist only in a build with -DEAMM_EXPERIMENTS
- * (make EXPERIMENTS=1); the product library's eamm_create fails when one of them is set. */
+ *   EAMM_WINO_TILE (4 | 2), EAMM_WINO_MIN_M (< 0: direct), EAMM_WINO4_MIN_M    bottleneck form: F(4x4), F(2x2), direct
+ *   EAMM_ENC_WINO, EAMM_PATCH_POLY, EAMM_HEAD_ROWSPLIT, EAMM_COL7, EAMM_FIRST7, EAMM_FINAL_FUSED, EAMM_FINAL_MFMA4
+ *                                          (0 | 1) the alternative kernel of a stage: hourglass encoder, up blocks, flow head, 7x7 layers
+ *   EAMM_WGRAD_WINO4, EAMM_WGRAD_ROW, EAMM_CONV_DEV_WINO4   (0 | 1) forms of the training operators
+ *   EAMM_PRIVATE_STREAMS (0 | 1)           never use the shared side-stream pool
+ *   EAMM_WARP_JOINT, EAMM_BNECK_STAGGER    scheduling variants measured in round 4 (off)
+ * TUNING aids (tile-size thresholds, pipeline variants, split sizes: everything else the sources read) are honoured only together
+ * with EAMM_TUNING=1; without it they are ignored and reported with "set": 2.
+ * Knobs that compute WRONG results (timing experiments: EAMM_WINO4_EPI_V, EAMM_COL7_DBG, EAMM_WINO4_VARIANT 10/16/17/50) exist
+ * only in a build with -DEAMM_EXPERIMENTS (make EXPERIMENTS=1); the product library's eamm_create fails when one of them is set. */
 int eamm_knobs_json(char* buf, int cap);
 /* Executed matrix-core flops (what the launched grids really issue: padded tiles, Winograd / polyphase point counts -- not the
  * reference convolution's) of every kernel enqueued through the library in this PROCESS so far, all host threads (autograd runs

@@ -89,7 +89,7 @@ def test_bench_single_gpu_line():
     pc = d["parity_check"]
     assert pc["ok"] is True and pc["fixture"] == "tests/golden/full256_clip2.npz" and pc["frames"] == 2 and pc["max_abs_err"] <= 1e-4
     kn = d["knobs"]
-    assert kn["env"] == {} and kn["library"] == {} and kn["experiments_build"] == 0 and kn["library_defaults_read"] > 20
+    assert kn["env"] == {} and kn["library"] == {} and kn["ignored"] == [] and kn["experiments_build"] == 0 and kn["library_defaults_read"] > 20
     assert kn["plan"]["frames"] == 16 and kn["plan"]["pass_chains"] == 2 and kn["plan"]["bottleneck_form"] == 4
     assert "executed" in r["flops_basis"] and "reference-equivalent" in r["algorithmic_note"]
     # N4 leg (not part of `value`): one fine-tuning step of 8 pairs, forward with autograd graph + loss.backward()
@@ -211,6 +211,10 @@ def test_bench_refuses_a_wrong_results_knob():
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "EAMM_WINO4_EPI_V" in out.stderr and "EXPERIMENTS" in out.stderr
     d = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--clip-frames", "0", "--train-pairs", "0", "--e2e-frames", "0"],
-            env={"EAMM_PASS_CHAINS": "1"})
-    assert d["knobs"]["env"] == {"EAMM_PASS_CHAINS": "1"} and d["knobs"]["library"]["EAMM_PASS_CHAINS"] == 1
+            env={"EAMM_PASS_CHAINS": "1", "EAMM_FINAL_FUSED_MIN_ROWS": "100000"})
+    # a documented knob is honoured and recorded; a TUNING aid without EAMM_TUNING=1 is ignored (and reported as such): a stray
+    # variable cannot change the plan silently
+    assert d["knobs"]["env"] == {"EAMM_PASS_CHAINS": "1", "EAMM_FINAL_FUSED_MIN_ROWS": "100000"}
+    assert d["knobs"]["library"] == {"EAMM_PASS_CHAINS": 1} and d["knobs"]["ignored"] == ["EAMM_FINAL_FUSED_MIN_ROWS"]
     assert d["knobs"]["plan"]["pass_chains"] == 1 and d["knobs"]["plan"]["bottleneck_chains"] == 2 and d["parity_check"]["ok"] is True
+    assert d["knobs"]["plan"]["final"] == "col7q fused"

@@ -133,24 +133,6 @@ def test_three_chains_by_knob(monkeypatch):
     assert knobs["EAMM_PASS_CHAINS"] == {"value": 3, "set": 1}
 
 
-def test_bottleneck_subchains_knob(monkeypatch):
-    """EAMM_BNECK_SUB=2 (round-5 experiment, off by default: measured neutral -- the input transform does not shrink with the
-    frames per launch): each of the two whole-pass chains of a 16-frame call splits its bottleneck into two sub-chains of 4 frames
-    on two more pool streams.  Same frames as the default plan."""
-    st = state()
-    monkeypatch.setenv("EAMM_BNECK_SUB", "2")
-    _, es = fresh_engine(16)
-    plan = es.describe_plan(16)
-    assert plan["pass_chains"] == 2 and plan["bneck_subchains"] == 2 and plan["side_streams"] == 3
-    kd = {k: v[:16] for k, v in cuda(st["kp_d"]).items()}
-    out = es.forward_frames(kd, cuda(st["kp_s"]), outputs=KEYS)
-    errs = worst(out, {k: v[:16] for k, v in st["ref16"].items()})
-    show("16 frames, 2 x 2 bottleneck sub-chains vs the default plan", errs)
-    for k in KEYS:
-        assert errs[k] <= PLAN_TOL[k], (k, errs[k])
-    assert st["e16"].describe_plan(16)["bneck_subchains"] == 1
-
-
 def test_two_handles_on_two_caller_streams_share_the_pool():
     """Two handles driven alternately from ONE host thread on two caller streams: their chains interleave on the pool's
     three side streams (shared order, separate fork / join events) -- the frames must be the serial run's, bit for bit."""

@@ -3,7 +3,7 @@
 #   tools/exp_env.sh "EAMM_WINO4_VARIANT=0" "EAMM_WINO4_VARIANT=3" ...        (extra bench args in $BENCH_ARGS)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for kv in "$@"; do
-  env $kv python bench.py --cpu-frames 0 --clip-frames 0 --train-pairs 0 --e2e-frames 0 ${BENCH_ARGS:-} 2>/dev/null | python -c "
+  env EAMM_TUNING=1 $kv python bench.py --cpu-frames 0 --clip-frames 0 --train-pairs 0 --e2e-frames 0 ${BENCH_ARGS:-} 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
