@@ -158,7 +158,7 @@ int pad_state_dict(eamm_ctx* c) {
     const std::string dm = "dense_motion_network.";
     const int nb = c->nb, nd = c->nd;
     // the hourglass input line: per motion (heat-map, image channels) -- C + 1 values of the reference land in the kernels' four
-    const std::vector<PadPart> motion_line((size_t)c->K + 1, PadPart{c->Cimg + 1, 4});
+    const std::vector<PadPart> motion_line((size_t)c->K + 1, PadPart{c->Cimg + 1, 4 * c->G});
     int rc;
 #define PAD_TRY(e) if ((rc = (e))) return rc
     for (int i = 0; i < nb; ++i) {
@@ -184,11 +184,11 @@ int pad_state_dict(eamm_ctx* c) {
             auto it = c->sd.find(dm + "down.weight");
             if (it == c->sd.end() || (int)it->second.numel() != c->Cimg * 169)
                 return fail(c, EAMM_ERR_KEY, "%sdown.weight must be [%d,1,13,13]", dm.c_str(), c->Cimg);
-            it->second.data.resize(3 * 169, 0.f);
-            it->second.shape = {3, 1, 13, 13};
+            it->second.data.resize((size_t)c->Cpl * 169, 0.f);
+            it->second.shape = {c->Cpl, 1, 13, 13};
         }
     }
-    PAD_TRY(pad_conv(c, "first.conv", c->down_r[0], c->down_c[0], {{c->Cimg, 3}}));
+    PAD_TRY(pad_conv(c, "first.conv", c->down_r[0], c->down_c[0], {{c->Cimg, c->Cpl}}));
     PAD_TRY(pad_norm(c, "first.norm", c->down_r[0], c->down_c[0]));
     for (int i = 0; i < nd; ++i) {
         const std::string p = "down_blocks." + std::to_string(i);
@@ -206,7 +206,8 @@ int pad_state_dict(eamm_ctx* c) {
         PAD_TRY(pad_conv(c, p + ".conv", c->up_r[i], c->up_c[i], {in}));
         PAD_TRY(pad_norm(c, p + ".norm", c->up_r[i], c->up_c[i]));
     }
-    PAD_TRY(pad_conv(c, "final", c->Cimg, 3, {{c->up_r.back(), c->up_c.back()}}));
+    // (more than three image channels: `final` keeps its C outputs and runs on the generic kernel, see eamm_finalize_weights)
+    PAD_TRY(pad_conv(c, "final", c->Cimg, c->Cimg > 3 ? c->Cimg : 3, {{c->up_r.back(), c->up_c.back()}}));
 #undef PAD_TRY
     return 0;
 }
@@ -224,9 +225,9 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     if (!cfg || !out) return fail(nullptr, EAMM_ERR_ARG, "null argument");
     *out = nullptr;
     const eamm_config& g = *cfg;
-    if (g.num_channels < 1 || g.num_channels > 3)
-        return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 1, 2 or 3 (got %d): the motion kernels keep a pixel's image channels in "
-                    "one float4 beside its heat-map value", g.num_channels);
+    if (g.num_channels < 1 || g.num_channels > 6)
+        return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 1 .. 6 (got %d): the motion kernels keep a pixel's image channels in "
+                    "groups of three (one float4 beside its heat-map value per group), two groups at most", g.num_channels);
     if (g.num_kp < 1 || g.num_kp + 2 > 32) return fail(nullptr, EAMM_ERR_ARG, "num_kp out of range");
     // dm_num_blocks == 0: a generator without a motion network (dense_motion_params=None, generator.py:22-23)
     const bool has_dm = g.dm_num_blocks > 0;
@@ -271,8 +272,10 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->K = g.num_kp;
     c->hf = c->H >> c->nd;
     c->wf = c->W >> c->nd;
-    c->Cp0 = round_up((c->K + 1) * 4, 32);
     c->Cimg = g.num_channels;
+    c->G = c->Cimg > 3 ? 2 : 1;            // groups of three image channels (motion.hip: motion_front_kernel)
+    c->Cpl = 3 * c->G;                     // planes of the zero-extended source copy
+    c->Cp0 = round_up((c->K + 1) * 4 * c->G, 32);
     // hourglass channel plan (reference modules/util.py:941-987)
     for (int i = 0; i < c->nb; ++i) c->enc_r.push_back(std::min(g.dm_max_features, g.dm_block_expansion << (i + 1)));
     for (int i = c->nb - 1; i >= 0; --i) c->dec_r.push_back(std::min(g.dm_max_features, g.dm_block_expansion << i));
@@ -385,7 +388,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
     auto nm = [&](const std::string& norm) { return tr ? std::string() : norm; };
     // hourglass encoder: e_0 = 44-channel motion tensor (padded to Cp0), e_i = DownBlock2d_i(e_{i-1})
     c->hg_enc.resize(c->nb);
-    const int cin0 = (c->K + 1) * 4;
+    const int cin0 = (c->K + 1) * 4 * c->G;
     for (int i = 0; i < c->nb; ++i) {
         const std::string p = dm + "hourglass.encoder.down_blocks." + std::to_string(i);
         const int cr = i == 0 ? cin0 : c->enc_c[i - 1], cp = i == 0 ? c->Cp0 : c->enc_c[i - 1];
@@ -419,8 +422,8 @@ int eamm_finalize_weights(eamm_ctx* c) {
         }
     }
     // generator encoder
-    if ((rc = build_layer(c, {{"first.conv", nm("first.norm")}}, 7, 3, c->Csrc, 0, 0, &c->first))) return rc;
-    if (c->first7 && first7_supported(c->down_c[0])) {   // K = 147 (196 with the zero rows) instead of 49 x 32
+    if ((rc = build_layer(c, {{"first.conv", nm("first.norm")}}, 7, c->Cpl, c->Csrc, 0, 0, &c->first))) return rc;
+    if (c->first7 && c->Cpl == 3 && first7_supported(c->down_c[0])) {   // K = 147 (196 with the zero rows) instead of 49 x 32
         const HostTensor *wt = find(c, "first.conv.weight"), *bt = find(c, "first.conv.bias"), *gm = find(c, "first.norm.weight"),
                          *be = find(c, "first.norm.bias"), *mu = find(c, "first.norm.running_mean"), *vr = find(c, "first.norm.running_var");
         const int co = c->down_c[0];
@@ -509,7 +512,10 @@ int eamm_finalize_weights(eamm_ctx* c) {
         const int ci = i == 0 ? c->Cb : c->up_c[i - 1];
         if ((rc = build_set(c, {{p + ".conv", nm(p + ".norm")}}, ci, ci, 0, 0, &c->up[i], MODE_PHASE))) return rc;
     }
-    {   // final 7x7 (Cout = 3): 7x1 MFMA convolution over (dx, co) + horizontal gather
+    if (c->Cimg > 3) {   // more than three outputs: the plain 7x7 kernel (N padded to its 32-column tile), sigmoid and the NCHW
+        // store in its epilogue -- correct for any channel count, ten times the minimal work: RGBA is not the shipped case
+        if ((rc = build_layer(c, {{"final", ""}}, 7, c->up_c.back(), c->up_c.back(), 0, 0, &c->final_conv))) return rc;
+    } else {   // final 7x7 (Cout = 3): 7x1 MFMA convolution over (dx, co) + horizontal gather
         std::vector<float> fb;
         const bool col7_ok = c->col7 && c->up_c.back() % 32 == 0 && c->up_c.back() <= 64;
         if ((rc = build_layer(c, {{"final", ""}}, 7, c->up_c.back(), c->up_c.back(), 0, 0, &c->final_conv,
@@ -518,12 +524,12 @@ int eamm_finalize_weights(eamm_ctx* c) {
         if (c->final_conv.Cout != 21) return fail(c, EAMM_ERR_KEY, "final.weight must have 3 output channels");
         if ((rc = upload(c, &c->final_bias, fb))) return rc;
     }
-    // anti-alias buffer [3,1,13,13]
+    // anti-alias buffer [planes,1,13,13]
     {
-        std::vector<float> aa(3 * 169, 0.f);
+        std::vector<float> aa((size_t)c->Cpl * 169, 0.f);
         if (g.dm_inv_scale != 1) {
             const HostTensor* t = find(c, dm + "down.weight");
-            if (!t || t->numel() != 3 * 169) return fail(c, EAMM_ERR_KEY, "%sdown.weight must be [3,1,13,13]", dm.c_str());
+            if (!t || (int)t->numel() != c->Cpl * 169) return fail(c, EAMM_ERR_KEY, "%sdown.weight must be [%d,1,13,13]", dm.c_str(), c->Cimg);
             aa = t->data;
         }
         if ((rc = upload(c, &c->aa_w, aa))) return rc;
@@ -533,10 +539,11 @@ int eamm_finalize_weights(eamm_ctx* c) {
     const size_t S = g.max_sources, F = g.max_frames;
     const size_t HW = (size_t)c->H * c->W, hw = (size_t)c->h * c->w, hwf = (size_t)c->hf * c->wf;
     if ((rc = dev_alloc(c, &c->feat, S * hwf * c->Cb))) return rc;
-    if ((rc = dev_alloc(c, &c->src_small, S * hw * 4))) return rc;
-    if ((rc = dev_alloc(c, &c->src_full, S * 3 * HW))) return rc;
-    if (c->Cimg != 3) {   // the channels a source does not have stay zero for the handle's life (eamm_encode_source copies only the real ones)
-        HIP_TRY(c, hipMemset(c->src_full, 0, S * 3 * HW * sizeof(float)));
+    if ((rc = dev_alloc(c, &c->src_small, (size_t)c->G * S * hw * 4))) return rc;     // [group][source][h][w][4]
+    if ((rc = dev_alloc(c, &c->src_full, S * c->Cpl * HW))) return rc;
+    if (c->Cimg != 3)    // the channels a source does not have stay zero for the handle's life (eamm_encode_source copies only the real ones)
+        HIP_TRY(c, hipMemset(c->src_full, 0, S * c->Cpl * HW * sizeof(float)));
+    if (c->Cimg < 3) {   // one or two channels: the three-channel kernels write staging tensors (four and more write the caller's)
         if ((rc = dev_alloc(c, &c->stage_pred, F * 3 * HW))) return rc;
         if (c->nb > 0 && (rc = dev_alloc(c, &c->stage_deformed, F * 3 * HW))) return rc;
         if (c->nb > 0 && (rc = dev_alloc(c, &c->stage_sparse, F * (c->K + 1) * 3 * hw))) return rc;
@@ -697,12 +704,19 @@ int eamm_encode_source(eamm_ctx* c, const float* source, int ns, void* stream_) 
     if (c->Cimg == 3) {
         HIP_TRY(c, hipMemcpyAsync(c->src_full, source, (size_t)ns * 3 * HW * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else {   // [ns,C,H,W] into the first C planes of [ns,3,H,W]; the kernels below read the zero-extended copy
-        HIP_TRY(c, hipMemcpy2DAsync(c->src_full, 3 * HW * sizeof(float), source, c->Cimg * HW * sizeof(float), c->Cimg * HW * sizeof(float),
+        HIP_TRY(c, hipMemcpy2DAsync(c->src_full, c->Cpl * HW * sizeof(float), source, c->Cimg * HW * sizeof(float), c->Cimg * HW * sizeof(float),
                                     (size_t)ns, hipMemcpyDeviceToDevice, s));
         source = c->src_full;
     }
-    HIP_TRY(c, source_prepare_launch(source, c->aa_w, ns, c->H, c->W, c->cfg.dm_inv_scale, c->Csrc, c->src_nhwc,
-                                     c->src_small, s));
+    if (c->G == 1) {
+        HIP_TRY(c, source_prepare_launch(source, c->aa_w, ns, c->H, c->W, c->cfg.dm_inv_scale, c->Csrc, c->src_nhwc,
+                                         c->src_small, s));
+    } else {   // two groups of three planes: the padded NHWC copy for `first`, one down-sampled float4 image per group
+        HIP_TRY(c, nchw_to_nhwc_pad_launch(source, ns, c->Cpl, c->H, c->W, c->Csrc, c->src_nhwc, s));
+        for (int g = 0; g < c->G; ++g)
+            HIP_TRY(c, antialias_down_launch(source, c->aa_w, ns, c->H, c->W, c->cfg.dm_inv_scale, 4,
+                                             c->src_small + (size_t)g * c->cfg.max_sources * c->h * c->w * 4, s, c->Cpl, 3 * g));
+    }
     ConvIO io{};
     io.in0 = c->src_nhwc;
     io.B = ns;
@@ -816,7 +830,7 @@ static FrameView make_view(const eamm_ctx* c, int f0, int n, int ns_call, int sl
     v.ks_jac = ks_jac ? ks_jac + sf * K * 4 : nullptr;
     v.feat = c->feat + sf * hwf * c->Cb;
     v.src_small = c->src_small + sf * hw * 4;
-    v.src_full = c->src_full + sf * 3 * HW;
+    v.src_full = c->src_full + sf * c->Cpl * HW;
     v.kp_rec = c->kp_rec + F * K * KP_STRIDE;
     v.hg_in = c->hg_in ? c->hg_in + F * hw * c->Cp0 : nullptr;            // (no motion network: these four do not exist)
     for (int i = 0; i < c->nb; ++i) {
@@ -837,11 +851,12 @@ static FrameView make_view(const eamm_ctx* c, int f0, int n, int ns_call, int sl
     v.wino_v = c->wino_v ? c->wino_v + 4 * F * hwf * c->Cb : nullptr;                  // sized 4 x activations per frame
     v.wino_z = c->wino_z ? c->wino_z + 24 * (F * hwf / 16) * c->Cb : nullptr;
     v.out = *o;
-    if (o->prediction) v.out.prediction = o->prediction + F * 3 * HW;
+    const size_t CO = c->Cimg > 3 ? c->Cimg : 3;   // channels of the tensors the pass writes (staging tensors for one or two)
+    if (o->prediction) v.out.prediction = o->prediction + F * CO * HW;
     if (o->mask) v.out.mask = o->mask + F * (K + 1) * hw;
-    if (o->sparse_deformed) v.out.sparse_deformed = o->sparse_deformed + F * (K + 1) * 3 * hw;
+    if (o->sparse_deformed) v.out.sparse_deformed = o->sparse_deformed + F * (K + 1) * CO * hw;
     if (o->occlusion_map) v.out.occlusion_map = o->occlusion_map + F * hw;
-    if (o->deformed) v.out.deformed = o->deformed + F * 3 * HW;
+    if (o->deformed) v.out.deformed = o->deformed + F * CO * HW;
     if (o->deformation) v.out.deformation = o->deformation + F * hw * 2;
     if (o->frames_u8) v.out.frames_u8 = o->frames_u8 + F * HW * 3;
     return v;
@@ -916,7 +931,7 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
     HIP_TRY(c, kp_prepare_launch(v.kd_val, v.kd_jac, v.ks_val, v.kd_jac ? v.ks_jac : nullptr, n, ns, K, v.kp_rec, c->bad_flag, s));
     // heat-maps + sparse motions + K+1 warped sources -> hourglass input     dense_motion.py:88-94
     HIP_TRY(c, motion_front_launch(v.kp_rec, v.src_small, n, ns, K, h, w, c->cfg.kp_variance, c->Cp0, v.hg_in,
-                                   v.out.sparse_deformed, s));
+                                   v.out.sparse_deformed, s, c->G, c->Cimg > 3 ? c->Cimg : 3, (size_t)c->cfg.max_sources * h * w * 4));
     STAGE_MARK(1);
     // hourglass encoder                                                       util.py:956-960
     for (int i = 0; i < c->nb; ++i) {
@@ -1022,7 +1037,8 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         HIP_TRY(c, warp_features_launch(wv.feat, wv.deformation, occ ? wv.occlusion : nullptr, wv.n, wv.ns, hf, wf, c->Cb, h, w,
                                         wv.xa, wino ? nullptr : wv.act, c->pre_s[0], c->pre_t[0], s));
         if (wv.out.deformed)                                                        // generator.py:86
-            HIP_TRY(c, warp_image_launch(wv.src_full, wv.deformation, wv.n, wv.ns, c->H, c->W, h, w, wv.out.deformed, s));
+            HIP_TRY(c, warp_image_launch(wv.src_full, wv.deformation, wv.n, wv.ns, c->H, c->W, h, w, wv.out.deformed, s, c->Cpl,
+                                         c->Cimg > 3 ? c->Cimg : 3));
         if (joint) HIP_TRY(c, hipEventRecord(c->ev_warp, s));
         STAGE_MARK(5);
     }
@@ -1169,6 +1185,14 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         io.out = v.final_part;
         io.partial = v.partial;
         io.partial_cap = v.partial_elems;
+        if (c->Cimg > 3) {   // plain 7x7 kernel, sigmoid + NCHW store in the epilogue, straight into the caller's [n,C,H,W]
+            io.act = ACT_SIGMOID;
+            io.nchw = 1;
+            io.out = v.out.prediction;
+            HIP_TRY(c, conv_launch(c->final_conv, io, s));
+            account(7);
+            return EAMM_OK;
+        }
         ConvLayer fl = c->final_conv;
         fl.Cout = 32;  // 32-float pixel stride; channels >= 21 have zero weights
         // fused form: one workgroup per ROW of 16x16 tiles -- only when those rows fill at least half the chip (measured
@@ -1211,7 +1235,8 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     const eamm_outputs* const user = o;
     eamm_outputs staged = *o;
-    if (c->Cimg != 3) {   // one or two image channels: the pass writes three-channel staging tensors (eamm_ctx.h: Cimg)
+    if (o->frames_u8 && c->Cimg != 3) return fail(c, EAMM_ERR_ARG, "uint8 RGB frames need num_channels == 3");
+    if (c->Cimg < 3) {   // one or two image channels: the pass writes three-channel staging tensors (eamm_ctx.h: Cimg)
         if (o->frames_u8) return fail(c, EAMM_ERR_ARG, "uint8 RGB frames need num_channels == 3");
         staged.prediction = c->stage_pred;
         if (o->deformed) staged.deformed = c->stage_deformed;
@@ -1265,7 +1290,7 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
             HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0));
         }
     }
-    if (c->Cimg != 3) {   // the real channels of every frame: rows of C planes out of rows of three
+    if (c->Cimg < 3) {   // the real channels of every frame: rows of C planes out of rows of three
         const size_t HW = (size_t)c->H * c->W * sizeof(float), hw = (size_t)c->h * c->w * sizeof(float), C = (size_t)c->Cimg;
         HIP_TRY(c, hipMemcpy2DAsync(user->prediction, C * HW, c->stage_pred, 3 * HW, C * HW, (size_t)n, hipMemcpyDeviceToDevice, s));
         if (user->deformed)
@@ -1409,7 +1434,7 @@ int eamm_check_numeric(eamm_ctx* c, void* stream_) {
 
 size_t eamm_source_cache_bytes(const eamm_ctx* c, int ns) {
     if (!c) return 0;
-    const size_t per = (size_t)c->hf * c->wf * c->Cb + (size_t)c->h * c->w * 4 + (size_t)3 * c->H * c->W;
+    const size_t per = (size_t)c->hf * c->wf * c->Cb + (size_t)c->G * c->h * c->w * 4 + (size_t)c->Cpl * c->H * c->W;
     return per * (size_t)ns * sizeof(float);
 }
 
@@ -1419,11 +1444,13 @@ int eamm_export_source_cache(eamm_ctx* c, void* dst, int ns, void* stream_) {
     DeviceGuard guard(c->device);
     if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
-    const size_t a = (size_t)ns * c->hf * c->wf * c->Cb, b = (size_t)ns * c->h * c->w * 4, d = (size_t)ns * 3 * c->H * c->W;
+    const size_t a = (size_t)ns * c->hf * c->wf * c->Cb, b = (size_t)ns * c->h * c->w * 4, d = (size_t)ns * c->Cpl * c->H * c->W;
+    const size_t gstride = (size_t)c->cfg.max_sources * c->h * c->w * 4;   // src_small is [group][max_sources][h][w][4]
     float* p = reinterpret_cast<float*>(dst);
     HIP_TRY(c, hipMemcpyAsync(p, c->feat, a * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(p + a, c->src_small, b * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(p + a + b, c->src_full, d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int g = 0; g < c->G; ++g)
+        HIP_TRY(c, hipMemcpyAsync(p + a + g * b, c->src_small + g * gstride, b * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(p + a + c->G * b, c->src_full, d * sizeof(float), hipMemcpyDeviceToDevice, s));
     return EAMM_OK;
 }
 
@@ -1434,11 +1461,13 @@ int eamm_import_source_cache(eamm_ctx* c, const void* src, int ns, void* stream_
     DeviceGuard guard(c->device);
     if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
-    const size_t a = (size_t)ns * c->hf * c->wf * c->Cb, b = (size_t)ns * c->h * c->w * 4, d = (size_t)ns * 3 * c->H * c->W;
+    const size_t a = (size_t)ns * c->hf * c->wf * c->Cb, b = (size_t)ns * c->h * c->w * 4, d = (size_t)ns * c->Cpl * c->H * c->W;
+    const size_t gstride = (size_t)c->cfg.max_sources * c->h * c->w * 4;
     const float* p = reinterpret_cast<const float*>(src);
     HIP_TRY(c, hipMemcpyAsync(c->feat, p, a * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->src_small, p + a, b * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->src_full, p + a + b, d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int g = 0; g < c->G; ++g)
+        HIP_TRY(c, hipMemcpyAsync(c->src_small + g * gstride, p + a + g * b, b * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->src_full, p + a + c->G * b, d * sizeof(float), hipMemcpyDeviceToDevice, s));
     c->ns_cached = ns;
     return EAMM_OK;
 }

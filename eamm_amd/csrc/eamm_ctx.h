@@ -32,6 +32,7 @@ struct eamm_ctx : eamm::CtxBase {
     // head, zero filters + bias on the missing outputs of `final` (pad_state_dict) -- on a zero-extended source; the three-channel
     // results land in the staging buffers below and only the real channels are copied to the caller's tensors.
     int Cimg = 3;
+    int G = 1, Cpl = 3;         // four to six image channels: G = 2 groups of three, Cpl = 6 planes in the zero-extended source copy
     float *stage_pred = nullptr, *stage_deformed = nullptr, *stage_sparse = nullptr;
 
     // layers

@@ -166,7 +166,8 @@ hipError_t kp_prepare_launch(const float* kd_val, const float* kd_jac, const flo
                              int n, int ns, int K, float* kp_rec, int* bad_flag, hipStream_t s);
 hipError_t motion_front_launch(const float* kp_rec, const float* src_small /*[ns,h,w,4]*/, int n, int ns, int K,
                                int h, int w, float variance, int Cpad, float* hg_in /*[n,h,w,Cpad]*/,
-                               float* sparse_deformed /*[n,K+1,3,h,w] or null*/, hipStream_t s);
+                               float* sparse_deformed /*[n,K+1,channels,h,w] or null*/, hipStream_t s, int groups = 1,
+                               int channels = 3, size_t group_stride = 0);   // groups of three image channels (motion.hip)
 hipError_t motion_head_launch(const float* logits /*[n,h,w,32]*/, const float* kp_rec, int n, int K, int h, int w,
                               int has_occ, float* deformation /*[n,h,w,2]*/, float* occlusion /*[n,h,w]*/,
                               float* mask_out /*[n,K+1,h,w] or null*/, float* occ_out /*[n,1,h,w] or null*/,
@@ -182,14 +183,16 @@ hipError_t warp_features_launch(const float* feat /*[ns,hf,wf,C]*/, const float*
 hipError_t broadcast_features_launch(const float* feat /*[ns,hf,wf,C]*/, int n, int ns, int hf, int wf, int C, float* out,
                                      float* out2, const float* s2, const float* t2, hipStream_t s);
 hipError_t warp_image_launch(const float* src /*[ns,3,H,W]*/, const float* deformation /*[n,h,w,2]*/, int n, int ns,
-                             int H, int W, int h, int w, float* out /*[n,3,H,W]*/, hipStream_t s);
+                             int H, int W, int h, int w, float* out /*[n,channels,H,W]*/, hipStream_t s, int src_planes = 3,
+                             int channels = 3);
 hipError_t source_prepare_launch(const float* src /*[ns,3,H,W]*/, const float* aa_w /*[3,13,13] dev*/, int ns, int H,
                                  int W, int inv_scale, int Cpad, float* src_nhwc /*[ns,H,W,Cpad]*/,
                                  float* src_small /*[ns,h,w,4]*/, hipStream_t s);
 hipError_t final_shift_sum_launch(const float* part /*[n,H,W,32]: channel dx*3+co*/, const float* bias /*[3] dev*/,
                                   int n, int H, int W, float* out /*[n,3,H,W]*/, hipStream_t s);
 hipError_t antialias_down_launch(const float* src /*[ns,3,H,W]*/, const float* aa_w, int ns, int H, int W,
-                                 int inv_scale, int Cpad, float* dst /*[ns,h,w,Cpad]: RGB + zeros*/, hipStream_t s);
+                                 int inv_scale, int Cpad, float* dst /*[ns,h,w,Cpad]: RGB + zeros*/, hipStream_t s,
+                                 int src_planes = 3, int first_channel = 0);
 hipError_t nchw_to_nhwc_pad_launch(const float* src /*[B,C,H,W]*/, int B, int C, int H, int W, int Cpad,
                                    float* dst /*[B,H,W,Cpad]*/, hipStream_t s);
 hipError_t kp_head_launch(const float* logits /*[B,h,w,Cs]*/, int B, int K, int njm, int h, int w, int Cs, int pad,

@@ -100,11 +100,16 @@ __global__ void kp_prepare_kernel(const float* __restrict__ kd_val, const float*
 // bilinear warps of the down-sampled source (:69-79), written straight into the hourglass input
 // layout: channel 4k = heat_k, 4k+1..3 = RGB warped by T_k (:93-94), zero-padded to Cpad channels.
 // ---------------------------------------------------------------------------------------------
+// Image channels beyond three (num_channels 4 .. 6; generator.py:14 accepts any): the channels are handled in GROUPS of three,
+// one launch per group g: the per-motion record of the hourglass input grows to G float4 -- group 0 writes (heat, c0, c1, c2) at
+// slot k G, group g >= 1 writes (c_3g, c_3g+1, c_3g+2, 0) at slot k G + g -- so that a motion's C + 1 real values stay contiguous
+// (heat, c0 .. c_{C-1}) for C <= 6, which is how pad_state_dict lays the filters out.  sparse_deformed planes: [n, K+1, Ctot, h, w],
+// this launch writes channels coff .. coff + cn - 1.  One group (G = 1, Ctot = 3, cn = 3): the RGB layout of rounds 1-4.
 __global__ __launch_bounds__(256) void motion_front_kernel(const float* __restrict__ rec_all,
                                                            const float4* __restrict__ src_small, int ns, int K, int h,
                                                            int w, float variance, int Cpad,
                                                            float* __restrict__ hg_in,
-                                                           float* __restrict__ sparse_deformed) {
+                                                           float* __restrict__ sparse_deformed, int G, int g, int Ctot, int cn) {
     const int f = blockIdx.y;
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= h * w) return;
@@ -114,7 +119,8 @@ __global__ __launch_bounds__(256) void motion_front_kernel(const float* __restri
     const float* rec = rec_all + (size_t)f * K * KP_STRIDE;
     float4* dst = reinterpret_cast<float4*>(hg_in + ((size_t)f * h * w + pi) * Cpad);
     const size_t plane = (size_t)h * w;
-    float* sd = sparse_deformed ? sparse_deformed + (size_t)f * (K + 1) * 3 * plane + pi : nullptr;
+    const int coff = 3 * g;
+    float* sd = sparse_deformed ? sparse_deformed + ((size_t)f * (K + 1) * Ctot + coff) * plane + pi : nullptr;
     for (int k = 0; k <= K; ++k) {
         float tx = gx, ty = gy, heat = 0.f;
         if (k > 0) {
@@ -142,14 +148,15 @@ __global__ __launch_bounds__(256) void motion_front_kernel(const float* __restri
         r_ = fmaf(vne.x, wne, r_); g_ = fmaf(vne.y, wne, g_); b_ = fmaf(vne.z, wne, b_);
         r_ = fmaf(vsw.x, wsw, r_); g_ = fmaf(vsw.y, wsw, g_); b_ = fmaf(vsw.z, wsw, b_);
         r_ = fmaf(vse.x, wse, r_); g_ = fmaf(vse.y, wse, g_); b_ = fmaf(vse.z, wse, b_);
-        dst[k] = make_float4(heat, r_, g_, b_);
+        dst[k * G + g] = g == 0 ? make_float4(heat, r_, g_, b_) : make_float4(r_, g_, b_, 0.f);
         if (sd) {
-            sd[(size_t)(k * 3 + 0) * plane] = r_;
-            sd[(size_t)(k * 3 + 1) * plane] = g_;
-            sd[(size_t)(k * 3 + 2) * plane] = b_;
+            sd[(size_t)(k * Ctot + 0) * plane] = r_;
+            if (cn > 1) sd[(size_t)(k * Ctot + 1) * plane] = g_;
+            if (cn > 2) sd[(size_t)(k * Ctot + 2) * plane] = b_;
         }
     }
-    for (int c4 = K + 1; c4 < Cpad / 4; ++c4) dst[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g == 0)
+        for (int c4 = (K + 1) * G; c4 < Cpad / 4; ++c4) dst[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -370,7 +377,8 @@ __global__ __launch_bounds__(256) void warp_features_kernel(const float* __restr
 // 'deformed' side output: flow resized to the frame, grid_sample of the RGB source (generator.py:86).
 __global__ __launch_bounds__(256) void warp_image_kernel(const float* __restrict__ src,
                                                          const float* __restrict__ deformation, int n, int ns, int H,
-                                                         int W, int h, int w, float* __restrict__ out) {
+                                                         int W, int h, int w, float* __restrict__ out, int Cplanes,
+                                                         int Cout) {
     const size_t total = (size_t)n * H * W;
     const size_t plane = (size_t)H * W;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -382,17 +390,17 @@ __global__ __launch_bounds__(256) void warp_image_kernel(const float* __restrict
         flow_at(reinterpret_cast<const float2*>(deformation) + (size_t)f * h * w, nullptr, h, w, H, W, y, x, gx, gy,
                 o);
         const Bilinear b = bilinear_setup(gx, gy, W, H);
-        const float* s = src + (size_t)((ns == 1) ? 0 : f) * 3 * plane;
+        const float* s = src + (size_t)((ns == 1) ? 0 : f) * Cplanes * plane;
         const bool x0ok = (unsigned)b.x0 < (unsigned)W, x1ok = (unsigned)(b.x0 + 1) < (unsigned)W;
         const bool y0ok = (unsigned)b.y0 < (unsigned)H, y1ok = (unsigned)(b.y0 + 1) < (unsigned)H;
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < Cout; ++c) {
             const float* pc = s + c * plane;
             float v = 0.f;
             if (y0ok && x0ok) v = fmaf(pc[b.y0 * W + b.x0], b.wnw, v);
             if (y0ok && x1ok) v = fmaf(pc[b.y0 * W + b.x0 + 1], b.wne, v);
             if (y1ok && x0ok) v = fmaf(pc[(b.y0 + 1) * W + b.x0], b.wsw, v);
             if (y1ok && x1ok) v = fmaf(pc[(b.y0 + 1) * W + b.x0 + 1], b.wse, v);
-            out[((size_t)f * 3 + c) * plane + (size_t)y * W + x] = v;
+            out[((size_t)f * Cout + c) * plane + (size_t)y * W + x] = v;
         }
     }
 }
@@ -424,7 +432,8 @@ __global__ __launch_bounds__(256) void source_to_nhwc_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void antialias_down_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ aa_w, int ns, int H, int W,
-                                                             int inv_scale, int c4pad, float4* __restrict__ dst) {
+                                                             int inv_scale, int c4pad, float4* __restrict__ dst, int Cplanes,
+                                                             int coff) {
     const int h = H / inv_scale, w = W / inv_scale;
     const size_t plane = (size_t)H * W;
     const size_t total = (size_t)ns * h * w;
@@ -433,12 +442,12 @@ __global__ __launch_bounds__(256) void antialias_down_kernel(const float* __rest
     const int x = (int)(idx % w), y = (int)((idx / w) % h), b = (int)(idx / ((size_t)w * h));
     float acc[3] = {0.f, 0.f, 0.f};
     if (inv_scale == 1) {
-        for (int c = 0; c < 3; ++c) acc[c] = src[((size_t)b * 3 + c) * plane + (size_t)y * W + x];
+        for (int c = 0; c < 3; ++c) acc[c] = src[((size_t)b * Cplanes + coff + c) * plane + (size_t)y * W + x];
     } else {
         const int cy = y * inv_scale - 6, cx = x * inv_scale - 6;
         for (int c = 0; c < 3; ++c) {
-            const float* p = src + ((size_t)b * 3 + c) * plane;
-            const float* k = aa_w + c * 169;
+            const float* p = src + ((size_t)b * Cplanes + coff + c) * plane;
+            const float* k = aa_w + (coff + c) * 169;
             float s = 0.f;
             for (int ky = 0; ky < 13; ++ky) {
                 const int yy = cy + ky;
@@ -524,10 +533,15 @@ hipError_t kp_prepare_launch(const float* kd_val, const float* kd_jac, const flo
 }
 
 hipError_t motion_front_launch(const float* kp_rec, const float* src_small, int n, int ns, int K, int h, int w,
-                               float variance, int Cpad, float* hg_in, float* sparse_deformed, hipStream_t s) {
-    hipLaunchKernelGGL(motion_front_kernel, dim3((h * w + 255) / 256, n), dim3(256), 0, s, kp_rec,
-                       reinterpret_cast<const float4*>(src_small), ns, K, h, w, variance, Cpad, hg_in,
-                       sparse_deformed);
+                               float variance, int Cpad, float* hg_in, float* sparse_deformed, hipStream_t s, int groups,
+                               int channels, size_t group_stride) {
+    // one launch per group of three image channels (groups = 1, channels = 3: the RGB layout); src_small of group g starts
+    // group_stride floats behind group g - 1's
+    if (groups < 1 || groups > 2 || channels < 1 || channels > 3 * groups || (K + 1) * 4 * groups > Cpad) return hipErrorInvalidValue;
+    for (int g = 0; g < groups; ++g)
+        hipLaunchKernelGGL(motion_front_kernel, dim3((h * w + 255) / 256, n), dim3(256), 0, s, kp_rec,
+                           reinterpret_cast<const float4*>(src_small + (size_t)g * group_stride), ns, K, h, w, variance, Cpad, hg_in,
+                           sparse_deformed, groups, g, groups == 1 ? 3 : channels, std::min(3, channels - 3 * g));
     return hipGetLastError();
 }
 
@@ -560,10 +574,10 @@ hipError_t warp_features_launch(const float* feat, const float* deformation, con
 }
 
 hipError_t warp_image_launch(const float* src, const float* deformation, int n, int ns, int H, int W, int h, int w,
-                             float* out, hipStream_t s) {
+                             float* out, hipStream_t s, int src_planes, int channels) {
     const size_t total = (size_t)n * H * W;
     hipLaunchKernelGGL(warp_image_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, deformation, n, ns, H, W, h, w,
-                       out);
+                       out, src_planes, channels);
     return hipGetLastError();
 }
 
@@ -604,15 +618,16 @@ hipError_t source_prepare_launch(const float* src, const float* aa_w, int ns, in
     hipLaunchKernelGGL(source_to_nhwc_kernel, dim3(grid_for(t1)), dim3(256), 0, s, src, ns, H, W, Cpad, src_nhwc);
     const size_t t2 = (size_t)ns * (H / inv_scale) * (W / inv_scale);
     hipLaunchKernelGGL(antialias_down_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, src, aa_w, ns, H, W,
-                       inv_scale, 1, reinterpret_cast<float4*>(src_small));
+                       inv_scale, 1, reinterpret_cast<float4*>(src_small), 3, 0);
     return hipGetLastError();
 }
 
 hipError_t antialias_down_launch(const float* src, const float* aa_w, int ns, int H, int W, int inv_scale, int Cpad,
-                                 float* dst, hipStream_t s) {
+                                 float* dst, hipStream_t s, int src_planes, int first_channel) {
+    // three channels first_channel .. + 2 of a source with src_planes planes per image (aa_w: one 13x13 filter per plane)
     const size_t t2 = (size_t)ns * (H / inv_scale) * (W / inv_scale);
     hipLaunchKernelGGL(antialias_down_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, src, aa_w, ns, H, W,
-                       inv_scale, Cpad / 4, reinterpret_cast<float4*>(dst));
+                       inv_scale, Cpad / 4, reinterpret_cast<float4*>(dst), src_planes, first_channel);
     return hipGetLastError();
 }
 

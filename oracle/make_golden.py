@@ -725,8 +725,11 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "channels":   # num_channels 1 and 2 (generator.py:14,25,46; dense_motion.py:17-18,27)
         OAG = import_reference()
-        for name, ch in (("tiny64_gray", 1), ("tiny64_two_channels", 2)):
-            rep = case(OAG, name, {**tiny_config(), "num_channels": ch}, 64, 2, 1234, 1, per_frame_source=(ch == 2))
+        which = sys.argv[2:] or ["tiny64_gray", "tiny64_two_channels", "tiny64_rgba", "tiny64_six_channels"]
+        for name, ch in (("tiny64_gray", 1), ("tiny64_two_channels", 2), ("tiny64_rgba", 4), ("tiny64_six_channels", 6)):
+            if name not in which:
+                continue
+            rep = case(OAG, name, {**tiny_config(), "num_channels": ch}, 64, 2, 1234, 1, per_frame_source=(ch in (2, 6)))
             print(name, {k: (r["oracle_vs_reference"], r["fp32_vs_fp64_floor"]) for k, r in rep.items()})
             path = os.path.join(GOLDEN, "summary.json")   # (added without regenerating the other fixtures)
             summary = json.load(open(path))
@@ -778,6 +781,8 @@ def main():
     summary["full512_clip1"] = case(OAG, "full512_clip1", full, 512, 1, 1234, 8)
     summary["tiny64_gray"] = case(OAG, "tiny64_gray", {**tiny, "num_channels": 1}, 64, 2, 1234, 1)
     summary["tiny64_two_channels"] = case(OAG, "tiny64_two_channels", {**tiny, "num_channels": 2}, 64, 2, 1234, 1, per_frame_source=True)
+    summary["tiny64_rgba"] = case(OAG, "tiny64_rgba", {**tiny, "num_channels": 4}, 64, 2, 1234, 1)
+    summary["tiny64_six_channels"] = case(OAG, "tiny64_six_channels", {**tiny, "num_channels": 6}, 64, 2, 1234, 1, per_frame_source=True)
     summary["tiny64_adversarial"] = adversarial_case(OAG, "tiny64_adversarial", tiny, 64, 3, 1)
     summary["full256_adversarial"] = adversarial_case(OAG, "full256_adversarial", full, 256, 2, 4)
     no_motion_case(OAG)

@@ -60,9 +60,9 @@ def test_create_rejects_bad_config_without_gpu_compute():
     cs = config_struct(hot_path_config(), 512, 512, 256, 1)  # 256 frames of 512x512: a > 4 GiB activation tensor
     assert L.eamm_create(ctypes.byref(cs), 0, ctypes.byref(ctx)) == _lib.ERR_ARG
     assert b"4 GiB" in L.eamm_last_error(None)
-    cs = config_struct({**tiny_config(), "num_channels": 4}, 64, 64, 4, 1)  # one to three image channels (include/eamm_hip.h)
+    cs = config_struct({**tiny_config(), "num_channels": 7}, 64, 64, 4, 1)  # one to six image channels (include/eamm_hip.h)
     assert L.eamm_create(ctypes.byref(cs), 0, ctypes.byref(ctx)) == _lib.ERR_ARG
-    assert b"num_channels must be 1, 2 or 3" in L.eamm_last_error(None)
+    assert b"num_channels must be 1 .. 6" in L.eamm_last_error(None)
 
 
 @pytest.mark.parametrize("cfg_fn,nkeys,nparams", [(tiny_config, 112, None), (hot_path_config, 196, 45593205)])

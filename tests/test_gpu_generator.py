@@ -9,7 +9,8 @@ from conftest import TOL
 from eamm_amd import EngineBackend, OcclusionAwareGenerator, animate_clip, hot_path_config, tiny_config
 from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict
 from oracle import eamm_oracle as orc
-from test_oracle_golden import gray_config, inputs_from_fixture, load_case, sample, two_channel_config
+from test_oracle_golden import (gray_config, inputs_from_fixture, load_case, rgba_config, sample, six_channel_config,
+                                two_channel_config)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -47,10 +48,12 @@ def report(tag, errs):
 @pytest.mark.parametrize("name,cfg_fn", [("tiny64_clip3", tiny_config), ("tiny64_batch2", tiny_config),
                                          ("tiny64_nojac", tiny_config), ("full256_clip2", hot_path_config),
                                          ("full512_clip1", hot_path_config),
-                                         ("tiny64_gray", gray_config), ("tiny64_two_channels", two_channel_config)])
+                                         ("tiny64_gray", gray_config), ("tiny64_two_channels", two_channel_config),
+                                         ("tiny64_rgba", rgba_config), ("tiny64_six_channels", six_channel_config)])
 def test_module_forward_matches_reference_fixture(name, cfg_fn):
     """Reference contract forward(source, kp_driving, kp_source) -> dict, against reference outputs.  The last two: one and two
-    image channels (num_channels; generator.py:14 accepts any) -- [n,C,H,W] in and out, run as the zero-extended RGB network."""
+    image channels (num_channels; generator.py:14 accepts any) -- [n,C,H,W] in and out, run as the zero-extended RGB network -- and
+    four and six (round 5): two groups of three channels through the motion kernels, `final` on the generic 7x7 kernel."""
     cfg = cfg_fn()
     fx = load_case(name)
     sd, src, kp_d, kp_s, n, per_frame = inputs_from_fixture(fx, cfg)
@@ -85,6 +88,35 @@ def test_gray_clip_interface_and_rgb_only_uint8():
     assert float((frames.cpu() - ref).abs().max()) <= TOL["prediction"]
     with pytest.raises(RuntimeError, match="num_channels == 3"):
         animate_clip(EngineBackend(gen, batch=3), src, kp_s, kp_d, 64, 64, uint8=True)
+
+
+def test_rgba_clip_interface_and_source_cache_roundtrip():
+    """Four image channels through encode-once + batched frames, and the source cache of a two-group handle (two down-sampled
+    float4 images + six source planes) exported from one handle and imported into another."""
+    cfg = rgba_config()
+    sd = synthetic_state_dict(cfg, seed=1234)
+    gen = generator(rgba_config)
+    src = synthetic_source(64, seed=1, channels=4)
+    kp_s, kp_d = synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(5, 10, seed=2)
+    frames, span = animate_clip(EngineBackend(gen, batch=3), src, kp_s, kp_d, 64, 64)
+    assert span == (0, 5) and frames.shape == (5, 4, 64, 64)
+    ref = orc.generator_forward(sd, cfg, src.expand(5, -1, -1, -1).contiguous(), kp_d,
+                                {k: v.expand(5, *v.shape[1:]).contiguous() for k, v in kp_s.items()})["prediction"]
+    assert float((frames.cpu() - ref).abs().max()) <= TOL["prediction"]
+    with pytest.raises(RuntimeError, match="num_channels == 3"):
+        animate_clip(EngineBackend(gen, batch=3), src, kp_s, kp_d, 64, 64, uint8=True)
+    e1 = gen.encode_source(src.to(DEV), max_frames=3)
+    blob = e1.export_source_cache(1)
+    g2 = OcclusionAwareGenerator(**cfg)
+    g2.load_state_dict(sd, strict=True)
+    g2 = g2.to(DEV).eval()
+    e2 = g2._ensure_engine(64, 64, 3, 1)
+    e2.import_source_cache(blob, 1)
+    kd, ks = cuda({k: v[:3] for k, v in kp_d.items()}), cuda(kp_s)
+    a = e1.forward_frames(kd, ks, outputs=KEYS)
+    b = e2.forward_frames(kd, ks, outputs=KEYS)
+    for k in KEYS:
+        assert torch.equal(a[k], b[k]), k
 
 
 def test_internal_flow_matches_fixture():
@@ -231,6 +263,10 @@ VARIANTS = {
     # one / two image channels (run as the zero-extended RGB network) together with the other load-time rewrites
     "gray_scale_one": ({"num_channels": 1}, {"scale_factor": 1}, 64, 64),
     "two_channels_odd_widths": ({"num_channels": 2, "block_expansion": 48, "max_features": 200}, {"block_expansion": 40, "max_features": 100}, 64, 96),
+    # four / five image channels (two channel groups) together with the other rewrites: rectangular frame, resized flow, odd widths
+    "rgba_scale_half_rect": ({"num_channels": 4}, {"scale_factor": 0.5}, 64, 96),
+    "five_channels_odd_widths": ({"num_channels": 5, "block_expansion": 48, "max_features": 200}, {"block_expansion": 40, "max_features": 100}, 64, 64),
+    "rgba_scale_one": ({"num_channels": 4, "num_down_blocks": 1}, {"scale_factor": 1, "num_blocks": 2}, 32, 32),
 }
 
 

@@ -22,9 +22,19 @@ def two_channel_config():
     return {**tiny_config(), "num_channels": 2}
 
 
+def rgba_config():
+    """num_channels = 4: beyond the kernels' float4 pixel record -- two groups of three channels (csrc/motion.hip)."""
+    return {**tiny_config(), "num_channels": 4}
+
+
+def six_channel_config():
+    return {**tiny_config(), "num_channels": 6}
+
+
 CASES = [("tiny64_clip3", tiny_config), ("tiny64_batch2", tiny_config), ("tiny64_nojac", tiny_config),
          ("full256_clip2", hot_path_config), ("full512_clip1", hot_path_config),
-         ("tiny64_gray", gray_config), ("tiny64_two_channels", two_channel_config)]
+         ("tiny64_gray", gray_config), ("tiny64_two_channels", two_channel_config),
+         ("tiny64_rgba", rgba_config), ("tiny64_six_channels", six_channel_config)]
 
 
 def load_case(name):
