@@ -64,7 +64,7 @@ int eamm_kp_create(const eamm_kp_config* cfg, int device, eamm_kp_ctx** out) {
     if (!cfg || !out) return fail(nullptr, EAMM_ERR_ARG, "null argument");
     *out = nullptr;
     const eamm_kp_config& g = *cfg;
-    if (g.num_channels < 1 || g.num_channels > 3) return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 1, 2 or 3 (got %d)", g.num_channels);
+    if (g.num_channels < 1 || g.num_channels > 8) return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 1 .. 8 (got %d)", g.num_channels);
     if (g.num_kp < 1 || g.num_kp * (g.estimate_jacobian ? (g.single_jacobian_map ? 1 : 5) : 1) + (g.single_jacobian_map ? 4 : 0) > 64)
         return fail(nullptr, EAMM_ERR_ARG, "num_kp out of range for the 64-channel head");
     if (g.block_expansion % 32 || g.max_features % 32 || g.num_blocks < 1)
@@ -149,7 +149,7 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
         }
         // head input = cat[last up output (block_expansion), hourglass input (cin, stored padded)]  util.py:981-987
         if ((rc = build_layer(c, parts, 7, c->dec_c.back(), c->dec_c.back(), cin, c->Cin_pad, &c->head))) return rc;
-        std::vector<float> aa(3 * 169, 0.f);
+        std::vector<float> aa((size_t)std::max(3, g.num_channels) * 169, 0.f);
         if (g.inv_scale != 1) {
             const HostTensor* t = find(c, "down.weight");
             if (!t || (int)t->numel() != g.num_channels * 169)
@@ -157,7 +157,7 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
             std::copy(t->data.begin(), t->data.end(), aa.begin());   // (the planes an image does not have keep zero filters)
         }
         if ((rc = upload(c, &c->aa_w, aa))) return rc;
-        if (g.num_channels != 3) {   // one / two image channels: the hourglass's first block has filters for those only (cin above)
+        if (g.num_channels < 3) {   // one / two image channels: the hourglass's first block has filters for those only (cin above)
             const size_t n = (size_t)g.max_batch * 3 * c->H * c->W;
             if ((rc = dev_alloc(c, &c->img_stage, n))) return rc;
             HIP_TRY(c, hipMemset(c->img_stage, 0, n * sizeof(float)));
@@ -217,7 +217,14 @@ int eamm_kp_detect(eamm_kp_ctx* c, const float* image, int B, const eamm_kp_outp
         image = c->img_stage;
     }
     // x = down(x): anti-aliased, NHWC zero-padded to Cin_pad channels            keypoint_detector.py:79-80
-    HIP_TRY(c, antialias_down_launch(image, c->aa_w, B, c->H, c->W, c->cfg.inv_scale, c->Cin_pad, c->x_in, s));
+    if (c->cfg.num_channels <= 3) {
+        HIP_TRY(c, antialias_down_launch(image, c->aa_w, B, c->H, c->W, c->cfg.inv_scale, c->Cin_pad, c->x_in, s));
+    } else {   // four to eight channels: four per float4 slot, straight from the caller's [B,C,H,W] (real channels stay contiguous)
+        const int C = c->cfg.num_channels;
+        for (int g0 = 0, slot = 0; g0 < C; g0 += 4, ++slot)
+            HIP_TRY(c, antialias_down_launch(image, c->aa_w, B, c->H, c->W, c->cfg.inv_scale, c->Cin_pad, c->x_in, s, C, g0,
+                                             std::min(4, C - g0), slot));
+    }
     for (int i = 0; i < c->nb; ++i) {   // hourglass encoder                      util.py:956-960
         ConvIO io{};
         io.in0 = i == 0 ? c->x_in : c->e_buf[i - 1];

@@ -430,22 +430,24 @@ __global__ __launch_bounds__(256) void source_to_nhwc_kernel(const float* __rest
     }
 }
 
+// cn (1 .. 4) channels coff .. coff + cn - 1 of a source with Cplanes planes per image -> one float4 per kept pixel, written at
+// float4 slot `slot` of the pixel's c4pad slots; `fill`: the pixel's other slots are zeroed (the first launch of a pixel line).
 __global__ __launch_bounds__(256) void antialias_down_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ aa_w, int ns, int H, int W,
                                                              int inv_scale, int c4pad, float4* __restrict__ dst, int Cplanes,
-                                                             int coff) {
+                                                             int coff, int cn, int slot, int fill) {
     const int h = H / inv_scale, w = W / inv_scale;
     const size_t plane = (size_t)H * W;
     const size_t total = (size_t)ns * h * w;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int x = (int)(idx % w), y = (int)((idx / w) % h), b = (int)(idx / ((size_t)w * h));
-    float acc[3] = {0.f, 0.f, 0.f};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (inv_scale == 1) {
-        for (int c = 0; c < 3; ++c) acc[c] = src[((size_t)b * Cplanes + coff + c) * plane + (size_t)y * W + x];
+        for (int c = 0; c < cn; ++c) acc[c] = src[((size_t)b * Cplanes + coff + c) * plane + (size_t)y * W + x];
     } else {
         const int cy = y * inv_scale - 6, cx = x * inv_scale - 6;
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < cn; ++c) {
             const float* p = src + ((size_t)b * Cplanes + coff + c) * plane;
             const float* k = aa_w + (coff + c) * 169;
             float s = 0.f;
@@ -461,8 +463,10 @@ __global__ __launch_bounds__(256) void antialias_down_kernel(const float* __rest
             acc[c] = s;
         }
     }
-    dst[idx * c4pad] = make_float4(acc[0], acc[1], acc[2], 0.f);
-    for (int k = 1; k < c4pad; ++k) dst[idx * c4pad + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dst[idx * c4pad + slot] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (fill)
+        for (int k = 0; k < c4pad; ++k)
+            if (k != slot) dst[idx * c4pad + k] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // Final 7x7 convolution, second half (generator.py:92-93).  The MFMA kernel ran it as a 7x1 (vertical)
@@ -618,16 +622,18 @@ hipError_t source_prepare_launch(const float* src, const float* aa_w, int ns, in
     hipLaunchKernelGGL(source_to_nhwc_kernel, dim3(grid_for(t1)), dim3(256), 0, s, src, ns, H, W, Cpad, src_nhwc);
     const size_t t2 = (size_t)ns * (H / inv_scale) * (W / inv_scale);
     hipLaunchKernelGGL(antialias_down_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, src, aa_w, ns, H, W,
-                       inv_scale, 1, reinterpret_cast<float4*>(src_small), 3, 0);
+                       inv_scale, 1, reinterpret_cast<float4*>(src_small), 3, 0, 3, 0, 1);
     return hipGetLastError();
 }
 
 hipError_t antialias_down_launch(const float* src, const float* aa_w, int ns, int H, int W, int inv_scale, int Cpad,
-                                 float* dst, hipStream_t s, int src_planes, int first_channel) {
-    // three channels first_channel .. + 2 of a source with src_planes planes per image (aa_w: one 13x13 filter per plane)
+                                 float* dst, hipStream_t s, int src_planes, int first_channel, int channels, int slot) {
+    // `channels` (1 .. 4) channels from first_channel on of a source with src_planes planes per image (aa_w: one 13x13 filter per
+    // plane) into float4 slot `slot` of every pixel's Cpad / 4 slots; slot 0 also zeroes the pixel's other slots
+    if (channels < 1 || channels > 4 || slot < 0 || slot >= Cpad / 4 || first_channel + channels > src_planes) return hipErrorInvalidValue;
     const size_t t2 = (size_t)ns * (H / inv_scale) * (W / inv_scale);
     hipLaunchKernelGGL(antialias_down_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, src, aa_w, ns, H, W,
-                       inv_scale, Cpad / 4, reinterpret_cast<float4*>(dst), src_planes, first_channel);
+                       inv_scale, Cpad / 4, reinterpret_cast<float4*>(dst), src_planes, first_channel, channels, slot, slot == 0 ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -71,7 +71,7 @@ class Engine:
         self.height, self.width = int(height), int(width)
         self.max_frames, self.max_sources = int(max_frames), int(max_sources)
         self.num_kp = cfg["num_kp"]
-        self.num_channels = cfg["num_channels"]   # 1..3 (include/eamm_hip.h: one or two run as the equivalent three-channel network)
+        self.num_channels = cfg["num_channels"]   # 1..6 (include/eamm_hip.h: one or two run as the equivalent three-channel network, four to six as two channel groups)
         self._L = _lib.lib()
         self._cs = config_struct(cfg, height, width, max_frames, max_sources)
         self.inv_scale = self._cs.dm_inv_scale

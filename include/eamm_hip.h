@@ -47,13 +47,14 @@ typedef struct eamm_ctx eamm_ctx;
  * dense_motion_params (reference modules/dense_motion.py:12-13) flattened in, plus the two sizes
  * the workspace is allocated for.  Any positive channel widths: those that are not multiples of the kernels' 32-channel
  * granule are served by padding the state_dict at eamm_finalize_weights (the extra channels carry exact zeros); a
- * training-mode handle (eamm_set_training) needs multiples of 32 and three image channels.  num_channels: 1, 2 or 3 -- one
- * or two channels run as the equivalent three-channel network (zero filters on the channels that do not exist), sources
- * and outputs keep the reference's shapes [.,C,H,W]; more than three are refused (the motion kernels hold a pixel's image
- * channels in one float4 beside its heat-map value).
+ * training-mode handle (eamm_set_training) needs multiples of 32 and three image channels.  num_channels: 1 .. 6 -- one
+ * or two channels run as the equivalent three-channel network (zero filters on the channels that do not exist); four to six
+ * (RGBA ...) run as TWO groups of three channels through the motion kernels (a pixel's image channels live in one float4
+ * beside its heat-map value per group: motion.hip) with `final` on the generic 7x7 kernel; sources and outputs keep the
+ * reference's shapes [.,C,H,W] throughout; seven and more are refused.
  */
 typedef struct eamm_config {
-    int32_t num_channels;            /* 3 (1 and 2 accepted)                           */
+    int32_t num_channels;            /* 3 (1 .. 6 accepted)                            */
     int32_t num_kp;                  /* 10                                             */
     int32_t block_expansion;         /* 64                                             */
     int32_t max_features;            /* 512                                            */
@@ -190,7 +191,7 @@ int eamm_build_experiments(void);
 typedef struct eamm_kp_ctx eamm_kp_ctx;
 typedef struct eamm_kp_config {
     int32_t num_kp;                 /* 10                                                   */
-    int32_t num_channels;           /* 3 (1 and 2 accepted: the image is zero-extended)      */
+    int32_t num_channels;           /* 3 (1 .. 8 accepted)                                   */
     int32_t in_features;            /* hourglass input channels: num_channels (KPDetector) or num_channels_a */
     int32_t block_expansion;        /* 32                                                   */
     int32_t max_features;           /* 1024                                                 */

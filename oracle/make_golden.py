@@ -288,7 +288,9 @@ def kp_detector_cases(only=None):
     for name, cfg, size, audio in (("kp_tiny64", tiny_kp_config(), 64, False), ("kp_full256", kp_detector_config(), 256, False),
                                    ("kpa_tiny", tiny_kp_config(audio=True), 64, True),
                                    ("kpa_full", kp_detector_a_config(), 256, True),
-                                   ("kp_tiny64_gray", {**tiny_kp_config(), "num_channels": 1}, 64, False)):
+                                   ("kp_tiny64_gray", {**tiny_kp_config(), "num_channels": 1}, 64, False),
+                                   ("kp_tiny64_rgba", {**tiny_kp_config(), "num_channels": 4}, 64, False),
+                                   ("kp_tiny64_six_channels", {**tiny_kp_config(), "num_channels": 6}, 64, False)):
         if only and name not in only:
             continue
         sd = synthetic_state_dict(cfg, seed=77, spec=kp_state_dict_spec(cfg))

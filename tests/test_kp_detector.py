@@ -15,7 +15,9 @@ from oracle import eamm_oracle as orc
 TOL_KP = {"value": 5e-5, "jacobian": 1e-4, "heatmap": 5e-5}
 CASES = [("kp_tiny64", lambda: tiny_kp_config(), False), ("kp_full256", kp_detector_config, False),
          ("kpa_tiny", lambda: tiny_kp_config(audio=True), True), ("kpa_full", kp_detector_a_config, True),
-         ("kp_tiny64_gray", lambda: {**tiny_kp_config(), "num_channels": 1}, False)]   # one image channel (keypoint_detector.py:17-21)
+         ("kp_tiny64_gray", lambda: {**tiny_kp_config(), "num_channels": 1}, False),   # one image channel (keypoint_detector.py:17-21)
+         ("kp_tiny64_rgba", lambda: {**tiny_kp_config(), "num_channels": 4}, False),   # four / six: four channels per float4 slot
+         ("kp_tiny64_six_channels", lambda: {**tiny_kp_config(), "num_channels": 6}, False)]
 
 
 def load(name, cfg, audio):
