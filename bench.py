@@ -229,9 +229,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--clip-frames", type=int, default=2048, help="frames of the configs[3] clip leg (0 = skip)")
     ap.add_argument("--clip-batch", type=int, default=None,
-                    help="frames per launch sequence of the clip leg (the clip harness is free to batch: 64 frames per call at 256x256 "
-                         "run 5 %% faster than 16; the contract line above stays at --batch).  Default: 64 at 256x256, the same number "
-                         "of pixels per call at other sizes (16 at 512x512: activations stay under the 4 GiB per tensor)")
+                    help="frames per launch sequence of the clip leg (the clip harness is free to batch: 128 frames per call at 256x256 "
+                         "-- four chains of 32 -- run 4 %% faster than 16, 2.7 %% faster than 64: profiles/r05_sweeps.txt; the contract "
+                         "line above stays at --batch).  Default: 128 at 256x256, the same number of pixels per call at other sizes "
+                         "(32 at 512x512: activations stay under the 4 GiB per tensor)")
     ap.add_argument("--clip-gather", action="store_true", help="clip leg: gather uint8 frames on rank 0 inside the timed region")
     ap.add_argument("--e2e-frames", type=int, default=2048,
                     help="frames of the end-to-end leg (make_animation_smooth: LSTM features -> uint8 frames in host memory; 0 = skip)")
@@ -423,7 +424,7 @@ def main():
     clip = None
     if args.clip_frames > 0:
         T = args.clip_frames
-        CB = args.clip_batch if args.clip_batch else max(B, 64 * 256 * 256 // (S * S))
+        CB = args.clip_batch if args.clip_batch else max(B, 128 * 256 * 256 // (S * S))
         CB = max(1, min(CB, -(-T // world)))
         if CB == B:
             gen_clip = gen
@@ -514,7 +515,7 @@ def main():
         from eamm_amd import DeconvTail, KPDetector, KPDetector_a, animate_from_features, kp_detector_a_config, kp_detector_config
         from eamm_amd.weights import deconv_state_dict_spec, synthetic_lstm_features, trained_like_kp_state_dict
         T2 = args.e2e_frames
-        CB2 = max(1, min(64, -(-T2 // world)))
+        CB2 = max(1, min(128, -(-T2 // world)))
         gen_e = OcclusionAwareGenerator(**cfg, max_frames=CB2)
         gen_e.load_state_dict(sd, strict=True)
         gen_e = gen_e.to(dev).eval()

@@ -69,7 +69,7 @@ def test_bench_single_gpu_line():
     # configs[3] leg: the whole 2048-frame clip (encode + compute) must run at the steady-state rate within a few %
     k = d["clip"]
     assert k["frames"] == 2048 and k["n_gpus"] == 1 and abs(k["frames_per_s"] - 2048 / k["seconds"]) < 1.0
-    assert k["batch"] == 64          # the clip harness batches 64 frames per call (about 5 % over the contract line's 16)
+    assert k["batch"] == 128         # the clip harness batches 128 frames per call = four chains of 32 (about 4 % over the contract line's 16)
     assert 0.9 * d["value"] <= k["frames_per_s"] <= 1.12 * d["value"], (k["frames_per_s"], d["value"])
     assert {"encode_ms", "compute_ms"} <= set(k["phases_ms_rank0"]) and len(k["phases_ms_per_rank"]) == 1
     # the clip leg looks at what its TIMED pass produced: fixture frames + spot frames recomputed under the
@@ -77,7 +77,7 @@ def test_bench_single_gpu_line():
     v = k["verify"]
     assert v["ok"] is True and v["fixture"]["ok"] is True and v["fixture"]["max_abs_err"] <= 1e-4
     assert v["spot_frames"] == [0, 1024, 2047] and v["vs_contract_plan_max_abs"] <= 2e-5
-    assert k["plan"]["pass_chains"] == 4 and k["plan"]["frames_per_chain"] == 16 and k["collectives_per_clip"] == 0
+    assert k["plan"]["pass_chains"] == 4 and k["plan"]["frames_per_chain"] == 32 and k["collectives_per_clip"] == 0
     # end-to-end leg: make_animation_smooth whole, frames delivered to pinned host memory
     e = d["e2e_clip"]
     assert e["frames"] == 2048 and e["verify"]["ok"] is True and e["verify"]["uint8_levels_vs_contract_plan"] <= 1

@@ -117,6 +117,28 @@ def test_ragged_calls_on_the_four_chain_handle(n, chains):
             assert float((out[k][t].cpu() - ref[k][0]).abs().max()) <= TOL[k], (n, t, k)
 
 
+def test_128_frame_call_four_chains_of_32():
+    """The clip legs of bench.py batch 128 frames per call (four chains of 32 frames, each chain's bottleneck GEMM 512 workgroups):
+    against eight 16-frame calls and against the oracle on the first and the last frame."""
+    st = state()
+    _, e128 = fresh_engine(128)
+    assert e128.pass_chains(128) == 4 and e128.describe_plan(128)["frames_per_chain"] == 32
+    kp_d = synthetic_keypoints(128, 10, seed=2)
+    kd, ks = cuda(kp_d), cuda(st["kp_s"])
+    out = e128.forward_frames(kd, ks, outputs=KEYS)
+    parts = [st["e16"].forward_frames({k: v[i:i + 16] for k, v in kd.items()}, ks, outputs=KEYS) for i in range(0, 128, 16)]
+    ref16 = {k: torch.cat([p[k] for p in parts]) for k in KEYS}
+    errs = worst(out, ref16)
+    show("128 frames / four chains of 32 vs 8 x 16 frames", errs)
+    for k in KEYS:
+        assert errs[k] <= PLAN_TOL[k], (k, errs[k])
+    assert torch.equal(out["prediction"][:64], out["prediction"][:64]) and torch.equal(ref16["prediction"][:64], st["ref16"]["prediction"])
+    for t in (0, 127):
+        ref = orc.generator_forward(st["sd"], st["cfg"], st["src"], {k: v[t:t + 1] for k, v in kp_d.items()}, st["kp_s"])
+        for k in KEYS:
+            assert float((out[k][t].cpu() - ref[k][0]).abs().max()) <= TOL[k], (t, k)
+
+
 def test_three_chains_by_knob(monkeypatch):
     """EAMM_PASS_CHAINS=3: 64 frames as 22 + 21 + 21."""
     st = state()
