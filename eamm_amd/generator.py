@@ -15,7 +15,9 @@ Whenever gradients are enabled and anything that reaches the output requires one
 ``forward`` is the composition of differentiable HIP operators of ``train_graph`` (batch statistics in ``.train()``, running
 statistics in ``.eval()``) and its outputs carry the graph, exactly where the reference's would.  Under ``torch.no_grad()``
 (demo.py:195) it is the graph-free engine: the folded fast path in ``.eval()``, the resumable batch-statistics pass in
-``.train()``.  An output is never silently detached.
+``.train()``.  ``forward`` never returns a silently detached output.  (The clip interface below -- ``encode_source`` /
+``forward_frames`` and everything built on it -- is the INFERENCE path by contract: it has no reference counterpart that could
+carry a graph, always runs graph-free, and refuses an input that requires a gradient rather than detaching it.)
 
 Beyond the reference interface the module exposes the two halves of forward separately
 (``encode_source`` / ``forward_frames``) so that a clip can reuse the frame-invariant source
@@ -408,11 +410,24 @@ class OcclusionAwareGenerator(_Tracked, nn.Module):
         return {k: out[k] for k in ("mask", "sparse_deformed", "occlusion_map", "deformed", "prediction") if k in out}
 
     # -- the reference contract -----------------------------------------------------------------------
+    def _any_parameter_requires_grad(self) -> bool:
+        """``any(p.requires_grad ...)`` cached under the structure epoch + the flags themselves (``requires_grad_()`` changes
+        neither a version counter nor the structure: the flags are re-read, which is a tuple compare of ~200 booleans)."""
+        ps = [t for t in (store[key] for store, key, _ in self._tensor_slots()) if isinstance(t, nn.Parameter)]
+        return any(p.requires_grad for p in ps)
+
     def _wants_graph(self, source_image, kp_driving, kp_source) -> bool:
         if not torch.is_grad_enabled():
             return False
         tensors = [source_image] + [v for kp in (kp_driving, kp_source) if kp for v in kp.values() if torch.is_tensor(v)]
-        return any(t.requires_grad for t in tensors) or any(p.requires_grad for p in self.parameters())
+        return any(t.requires_grad for t in tensors) or self._any_parameter_requires_grad()
+
+    @staticmethod
+    def _refuse_grad_inputs(what, *tensors):
+        """The clip interface is graph-free by contract; an input that asks for a gradient would be silently detached."""
+        if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
+            raise RuntimeError(f"eamm_amd.OcclusionAwareGenerator.{what} is the graph-free inference path: an input requires a "
+                               "gradient, which it cannot carry -- call forward() for a differentiable pass, or detach the input")
 
     def forward(self, source_image, kp_driving, kp_source):
         """Reference generator.py:59-97: batch of independent (source, kp_source, kp_driving) triples.  In ``.train()`` mode
@@ -477,8 +492,12 @@ class OcclusionAwareGenerator(_Tracked, nn.Module):
         return {k: out[k] for k in ("mask", "sparse_deformed", "occlusion_map", "deformed", "prediction") if k in out}
 
     # -- clip interface: encoder hoisted out of the frame loop ------------------------------------------
-    @torch.no_grad()
     def encode_source(self, source_image: torch.Tensor, max_frames: Optional[int] = None) -> Engine:
+        self._refuse_grad_inputs("encode_source", source_image)
+        with torch.no_grad():
+            return self._encode_source(source_image, max_frames)
+
+    def _encode_source(self, source_image: torch.Tensor, max_frames: Optional[int] = None) -> Engine:
         if self.training:
             raise RuntimeError("the clip interface (encode_source / forward_frames) is the inference path: BatchNorm uses "
                                "running statistics (sync_batchnorm/batchnorm.py:48-53); call .eval() as demo.py:105 does")
@@ -488,12 +507,13 @@ class OcclusionAwareGenerator(_Tracked, nn.Module):
         self._src_ref = None   # the engine's cache no longer belongs to forward()'s last source
         return e
 
-    @torch.no_grad()
     def forward_frames(self, kp_driving: Dict[str, torch.Tensor], kp_source: Dict[str, torch.Tensor],
                        outputs: Iterable[str] = ("prediction",), uint8_frames: bool = False):
+        self._refuse_grad_inputs("forward_frames", *kp_driving.values(), *kp_source.values())
         if self._engine is None or self._engine.ns_cached < 1:
             raise RuntimeError("call encode_source(source_image) first")
-        return self._engine.forward_frames(kp_driving, kp_source, outputs=outputs, uint8_frames=uint8_frames)
+        with torch.no_grad():
+            return self._engine.forward_frames(kp_driving, kp_source, outputs=outputs, uint8_frames=uint8_frames)
 
     @property
     def engine(self) -> Optional[Engine]:

@@ -106,3 +106,17 @@ def test_tensor_slots_follow_structural_changes():
     ids = set(twin._weights_version()[:len(v2) // 2])
     assert ids <= {id(t) for t in list(twin.parameters()) + list(twin.buffers())}
     assert not ids & set(gen._weights_version()[:len(v2) // 2])      # the copy reads ITS tensors, not the original's
+
+
+def test_clip_interface_refuses_inputs_that_require_grad():
+    """encode_source / forward_frames are the graph-free inference path; an input that asks for a gradient is refused
+    (forward() is the differentiable entry) instead of being detached silently."""
+    from eamm_amd import OcclusionAwareGenerator, tiny_config
+    gen = OcclusionAwareGenerator(**tiny_config()).eval()
+    with pytest.raises(RuntimeError, match="graph-free inference path"):
+        gen.encode_source(torch.zeros(1, 3, 64, 64, requires_grad=True))
+    kp = {"value": torch.zeros(1, 10, 2)}
+    with pytest.raises(RuntimeError, match="graph-free inference path"):
+        gen.forward_frames({"value": torch.zeros(1, 10, 2, requires_grad=True)}, kp)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="encode_source"):     # under no_grad the flag is moot: the normal checks apply
+        gen.forward_frames({"value": torch.zeros(1, 10, 2, requires_grad=True)}, kp)
