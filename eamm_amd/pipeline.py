@@ -86,6 +86,8 @@ def animate_from_features(generator, kp_detector, deconv_tail, kp_detector_a, so
     if lstm_features.dim() == 3 and lstm_features.shape[0] == 1:
         lstm_features = lstm_features[0]
     T = lstm_features.shape[0]
+    if T < 1:
+        raise ValueError("animate_from_features: the clip has no frames (lstm_features is empty)")
     kp_source = _kp_only(kp_detector(src))                                                   # demo.py:206
     a, b = shard_bounds(T, world, rank)
     raw = driving_keypoints(deconv_tail, kp_detector_a, lstm_features[a:b].to(dev), batch=front_batch) if b > a else None   # demo.py:212-219
