@@ -10,17 +10,16 @@
 //     alpha(c) = 1 / (1 + (1 / (2 pi c)) / te),  te = 1 / freq
 // with x = input * scale and output s / scale, every step in float32 in the reference's operation order (separate multiplies
 // and adds: no fused multiply-add, so the result follows the host filter to rounding).  A frame's 60 values are loaded
-// sixteen frames ahead of the dependent chain (the loads do not depend on it), so the walk costs the chain's ~100 cycles per
-// frame, not a memory round trip per frame: 2048 frames in ~0.15 ms where the host loop takes 600 ms.
+// sixteen frames ahead of the dependent chain (the loads do not depend on it), so the walk costs the chain's ~40 dependent
+// float operations per frame (two correctly rounded reciprocals among them: ~380 cycles), not a memory round trip per frame:
+// 2048 frames in 0.32 ms (rocprofv3, profiles/r05_e2e_kernel_trace_stats.txt) where the host loop takes 600 ms.
 #include "kernels.h"
 
 namespace eamm {
 
-namespace {
-
 constexpr int EURO_AHEAD = 16;
 
-__device__ __forceinline__ float euro_alpha(float cutoff, float inv_te) {
+static __device__ __forceinline__ float euro_alpha(float cutoff, float inv_te) {
     // torch evaluates 1.0 / (2 * np.pi * cutoff) as reciprocal(cutoff * float(2 pi)) and tau / te as tau * (1 / te)
     const float tau = __frcp_rn(__fmul_rn(cutoff, 6.283185307179586f));
     return __frcp_rn(__fadd_rn(1.0f, __fmul_rn(tau, inv_te)));
@@ -58,8 +57,6 @@ __global__ __launch_bounds__(64) void one_euro_kernel(const float* __restrict__ 
         }
     }
 }
-
-}  // namespace
 
 hipError_t one_euro_launch(const float* x, int T, int E, float mincutoff, float beta, float dcutoff, float freq, float scale,
                            float* out, hipStream_t stream) {

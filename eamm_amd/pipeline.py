@@ -18,7 +18,7 @@ LSTM features in, the clip's frames in host memory out -- every step of the refe
 The emotion network (``emo_detector``) and the audio LSTM are outside this path (out of scope / "stays in
 PyTorch-ROCm"): their outputs are inputs here -- ``lstm_features`` [T,256] and, optionally, ``emo_driving``.
 Under torch.distributed BOTH loops shard by frames: rank 0's inputs are broadcast (header + one payload), every rank runs the
-detectors on its frames, one all-gather gives every rank the whole key-point sequence (the One-Euro recurrence needs it; 0.2 ms,
+detectors on its frames, one all-gather gives every rank the whole key-point sequence (the One-Euro recurrence needs it; 0.7 ms,
 computed redundantly), and every rank animates its shard from its own encoding of the source -- three collectives per clip.
 """
 from __future__ import annotations
@@ -78,7 +78,7 @@ def animate_from_features(generator, kp_detector, deconv_tail, kp_detector_a, so
     if distributed:
         # every rank gets the clip's INPUTS (source image, LSTM features, emotion displacements: 2.9 MB for 2048 frames at
         # 256x256) in two broadcasts -- fixed header + one payload -- and runs the front end on ITS frames; one all-gather of the
-        # raw key points (T x 60 floats) later every rank holds the whole sequence, smooths and normalises it (0.2 ms, redundant)
+        # raw key points (T x 60 floats) later every rank holds the whole sequence, smooths and normalises it (under 2 ms, redundant)
         # and animates its shard.  Three collectives per clip; nothing of the front end's 23 us per frame stays serial.
         source_image, lstm_features, emo_driving = _broadcast_inputs(source_image, lstm_features, emo_driving, dev, group)
         mark("broadcast_ms")
