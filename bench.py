@@ -544,7 +544,9 @@ def main():
         fence()
         # verification of what was delivered: the host frames of the timed pass == the instrumented pass (deterministic), and on
         # rank 0 three frames recomputed by the contract handle from the harness's own normalised key points, to one uint8 level
-        e_ok = bool(torch.equal(e_frames, e_frames2)) and e_frames.dtype == torch.uint8 and e_frames.is_pinned()
+        # (the timed pass STREAMS -- front end beside the generator --, the instrumented one runs the phases one after the other)
+        e_same = int((e_frames.to(torch.int16) - e_frames2.to(torch.int16)).abs().max()) if e_frames.numel() else 0
+        e_ok = e_same <= 1 and e_frames.dtype == torch.uint8 and e_frames.is_pinned()
         e_worst = None
         if rank == 0 and e_frames.shape[0]:
             a2, b2 = e_span
@@ -560,7 +562,10 @@ def main():
             e2e = {"frames": T2, "frames_per_s": round(T2 / dt_e2e, 2), "seconds": round(dt_e2e, 4), "n_gpus": world, "batch": CB2,
                    "phases_ms_rank0": {k: round(v, 3) for k, v in e_ph.items()},
                    "delivered": "uint8 [T,H,W,3] frames in pinned host memory (non_blocking copies on a copy stream, overlapped with the next batch)",
-                   "host_bytes": int(e_frames.numel()), "verify": {"ok": True, "uint8_levels_vs_contract_plan": e_worst},
+                   "host_bytes": int(e_frames.numel()),
+                   "verify": {"ok": True, "uint8_levels_vs_contract_plan": e_worst, "uint8_levels_streamed_vs_phased": e_same},
+                   "streamed": "timed pass: the detectors / smoothing / normalisation of later frames run on their own stream beside the "
+                               "generator of earlier ones (animate_from_features stream=True); phases_ms come from a second, un-streamed pass",
                    "timed": "LSTM features + source on the device -> KPDetector, DeconvTail + KPDetector_a, One-Euro smoothing, "
                             "normalize_kp (relative, adapt_movement_scale), source encode, generator, D2H of every frame; max over ranks",
                    "workload": f"make_animation_smooth (reference demo.py:194-282) on a {T2}-frame clip at {S}x{S}, synthetic LSTM features and weights"}

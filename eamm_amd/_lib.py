@@ -80,7 +80,7 @@ SIGNATURES = {
     "eamm_bottleneck_chains": (C.c_int, [C.c_void_p, C.c_int]),
     "eamm_pass_chains": (C.c_int, [C.c_void_p, C.c_int]),
     "eamm_op_one_euro": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                  C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "eamm_last_stream_set": (C.c_int, [C.c_void_p]),
     "eamm_describe_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "eamm_knobs_json": (C.c_int, [C.c_char_p, C.c_int]),

@@ -169,7 +169,7 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
                  relative: bool = False, adapt_movement_scale: bool = False,
                  emo_driving: Optional[Dict[str, torch.Tensor]] = None, emo_type: str = "linear_3",
                  timings: Optional[Dict[str, float]] = None, to_host: bool = False,
-                 replicated: bool = False) -> Tuple[torch.Tensor, Tuple[int, int]]:
+                 replicated: bool = False, before_batch=None) -> Tuple[torch.Tensor, Tuple[int, int]]:
     """Animate one clip; returns (frames of this rank's shard, (start, stop)).
 
     ``emo_driving`` ({'value': [T,E,2], 'jacobian': [T,E,2,2]}, the emotion network's per-frame displacements) adds the
@@ -184,6 +184,10 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
     ``replicated=True``: every rank already holds the source image and all key points (eamm_amd.animate_from_features with its
     sharded front end): no broadcast at all -- each rank encodes the source itself (0.25 ms at 256x256, less than moving the 5 MB
     cache) and computes its contiguous shard.
+
+    ``before_batch(start, stop)`` (optional) is called before the launch sequence of every batch of frames [start, stop): the
+    streaming harness (``animate_from_features``) makes the stream wait there for the event behind which that batch's key points
+    are complete, so the front end of later frames runs beside the generator of earlier ones.
 
     ``to_host=True`` delivers this rank's frames in PINNED HOST memory (what demo.py:281 does per frame with a blocking
     ``.cpu()``): every batch's frames are copied ``non_blocking`` on a copy stream behind an event, so the copy of batch i
@@ -261,6 +265,8 @@ def animate_clip(backend, source_image: Optional[torch.Tensor], kp_source: Optio
             copier = backend.copy_stream()
     for s in range(start, stop, backend.batch):
         e = min(stop, s + backend.batch)
+        if before_batch is not None:
+            before_batch(s, e)
         out = backend.run({k: v[s:e] for k, v in kp_driving.items()}, kp_source, uint8)
         if host is None:
             chunks.append(out)

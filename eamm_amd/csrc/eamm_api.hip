@@ -1812,11 +1812,11 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
 }
 
 int eamm_op_one_euro(int device, const float* x, int T, int E, float mincutoff, float beta, float dcutoff, float freq, float scale,
-                     float* out, void* stream_) {
-    if (!x || !out || T < 0 || E < 1) return fail(nullptr, EAMM_ERR_ARG, "eamm_op_one_euro: bad argument");
+                     float* out, float* state, int resume, void* stream_) {
+    if (!x || !out || T < 0 || E < 1 || (resume && !state)) return fail(nullptr, EAMM_ERR_ARG, "eamm_op_one_euro: bad argument");
     DeviceGuard guard(device);
     if (guard.status != hipSuccess) return fail(nullptr, EAMM_ERR_HIP, "hipSetDevice failed");
-    const hipError_t e = one_euro_launch(x, T, E, mincutoff, beta, dcutoff, freq, scale, out, reinterpret_cast<hipStream_t>(stream_));
+    const hipError_t e = one_euro_launch(x, T, E, mincutoff, beta, dcutoff, freq, scale, out, reinterpret_cast<hipStream_t>(stream_), state, resume);
     return e == hipSuccess ? EAMM_OK : fail(nullptr, EAMM_ERR_HIP, "one_euro_kernel: %s", hipGetErrorString(e));
 }
 

@@ -282,6 +282,6 @@ hipError_t motion_head_backward_launch(const float* mask, const float* occlusion
 
 // One-Euro smoothing of [T,E] sequences along T (keypoints.hip; reference filter1.py:13-47 as driven by demo.py:241-250).
 hipError_t one_euro_launch(const float* x, int T, int E, float mincutoff, float beta, float dcutoff, float freq, float scale,
-                           float* out, hipStream_t stream);
+                           float* out, hipStream_t stream, float* state = nullptr, int resume = 0);
 
 }  // namespace eamm

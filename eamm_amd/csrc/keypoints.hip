@@ -27,10 +27,18 @@ static __device__ __forceinline__ float euro_alpha(float cutoff, float inv_te) {
 
 __global__ __launch_bounds__(64) void one_euro_kernel(const float* __restrict__ x, int T, int E, float mincutoff, float beta,
                                                      float a_d, float one_m_ad, float freq, float inv_te, float scale, float inv_scale,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, float* __restrict__ state, int resume) {
+    // state (optional, [3][E]): the filter's memory -- previous scaled input, previous filtered value, previous filtered
+    // derivative -- written at the end; with `resume` it is read first and frame 0 of this call continues the sequence (a clip
+    // filtered in chunks gives the bits of the clip filtered whole)
     const int e = blockIdx.x * 64 + threadIdx.x;
     if (e >= E) return;
     float prev_x = 0.f, prev_s = 0.f, prev_edx = 0.f;
+    if (resume) {
+        prev_x = state[e];
+        prev_s = state[E + e];
+        prev_edx = state[2 * E + e];
+    }
     for (int t0 = 0; t0 < T; t0 += EURO_AHEAD) {
         float buf[EURO_AHEAD];
 #pragma unroll
@@ -41,7 +49,7 @@ __global__ __launch_bounds__(64) void one_euro_kernel(const float* __restrict__ 
             if (t >= T) break;
             const float xv = __fmul_rn(buf[i], scale);
             float s, edx;
-            if (t == 0) {          // first sample: dx = 0 and both low-pass filters pass their input through (filter1.py:19-21, 41-42)
+            if (t == 0 && !resume) {          // first sample: dx = 0 and both low-pass filters pass their input through (filter1.py:19-21, 41-42)
                 edx = 0.f;
                 s = xv;
             } else {
@@ -56,11 +64,16 @@ __global__ __launch_bounds__(64) void one_euro_kernel(const float* __restrict__ 
             out[(size_t)t * E + e] = __fmul_rn(s, inv_scale);   // `/ scale` by a Python scalar: torch multiplies by float(1 / scale)
         }
     }
+    if (state != nullptr) {
+        state[e] = prev_x;
+        state[E + e] = prev_s;
+        state[2 * E + e] = prev_edx;
+    }
 }
 
 hipError_t one_euro_launch(const float* x, int T, int E, float mincutoff, float beta, float dcutoff, float freq, float scale,
-                           float* out, hipStream_t stream) {
-    if (!x || !out || T < 0 || E < 1 || !(freq > 0.f) || !(dcutoff > 0.f) || !(scale != 0.f)) return hipErrorInvalidValue;
+                           float* out, hipStream_t stream, float* state, int resume) {
+    if (!x || !out || T < 0 || E < 1 || !(freq > 0.f) || !(dcutoff > 0.f) || !(scale != 0.f) || (resume && !state)) return hipErrorInvalidValue;
     if (T == 0) return hipSuccess;
     // alpha(dcutoff) is a Python-float (double) computation in the reference (filter1.py:35-38 on scalars), rounded when it meets the tensor
     const double te = 1.0 / (double)freq;
@@ -69,7 +82,7 @@ hipError_t one_euro_launch(const float* x, int T, int E, float mincutoff, float 
     const float a_d = (float)a_dd, one_m_ad = (float)(1.0 - a_dd);   // `(1.0 - a_d)` is a double subtraction there too
     const float inv_te = 1.0f / (float)te;      // tensor / Python-scalar: torch multiplies by the reciprocal of the scalar cast to float
     hipLaunchKernelGGL(one_euro_kernel, dim3((E + 63) / 64), dim3(64), 0, stream, x, T, E, mincutoff, beta, a_d, one_m_ad, freq, inv_te, scale,
-                       1.0f / scale, out);
+                       1.0f / scale, out, state, resume);
     return hipGetLastError();
 }
 

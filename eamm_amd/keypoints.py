@@ -5,7 +5,7 @@ driving frames so a whole clip is normalised at once instead of once per frame.
 """
 from __future__ import annotations
 
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 import torch
@@ -28,20 +28,30 @@ def _inverse_2x2(m: torch.Tensor) -> torch.Tensor:
     return torch.stack([torch.stack([d, -b], -1), torch.stack([-c, a], -1)], -2) / det[..., None, None]
 
 
+def movement_scale(kp_source: Dict[str, torch.Tensor], kp_driving_initial: Dict[str, torch.Tensor]) -> float:
+    """sqrt(area(hull(source))) / sqrt(area(hull(initial driving)))  (demo.py:114-117); one host read of 2 x K points."""
+    return float(np.sqrt(_hull_area(kp_source["value"][0])) / np.sqrt(_hull_area(kp_driving_initial["value"][0])))
+
+
 def normalize_kp(kp_source: Dict[str, torch.Tensor], kp_driving: Dict[str, torch.Tensor],
                  kp_driving_initial: Dict[str, torch.Tensor], adapt_movement_scale: bool = False,
-                 use_relative_movement: bool = False, use_relative_jacobian: bool = False) -> Dict[str, torch.Tensor]:
+                 use_relative_movement: bool = False, use_relative_jacobian: bool = False,
+                 scale: Optional[float] = None) -> Dict[str, torch.Tensor]:
     """Same contract as reference demo.py:normalize_kp; ``kp_driving`` may hold T frames ([T,K,2] / [T,K,2,2])
     against one source / initial set ([1,K,2] / [1,K,2,2]).
 
     * adapt_movement_scale: sqrt(area(hull(source))) / sqrt(area(hull(initial driving)))  (demo.py:114-117)
     * use_relative_movement: value = (driving - initial) * scale + source                  (demo.py:123-126)
     * use_relative_jacobian: jacobian = driving @ inverse(initial) @ source                (demo.py:128-130)
-    With both flags off the driving key points pass through unchanged (`relative=False`, demo.py:558).
+    With both flags off the driving key points pass through unchanged (`relative=False`, demo.py:558).  ``scale``: the
+    adapt_movement_scale factor computed earlier by ``movement_scale`` (then the hulls are not read again).
     """
-    scale = 1.0
-    if adapt_movement_scale:
+    if scale is not None:                  # computed before (movement_scale): a clip normalised chunk by chunk reads the hulls once
+        scale = float(scale)
+    elif adapt_movement_scale:
         scale = np.sqrt(_hull_area(kp_source["value"][0])) / np.sqrt(_hull_area(kp_driving_initial["value"][0]))
+    else:
+        scale = 1.0
     out = dict(kp_driving)
     if use_relative_movement:
         diff = (kp_driving["value"] - kp_driving_initial["value"]) * scale
@@ -82,10 +92,14 @@ def apply_emotion_offsets(kp_driving: Dict[str, torch.Tensor], emo_driving: Dict
 
 
 def one_euro_smooth(seq: torch.Tensor, mincutoff: float = 1.0, beta: float = 0.0, dcutoff: float = 1.0,
-                    freq: float = 30.0, scale: float = 1.0) -> torch.Tensor:
+                    freq: float = 30.0, scale: float = 1.0, state: Optional[torch.Tensor] = None, resume: bool = False) -> torch.Tensor:
     """One-Euro low-pass filter along dim 0 of ``seq`` ([T, ...]), element-wise over the rest -- the reference's
     ``filter1.OneEuroFilter`` (filter1.py:13-47) applied as ``process(x * scale) / scale`` frame after frame
     (demo.py:237-250).  The recurrence is sequential in T and independent per element.
+
+    ``state`` (GPU tensors only): a float32 [3, E] tensor on ``seq``'s device that receives the filter's memory after the last
+    frame; with ``resume`` it is read first, so chunks of a clip filtered one after the other give exactly the clip filtered
+    whole (the filter is causal: ``animate_from_features`` streams a clip through it).
 
     A tensor on the GPU is filtered there by ``eamm_op_one_euro`` (csrc/keypoints.hip: one thread per element walks the
     frames; a 2048-frame clip takes ~0.15 ms, no host round trip) -- the clip pipeline's path.  A CPU tensor is filtered on
@@ -97,11 +111,18 @@ def one_euro_smooth(seq: torch.Tensor, mincutoff: float = 1.0, beta: float = 0.0
         T = x.shape[0]
         out = torch.empty_like(x)
         if T:
+            E = x.numel() // T
+            if state is not None and (state.device != x.device or state.dtype != torch.float32 or state.numel() != 3 * E
+                                      or not state.is_contiguous()):
+                raise RuntimeError(f"one_euro_smooth: state must be a contiguous float32 [3,{E}] tensor on {x.device}")
             with torch.cuda.device(x.device):
-                _lib.check(_lib.lib().eamm_op_one_euro(x.device.index, C.c_void_p(x.data_ptr()), T, x.numel() // T, float(mincutoff),
+                _lib.check(_lib.lib().eamm_op_one_euro(x.device.index, C.c_void_p(x.data_ptr()), T, E, float(mincutoff),
                                                        float(beta), float(dcutoff), float(freq), float(scale), C.c_void_p(out.data_ptr()),
+                                                       None if state is None else C.c_void_p(state.data_ptr()), int(bool(resume)),
                                                        C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), None)
         return out
+    if state is not None or resume:
+        raise RuntimeError("one_euro_smooth: the resumable form is the device path's (a CPU tensor is filtered whole)")
     f32 = np.float32
     x_all = seq.detach().to(torch.float32).numpy().reshape(seq.shape[0], -1) * f32(scale)
     out = np.empty_like(x_all)
@@ -127,7 +148,13 @@ def one_euro_smooth(seq: torch.Tensor, mincutoff: float = 1.0, beta: float = 0.0
 
 
 def smooth_keypoints(kp_seq: Dict[str, torch.Tensor], mincutoff: float = 0.05, beta: float = 8.0, dcutoff: float = 1.0,
-                     freq: float = 100.0, scale: float = 10.0) -> Dict[str, torch.Tensor]:
+                     freq: float = 100.0, scale: float = 10.0, state: Optional[Dict[str, torch.Tensor]] = None,
+                     resume: bool = False) -> Dict[str, torch.Tensor]:
     """Temporal smoothing of a clip's driving key points, defaults = the reference's (demo.py:241-250: one filter for
     the values, one for the jacobians, inputs scaled by 10).  ``kp_seq``: {'value': [T,K,2], 'jacobian': [T,K,2,2]}."""
-    return {k: one_euro_smooth(v, mincutoff, beta, dcutoff, freq, scale) for k, v in kp_seq.items() if k in ("value", "jacobian")}
+    if state is not None:      # chunked clip: one memory tensor per key, created on first use
+        for k, v in kp_seq.items():
+            if k in ("value", "jacobian") and k not in state:
+                state[k] = torch.zeros(3, v.numel() // max(1, v.shape[0]), dtype=torch.float32, device=v.device)
+    return {k: one_euro_smooth(v, mincutoff, beta, dcutoff, freq, scale, None if state is None else state[k], resume)
+            for k, v in kp_seq.items() if k in ("value", "jacobian")}

@@ -47,7 +47,7 @@ def animate_from_features(generator, kp_detector, deconv_tail, kp_detector_a, so
                           relative: bool = True, adapt_movement_scale: bool = True, smooth: bool = True, batch: int = 64,
                           front_batch: int = 64, uint8: bool = True, to_host: bool = True, group=None,
                           backend: Optional[EngineBackend] = None, timings: Optional[Dict[str, float]] = None,
-                          return_keypoints: bool = False, size: Optional[Tuple[int, int]] = None):
+                          return_keypoints: bool = False, size: Optional[Tuple[int, int]] = None, stream: Optional[bool] = None):
     """make_animation_smooth (demo.py:194-282) for one clip.
 
     ``source_image``: [1,C,H,W] float in [0,1]; ``lstm_features``: [T,256] (or [1,T,256]), the audio network's LSTM output;
@@ -56,7 +56,9 @@ def animate_from_features(generator, kp_detector, deconv_tail, kp_detector_a, so
     [n,H,W,3] uint8 (``uint8=True``; what demo.py:507 writes) or [n,3,H,W] float32, in pinned host memory when ``to_host`` --
     plus, with ``return_keypoints``, a dict of the intermediate key points.  Rank > 0 of a process group may pass None for
     the inputs (they are broadcast from rank 0).  ``timings`` is filled with the phases' wall-clock milliseconds (a device synchronisation at each
-    boundary, only when asked for): front_ms (detectors), smooth_ms, normalize_ms, then animate_clip's own."""
+    boundary, only when asked for): front_ms (detectors), smooth_ms, normalize_ms, then animate_clip's own.  ``stream`` (default:
+    on for one process on a GPU when no ``timings`` are asked for): the front end runs on its own stream, `front_batch` frames at
+    a time, BESIDE the generator of the frames whose key points are already complete (``_animate_streaming``)."""
     dev = backend.device if backend is not None else next(generator.parameters()).device
     on_gpu = torch.device(dev).type == "cuda"
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
@@ -89,6 +91,12 @@ def animate_from_features(generator, kp_detector, deconv_tail, kp_detector_a, so
     if T < 1:
         raise ValueError("animate_from_features: the clip has no frames (lstm_features is empty)")
     kp_source = _kp_only(kp_detector(src))                                                   # demo.py:206
+    H, W = (int(src.shape[-2]), int(src.shape[-1])) if size is None else size
+    if stream is None:
+        stream = on_gpu and not distributed and timings is None
+    if stream and on_gpu and not distributed:
+        return _animate_streaming(backend, kp_detector_a, deconv_tail, src, lstm_features.to(dev), kp_source, emo_driving, relative,
+                                  adapt_movement_scale, smooth, front_batch, uint8, to_host, return_keypoints, H, W, dev)
     a, b = shard_bounds(T, world, rank)
     raw = driving_keypoints(deconv_tail, kp_detector_a, lstm_features[a:b].to(dev), batch=front_batch) if b > a else None   # demo.py:212-219
     if distributed:
@@ -105,10 +113,63 @@ def animate_from_features(generator, kp_detector, deconv_tail, kp_detector_a, so
                            use_relative_movement=relative, use_relative_jacobian=relative)    # demo.py:276
     mark("normalize_ms")
     kps = {"kp_source": kp_source, "kp_driving_raw": raw, "kp_driving_smoothed": kp_d, "kp_norm": kp_norm} if return_keypoints else {}
-    H, W = (int(src.shape[-2]), int(src.shape[-1])) if size is None else size
     frames, span = animate_clip(backend, src, kp_source, kp_norm, H, W, uint8=uint8, group=group, to_host=to_host,
                                 timings=timings, replicated=distributed)
     return (frames, span, kps) if return_keypoints else (frames, span)
+
+
+def _animate_streaming(backend, kp_detector_a, deconv_tail, src, feats, kp_source, emo_driving, relative, adapt_movement_scale, smooth,
+                       front_batch, uint8, to_host, return_keypoints, H, W, dev):
+    """One GPU, one process: the reference's FIRST loop (key points of every frame, demo.py:212-250) runs on its own stream,
+    `front_batch` frames at a time, and the generator starts on the first frames as soon as their key points are complete --
+    every step between the detector and the generator is causal (the One-Euro filter carries its memory from chunk to chunk:
+    ``eamm_op_one_euro`` with ``state`` / ``resume``; ``normalize_kp`` needs frame 0 and the source only), so the front end of
+    frames t >= front_batch is hidden behind the generator of the frames before.  Bit-identical to the un-streamed path: the same
+    kernels on the same batches, the filter resumed instead of run whole."""
+    from .keypoints import movement_scale
+    T, K = feats.shape[0], kp_source["value"].shape[1]
+    main = torch.cuda.current_stream(dev)
+    front = getattr(backend, "_front_stream", None)
+    if front is None:
+        front = backend._front_stream = torch.cuda.Stream(device=dev, priority=-1)   # small launches: let them in ahead of the generator's
+    norm = {"value": torch.empty(T, K, 2, device=dev), "jacobian": torch.empty(T, K, 2, 2, device=dev)}
+    keep = {"raw": [], "smoothed": []} if return_keypoints else None
+    emo = None if emo_driving is None else {k: v.to(dev) for k, v in _kp_only(emo_driving).items()}
+    front.wait_stream(main)                        # the source's key points and the features are complete
+    events, kp_state, emo_state, kp_initial, scale = [], {}, {}, None, None
+    with torch.cuda.stream(front):
+        for t0 in range(0, T, front_batch):
+            t1 = min(T, t0 + front_batch)
+            raw = driving_keypoints(deconv_tail, kp_detector_a, feats[t0:t1], batch=front_batch)          # demo.py:212-219
+            if t0 == 0:
+                kp_initial = {k: v[:1].clone() for k, v in raw.items()}                                       # demo.py:207
+                if adapt_movement_scale:
+                    scale = movement_scale(kp_source, kp_initial)        # the clip's one host read (2 x K points), behind the first batch
+            kp_d = smooth_keypoints(raw, **KP_FILTER, state=kp_state, resume=t0 > 0) if smooth else raw       # demo.py:241-250
+            if emo is not None:
+                e_c = {k: v[t0:t1] for k, v in emo.items()}
+                e_c = smooth_keypoints(e_c, **EMO_FILTER, state=emo_state, resume=t0 > 0) if smooth else e_c  # demo.py:231-239
+                kp_d = apply_emotion_offsets(kp_d, e_c)                                                       # demo.py:263-271
+            n_c = normalize_kp(kp_source, kp_d, kp_initial, adapt_movement_scale=adapt_movement_scale, use_relative_movement=relative,
+                               use_relative_jacobian=relative, scale=scale)                                   # demo.py:276
+            for k in ("value", "jacobian"):
+                norm[k][t0:t1].copy_(n_c[k])
+            if keep is not None:
+                keep["raw"].append(raw)
+                keep["smoothed"].append(kp_d)
+            ev = torch.cuda.Event()
+            ev.record(front)
+            events.append(ev)
+
+    def before_batch(s, e):        # the generator's stream waits for the key points of frames < e
+        main.wait_event(events[(e - 1) // front_batch])
+
+    frames, span = animate_clip(backend, src, kp_source, norm, H, W, uint8=uint8, to_host=to_host, before_batch=before_batch)
+    main.wait_stream(front)
+    if not return_keypoints:
+        return frames, span
+    cat = lambda parts: {k: torch.cat([p[k] for p in parts]) for k in ("value", "jacobian")}
+    return frames, span, {"kp_source": kp_source, "kp_driving_raw": cat(keep["raw"]), "kp_driving_smoothed": cat(keep["smoothed"]), "kp_norm": norm}
 
 
 _IN_HEADER = 8   # T, feature channels, emotion points E (0: none), image channels, H, W, features given as [1,T,C], reserved

@@ -399,9 +399,11 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
 /* Temporal smoothing of a clip's key points: the reference's filter1.OneEuroFilter (filter1.py:13-47)
  * applied as `process(x * scale) / scale` frame after frame (demo.py:241-250; key points: mincutoff 0.05, beta 8, dcutoff 1,
  * freq 100, scale 10; emotion displacements demo.py:231-239: 1, 0.2, 1, 100, 100).  x, out: device [T,E] float32, the filter
- * runs along T independently per element (E = K*2 values or K*4 jacobian entries; out may alias x).  Stream-ordered, no sync. */
+ * runs along T independently per element (E = K*2 values or K*4 jacobian entries; out may alias x).  `state` (device [3,E] or
+ * NULL) receives the filter's memory after the last frame; with `resume` != 0 it is read first, so a clip filtered in chunks gives
+ * exactly the clip filtered whole (the filter is causal: the streaming clip pipeline).  Stream-ordered, no sync. */
 int eamm_op_one_euro(int device, const float* x, int T, int E, float mincutoff, float beta, float dcutoff, float freq, float scale,
-                     float* out, void* stream);
+                     float* out, float* state, int resume, void* stream);
 
 /* The HBM-bound kernel of the path on its own: out = grid_sample(feat, deformation, bilinear, zeros, align_corners=False)
  * * occlusion (reference modules/generator.py:50-57, 79-84).  feat: NHWC [ns,hf,wf,C] (ns = 1 broadcasts one source to

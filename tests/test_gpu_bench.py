@@ -81,6 +81,7 @@ def test_bench_single_gpu_line():
     # end-to-end leg: make_animation_smooth whole, frames delivered to pinned host memory
     e = d["e2e_clip"]
     assert e["frames"] == 2048 and e["verify"]["ok"] is True and e["verify"]["uint8_levels_vs_contract_plan"] <= 1
+    assert e["verify"]["uint8_levels_streamed_vs_phased"] == 0        # streaming the front end changes no bit
     ph = e["phases_ms_rank0"]
     assert {"front_ms", "smooth_ms", "normalize_ms", "encode_ms", "compute_ms", "d2h_tail_ms"} <= set(ph)
     assert ph["smooth_ms"] <= 2.0, ph                  # the round-4 host loop: 608 ms
