@@ -19,6 +19,11 @@ namespace eamm {
 
 constexpr int EURO_AHEAD = 16;
 
+// hipcc contracts a * b + c into a fused multiply-add by default, and HIP's __fmul_rn / __fadd_rn are plain operators to it: left
+// alone, WHERE it fuses depends on the position in the unrolled walk (steps are paired for v_pk_mul_f32; one of a pair gets the fused
+// form) -- a clip filtered in chunks then differs from the clip filtered whole in the last bit (measured: cuts at odd frames), and
+// from the reference's separately rounded operations.  THIS FILE IS COMPILED WITH -ffp-contract=off (csrc/Makefile).
+
 static __device__ __forceinline__ float euro_alpha(float cutoff, float inv_te) {
     // torch evaluates 1.0 / (2 * np.pi * cutoff) as reciprocal(cutoff * float(2 pi)) and tau / te as tau * (1 / te)
     const float tau = __frcp_rn(__fmul_rn(cutoff, 6.283185307179586f));
