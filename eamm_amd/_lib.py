@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeamm_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4   # round 5: record entries (plan, knobs, stream set, flops total), eamm_op_one_euro with state / resume
 
 EAMM_OK = 0
 ERR_ARG, ERR_STATE, ERR_KEY, ERR_HIP, ERR_NUMERIC = -1, -2, -3, -4, -5

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EAMM_ABI_VERSION 3
+#define EAMM_ABI_VERSION 4
 
 typedef enum eamm_status {
     EAMM_OK = 0,
