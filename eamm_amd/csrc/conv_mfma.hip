@@ -393,7 +393,7 @@ static bool knob_documented(const char* name) {
     static const char* const names[] = {"EAMM_PASS_CHAINS", "EAMM_BNECK_CHAINS", "EAMM_WINO_TILE", "EAMM_WINO_MIN_M", "EAMM_WINO4_MIN_M",
                                         "EAMM_ENC_WINO", "EAMM_FINAL_FUSED", "EAMM_FINAL_MFMA4", "EAMM_COL7", "EAMM_FIRST7",
                                         "EAMM_PRIVATE_STREAMS", "EAMM_WARP_JOINT", "EAMM_BNECK_STAGGER", "EAMM_HEAD_ROWSPLIT",
-                                        "EAMM_PATCH_POLY", "EAMM_WGRAD_WINO4", "EAMM_WGRAD_ROW", "EAMM_CONV_DEV_WINO4",
+                                        "EAMM_PATCH_POLY", "EAMM_KPA_THIN", "EAMM_WGRAD_WINO4", "EAMM_WGRAD_ROW", "EAMM_CONV_DEV_WINO4",
                                         "EAMM_WINO4_EPI_V", "EAMM_COL7_DBG", "EAMM_WINO4_VARIANT"};   // (the last three: refused / experiments build)
     for (const char* n : names)
         if (!strcmp(n, name)) return true;

@@ -18,6 +18,12 @@ struct eamm_kp_ctx : eamm::CtxBase {
     std::vector<int> enc_c, dec_c;
     std::vector<LayerSet> hg_enc, hg_dec;
     ConvLayer head;               // kp (K) + jacobian (4*njm) stacked along Cout
+    // KPDetector_a whose feature map is 32 m + 3 channels wide (the shipped 35 = block_expansion 32 + num_channels_a 3): the heads
+    // run as a 7x7 MFMA convolution over the first 32 m channels (K = 49 x 32 m instead of 49 x the next multiple of 32: 45 % fewer
+    // multiplies at 35) PLUS the thin-channel 7x7 kernel (conv7_thin.hip: K = (tap, channel) = 196) over the last three, added in
+    // the wide convolution's epilogue (`resid`).  EAMM_KPA_THIN = 0: the plain padded convolution (rounds 1-4).
+    int thin_wide = 0;            // > 0: channels of the wide part
+    float *thin_w = nullptr, *thin_x = nullptr, *thin_y = nullptr, *thin_ws = nullptr;   // [64,3,7,7] filter, [B,h,w,4] input, [B,h,w,64] output, workspace
     float* aa_w = nullptr;
     float* img_stage = nullptr;   // num_channels 1 / 2: the image zero-extended to the three planes the anti-alias kernel reads
     float *x_in = nullptr, *logits = nullptr, *partial = nullptr;
@@ -27,10 +33,12 @@ struct eamm_kp_ctx : eamm::CtxBase {
 
 namespace {
 
-int run_head(eamm_kp_ctx* c, const float* in0, const float* in1, int B, const eamm_kp_outputs* o, hipStream_t s) {
+int run_head(eamm_kp_ctx* c, const float* in0, const float* in1, int B, const eamm_kp_outputs* o, hipStream_t s,
+             const float* resid = nullptr) {
     ConvIO io{};
     io.in0 = in0;
     io.in1 = in1;
+    io.resid = resid;
     io.B = B;
     io.Hin = c->h;
     io.Win = c->w;
@@ -165,13 +173,48 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
     } else {
         // KPDetector_a: the caller's feature map already is the hourglass output (feat_c channels)
         const int cp = (c->feat_c + 31) / 32 * 32;
-        if ((rc = build_layer(c, parts, 7, c->feat_c, cp, 0, 0, &c->head))) return rc;
+        const int wide = c->feat_c - 3;
+        if (wide >= 32 && wide % 32 == 0 && env_int("EAMM_KPA_THIN", 1)) {
+            // slice every head's filter [co, feat_c, 7, 7] into its wide part (replaces the entry) and its last three input channels
+            std::vector<float> thin((size_t)64 * 3 * 49, 0.f);
+            int o0 = 0;
+            for (auto& ps : parts) {
+                auto it = c->sd.find(ps.conv + ".weight");
+                if (it == c->sd.end() || it->second.shape.size() != 4 || it->second.shape[1] != c->feat_c || it->second.shape[2] != 7 ||
+                    it->second.shape[3] != 7)
+                    return fail(c, EAMM_ERR_KEY, "state_dict entry %s.weight missing or mis-shaped (expected [*,%d,7,7])", ps.conv.c_str(), c->feat_c);
+                HostTensor& wt = it->second;
+                const int co = (int)wt.shape[0];
+                if (o0 + co > 64) return fail(c, EAMM_ERR_KEY, "kp / jacobian heads have more than 64 output channels");
+                HostTensor nw;
+                nw.shape = {co, wide, 7, 7};
+                nw.data.resize((size_t)co * wide * 49);
+                for (int o = 0; o < co; ++o) {
+                    std::copy(wt.data.begin() + (size_t)o * c->feat_c * 49, wt.data.begin() + ((size_t)o * c->feat_c + wide) * 49,
+                              nw.data.begin() + (size_t)o * wide * 49);
+                    std::copy(wt.data.begin() + ((size_t)o * c->feat_c + wide) * 49, wt.data.begin() + (size_t)(o + 1) * c->feat_c * 49,
+                              thin.begin() + (size_t)(o0 + o) * 3 * 49);
+                }
+                wt = std::move(nw);
+                o0 += co;
+            }
+            if ((rc = build_layer(c, parts, 7, wide, wide, 0, 0, &c->head))) return rc;
+            if ((rc = upload(c, &c->thin_w, thin))) return rc;
+            c->thin_wide = wide;
+        } else if ((rc = build_layer(c, parts, 7, c->feat_c, cp, 0, 0, &c->head))) {
+            return rc;
+        }
     }
     if (c->head.Cout != c->K + 4 * c->njm) return fail(c, EAMM_ERR_KEY, "kp / jacobian heads have the wrong channel count");
 
     const size_t F = g.max_batch, hw = (size_t)c->h * c->w;
-    const int xin_c = g.with_predictor ? c->Cin_pad : (c->feat_c + 31) / 32 * 32;
+    const int xin_c = g.with_predictor ? c->Cin_pad : (c->thin_wide ? c->thin_wide : (c->feat_c + 31) / 32 * 32);
     if ((rc = dev_alloc(c, &c->x_in, F * hw * xin_c))) return rc;
+    if (c->thin_wide) {
+        if ((rc = dev_alloc(c, &c->thin_x, F * hw * 4))) return rc;
+        if ((rc = dev_alloc(c, &c->thin_y, F * hw * 64))) return rc;
+        if ((rc = dev_alloc(c, &c->thin_ws, conv7_thin_workspace_floats((int)F, c->h, c->w, 64)))) return rc;
+    }
     if ((rc = dev_alloc(c, &c->logits, F * hw * 64))) return rc;
     size_t need = 0;
     auto upd1 = [&](const ConvLayer& L, size_t M) { need = std::max(need, conv_plan(L, (int)M).partial_elems); };
@@ -260,6 +303,12 @@ int eamm_kp_detect_features(eamm_kp_ctx* c, const float* feature_map, int B, con
     DeviceGuard guard(c->device);
     if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (c->thin_wide) {   // wide part -> NHWC, last three channels -> one float4 per pixel, thin 7x7 -> added in the wide one's epilogue
+        HIP_TRY(c, nchw_to_nhwc_pad_launch(feature_map, B, c->thin_wide, c->h, c->w, c->thin_wide, c->x_in, s, c->feat_c));
+        HIP_TRY(c, antialias_down_launch(feature_map, nullptr, B, c->h, c->w, 1, 4, c->thin_x, s, c->feat_c, c->thin_wide, 3, 0));
+        HIP_TRY(c, conv7_thin_in_launch(c->thin_x, c->thin_w, nullptr, B, c->h, c->w, 64, 0, c->thin_y, c->thin_ws, s));
+        return run_head(c, c->x_in, nullptr, B, o, s, c->thin_y);   // keypoint_detector.py:180-203
+    }
     const int cp = (c->feat_c + 31) / 32 * 32;
     HIP_TRY(c, nchw_to_nhwc_pad_launch(feature_map, B, c->feat_c, c->h, c->w, cp, c->x_in, s));
     return run_head(c, c->x_in, nullptr, B, o, s);               // keypoint_detector.py:180-203

@@ -193,8 +193,8 @@ hipError_t final_shift_sum_launch(const float* part /*[n,H,W,32]: channel dx*3+c
 hipError_t antialias_down_launch(const float* src /*[ns,3,H,W]*/, const float* aa_w, int ns, int H, int W,
                                  int inv_scale, int Cpad, float* dst /*[ns,h,w,Cpad]: RGB + zeros*/, hipStream_t s,
                                  int src_planes = 3, int first_channel = 0, int channels = 3, int slot = 0);
-hipError_t nchw_to_nhwc_pad_launch(const float* src /*[B,C,H,W]*/, int B, int C, int H, int W, int Cpad,
-                                   float* dst /*[B,H,W,Cpad]*/, hipStream_t s);
+hipError_t nchw_to_nhwc_pad_launch(const float* src /*[B,planes,H,W]*/, int B, int C, int H, int W, int Cpad,
+                                   float* dst /*[B,H,W,Cpad]*/, hipStream_t s, int planes = 0 /*0: = C; else the first C of them*/);
 hipError_t kp_head_launch(const float* logits /*[B,h,w,Cs]*/, int B, int K, int njm, int h, int w, int Cs, int pad,
                           float temperature, float* value /*[B,K,2]*/, float* jacobian /*[B,K,2,2] or null*/,
                           float* heatmap /*[B,K,h-6+2pad,w-6+2pad] or null*/, hipStream_t s);

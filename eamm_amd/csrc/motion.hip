@@ -642,14 +642,14 @@ hipError_t antialias_down_launch(const float* src, const float* aa_w, int ns, in
 // ---------------------------------------------------------------------------------------------
 // [B,C,h,w] feature map -> [B,h,w,Cpad] (zero padded): the layout the MFMA convolutions read.
 __global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ src, int B, int C, int HW,
-                                                               int Cpad, float* __restrict__ dst) {
+                                                               int Cpad, float* __restrict__ dst, int planes) {
     const size_t total = (size_t)B * HW * Cpad;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % Cpad);
         const size_t pix = idx / Cpad;
         const size_t b = pix / HW, r = pix % HW;
-        dst[idx] = c < C ? src[(b * C + c) * HW + r] : 0.f;
+        dst[idx] = c < C ? src[(b * planes + c) * HW + r] : 0.f;     // (the first C of `planes` planes per image)
     }
 }
 
@@ -729,9 +729,9 @@ __global__ __launch_bounds__(256) void kp_head_kernel(const float* __restrict__ 
     }
 }
 
-hipError_t nchw_to_nhwc_pad_launch(const float* src, int B, int C, int H, int W, int Cpad, float* dst, hipStream_t s) {
+hipError_t nchw_to_nhwc_pad_launch(const float* src, int B, int C, int H, int W, int Cpad, float* dst, hipStream_t s, int planes) {
     const size_t total = (size_t)B * H * W * Cpad;
-    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, B, C, H * W, Cpad, dst);
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, B, C, H * W, Cpad, dst, planes > 0 ? planes : C);
     return hipGetLastError();
 }
 

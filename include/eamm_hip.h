@@ -161,8 +161,9 @@ int eamm_describe_plan(const eamm_ctx* ctx, int n, char* buf, int cap);
  * DOCUMENTED knobs -- selectors of a computation form or of the launch plan; every setting computes the same frames up to rounding:
  *   EAMM_PASS_CHAINS / EAMM_BNECK_CHAINS   chains of a call over the whole pass / inside the bottleneck (0 = automatic, 1 = off)
  *   EAMM_WINO_TILE (4 | 2), EAMM_WINO_MIN_M (< 0: direct), EAMM_WINO4_MIN_M    bottleneck form: F(4x4), F(2x2), direct
- *   EAMM_ENC_WINO, EAMM_PATCH_POLY, EAMM_HEAD_ROWSPLIT, EAMM_COL7, EAMM_FIRST7, EAMM_FINAL_FUSED, EAMM_FINAL_MFMA4
- *                                          (0 | 1) the alternative kernel of a stage: hourglass encoder, up blocks, flow head, 7x7 layers
+ *   EAMM_ENC_WINO, EAMM_PATCH_POLY, EAMM_HEAD_ROWSPLIT, EAMM_COL7, EAMM_FIRST7, EAMM_FINAL_FUSED, EAMM_FINAL_MFMA4, EAMM_KPA_THIN
+ *                                          (0 | 1) the alternative kernel of a stage: hourglass encoder, up blocks, flow head, 7x7 layers,
+ *                                          KPDetector_a's heads (wide + thin split | one padded convolution)
  *   EAMM_WGRAD_WINO4, EAMM_WGRAD_ROW, EAMM_CONV_DEV_WINO4   (0 | 1) forms of the training operators
  *   EAMM_PRIVATE_STREAMS (0 | 1)           never use the shared side-stream pool
  *   EAMM_WARP_JOINT, EAMM_BNECK_STAGGER    scheduling variants measured in round 4 (off)

@@ -78,6 +78,25 @@ def test_hip_modules_match_reference_fixture(name, cfg_fn, audio):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,cfg_fn", [("kpa_tiny", lambda: tiny_kp_config(audio=True)), ("kpa_full", kp_detector_a_config)])
+def test_kp_detector_a_padded_head_form(name, cfg_fn, monkeypatch):
+    """EAMM_KPA_THIN=0: the heads of KPDetector_a as ONE convolution over the feature map zero-padded from 35 to 64 channels (rounds
+    1-4) instead of the wide (32) + thin (3) split of round 5 -- the same fixture, and the two forms against each other."""
+    cfg = cfg_fn()
+    fx, sd, x = load(name, cfg, True)
+    split = KPDetector_a(**cfg)
+    split.load_state_dict(sd, strict=True)
+    a = split.to("cuda:0").eval()(x.to("cuda:0"))
+    monkeypatch.setenv("EAMM_KPA_THIN", "0")
+    padded = KPDetector_a(**cfg)
+    padded.load_state_dict(sd, strict=True)
+    b = padded.to("cuda:0").eval()(x.to("cuda:0"))
+    for k in ("value", "jacobian", "heatmap"):
+        assert float((b[k].cpu() - torch.from_numpy(fx[k])).abs().max()) <= TOL_KP[k], (name, k)
+        assert float((a[k] - b[k]).abs().max()) <= TOL_KP[k] / 2, (name, k)
+
+
+@pytest.mark.gpu
 def test_kp_detector_feeds_generator_contract():
     """demo.py:206,219,279: kp_source = kp_detector(source); kp_driving = kp_detector_a(feature map); both dicts go
     straight into the generator (extra 'heatmap' key ignored)."""
