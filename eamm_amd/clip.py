@@ -36,6 +36,9 @@ class EngineBackend:
         self.batch = int(batch)
         self.device = next(generator.parameters()).device
         self.engine = None
+        self._host = {}             # pinned delivery buffers by (dtype, frame shape): host_buffer()
+        self._copy_stream = None    # device -> host copies beside the kernels: copy_stream()
+        self._front_stream = None   # the streamed front end of animate_from_features
 
     def prepare(self, height: int, width: int):
         self.engine = self.generator._ensure_engine(height, width, self.batch, 1)
@@ -67,16 +70,14 @@ class EngineBackend:
         for d in tail:
             need *= int(d)
         key = (dtype, tuple(tail))
-        buf = self._host.get(key) if hasattr(self, "_host") else None
+        buf = self._host.get(key)
         if buf is None or buf.numel() < need:
-            if not hasattr(self, "_host"):
-                self._host = {}
             buf = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
             self._host[key] = buf
         return buf[:need].view((frames,) + tuple(tail))
 
     def copy_stream(self):
-        if getattr(self, "_copy_stream", None) is None:
+        if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)
         return self._copy_stream
 

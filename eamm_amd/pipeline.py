@@ -130,8 +130,8 @@ def _animate_streaming(backend, kp_detector_a, deconv_tail, src, feats, kp_sourc
     T, K = feats.shape[0], kp_source["value"].shape[1]
     main = torch.cuda.current_stream(dev)
     front = getattr(backend, "_front_stream", None)
-    if front is None:
-        front = backend._front_stream = torch.cuda.Stream(device=dev, priority=-1)   # small launches: let them in ahead of the generator's
+    if front is None:      # (small launches: a high-priority stream lets them in ahead of the generator's)
+        front = backend._front_stream = torch.cuda.Stream(device=dev, priority=-1)
     norm = {"value": torch.empty(T, K, 2, device=dev), "jacobian": torch.empty(T, K, 2, 2, device=dev)}
     keep = {"raw": [], "smoothed": []} if return_keypoints else None
     emo = None if emo_driving is None else {k: v.to(dev) for k, v in _kp_only(emo_driving).items()}
