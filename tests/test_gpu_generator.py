@@ -119,6 +119,31 @@ def test_rgba_clip_interface_and_source_cache_roundtrip():
         assert torch.equal(a[k], b[k]), k
 
 
+def test_rgba_at_the_benchmark_geometry():
+    """Four image channels on the SHIPPED configuration at 256x256, 16 frames per call (two whole-pass chains, F(4x4) bottleneck,
+    flow head on the column-patch kernel with a 96-channel motion line, `final` on the generic kernel): frames 0, 8 (first of the
+    second chain) and 15 against the oracle, every key."""
+    cfg = {**hot_path_config(), "num_channels": 4}
+    sd = synthetic_state_dict(cfg, seed=1234)
+    gen = OcclusionAwareGenerator(**cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    src = synthetic_source(256, seed=1, channels=4)
+    kp_s, kp_d = synthetic_keypoints(1, 10, seed=0), synthetic_keypoints(16, 10, seed=2)
+    e = gen.encode_source(src.to(DEV), max_frames=16)
+    assert e.pass_chains(16) == 2 and e.bottleneck_form(8) == 4
+    out = e.forward_frames(cuda(kp_d), cuda(kp_s), outputs=KEYS)
+    e.check_numeric()
+    assert out["prediction"].shape == (16, 4, 256, 256) and out["sparse_deformed"].shape == (16, 11, 4, 64, 64)
+    pick = [0, 8, 15]
+    ref = orc.generator_forward(sd, cfg, src.expand(3, -1, -1, -1).contiguous(), {k: v[pick] for k, v in kp_d.items()},
+                                {k: v.expand(3, *v.shape[1:]).contiguous() for k, v in kp_s.items()})
+    errs = {k: float((out[k][pick].cpu() - ref[k]).abs().max()) for k in KEYS}
+    report("rgba 256x256 x 16", errs)
+    for k in KEYS:
+        assert errs[k] <= TOL[k], (k, errs[k])
+
+
 def test_internal_flow_matches_fixture():
     cfg = hot_path_config()
     fx = load_case("full256_clip2")
