@@ -84,7 +84,8 @@ def test_bench_single_gpu_line():
     assert e["verify"]["uint8_levels_streamed_vs_phased"] == 0        # streaming the front end changes no bit
     ph = e["phases_ms_rank0"]
     assert {"front_ms", "smooth_ms", "normalize_ms", "encode_ms", "compute_ms", "d2h_tail_ms"} <= set(ph)
-    assert ph["smooth_ms"] <= 2.0, ph                  # the round-4 host loop: 608 ms
+    assert ph["smooth_ms"] <= 10.0, ph                 # wall clock incl. a device sync (typically 0.7 ms; the kernels' own time is
+    # asserted with HIP events in tests/test_gpu_pipeline.py); the round-4 host loop: 608 ms
     assert e["host_bytes"] == 2048 * 256 * 256 * 3 and 0.5 * k["frames_per_s"] <= e["frames_per_s"] <= 1.05 * k["frames_per_s"]
     # the line says what it was measured under: parity at the timed geometry, knobs, launch plan
     pc = d["parity_check"]

@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 5, call o: flakiness check of the threaded / captured launch-plan tests and the pipeline tests
+mkdir -p gpurun_out/r05_o
+cd $GRAFT_REPO_ROOT
+for i in 1 2 3 4 5 6; do
+  timeout 300 python -m pytest tests/test_gpu_plan64.py tests/test_gpu_pipeline.py -x -q -m gpu > gpurun_out/r05_o/run$i.log 2>&1
+  tail -1 gpurun_out/r05_o/run$i.log
+  grep -n "^FAILED\|^E  " gpurun_out/r05_o/run$i.log | head -8 | cut -c1-400
+done
