@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
     // tiles, whose 6x6 patches share two of six rows / columns -- land in eight different L2s and every L2 fetches the shared
     // pixels again (PMC: 50.9 MB fetched per 8-frame launch for 16.8 MB of input).  Remapped, XCD x walks the x-th EIGHTH of the
     // tiles: at 8 frames one whole frame per XCD, every overlap inside one L2 (measured in the pipeline: 34.8 -> 31.7 us per launch,
-    // 3953 -> 3998 frames/s).  (Placement is a speed hint only.)
-    const size_t bid = by_xcd ? (size_t)xcd_remap((int)blockIdx.x, (int)gridDim.x) : (size_t)blockIdx.x;
+    // 3953 -> 3998 frames/s; with the non-temporal V stores below 26.9 us, 4018 frames/s).  (Placement is a speed hint only.)
+    const size_t bid = (by_xcd & 1) ? (size_t)xcd_remap((int)blockIdx.x, (int)gridDim.x) : (size_t)blockIdx.x;
     for (size_t idx = bid * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int cv = (int)(idx % cvn);
         const size_t q = idx / cvn;
@@ -142,6 +142,18 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);                              // along x
+            if constexpr (VEC == 4) {
+                if (by_xcd & 2) {   // V leaves through NON-TEMPORAL stores: it is 2.25 x the input, is not read again by this kernel, and
+                    // written through the L2 it evicts the input pixels the neighbouring tiles are about to share (26.9 vs 31.8 us
+                    // per launch in the pipeline; the GEMM that reads V next pays 2 us for finding less of it cached: + 0.8 % frames/s)
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (unsigned)(36 * plane * 16), 0x00020000);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d[i][j]), rs,
+                                                               (unsigned)(((size_t)(i * 6 + j) * plane + q * cvn + cv) * 16), 0, 2);
+                    continue;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 6; ++j) out[(size_t)(i * 6 + j) * plane] = d[i][j];
         }
@@ -614,8 +626,8 @@ hipError_t wino4_transform_launch(const float* x, const float* s, const float* t
     const int vec = vec_env ? vec_env : ((size_t)B * (H / 4) * (W / 4) * (C / 4) <= 64 * 256 ? 1 : 4);
     const size_t total = (size_t)B * (H / 4) * (W / 4) * (C / vec);
     const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)1 << 20);
-    static const int xcd = (int)knob_int("EAMM_WINO4_TR_XCD", 1);   // tuning aid: 0 = workgroups in dispatch order
-    const int remap = xcd && (size_t)blocks * 256 >= total ? 1 : 0;   // (one pass of the grid: every workgroup owns one slice)
+    static const int xcd = (int)knob_int("EAMM_WINO4_TR_XCD", 3);   // tuning aid: bit 0 = XCD-aware workgroup order, bit 1 = non-temporal V stores
+    const int remap = ((size_t)blocks * 256 >= total ? (xcd & 1) : 0) | ((36.0 * total * 16 < 4.0e9 && vec == 4) ? (xcd & 2) : 0);
     if (vec == 1)
         hipLaunchKernelGGL(wino4_input_transform_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, s, t, B, H, W, C, V, remap);
     else if (vec == 2)
