@@ -260,12 +260,12 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
             // (a local copy: passing the captured array element straight to the builtin makes hipcc 7.2's HOST pass drop the
             // kernel's stub without a diagnostic -- the library then fails to load with an undefined kernel symbol)
             const unsigned vo = arow_off[r];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_ptr_t)dst, 16, vo, sa_off, sub * BK * 4, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lds_ptr_t)dst, 16, vo, sa_off, sub * BK * 4, DBG == 40 ? 2 : 0);   // 40 (variant 6): V is streamed once per XCD -- non-temporal
         } else {
             constexpr int j = r - A_INSTR;
             float* dst = Bs + n_st * B_STAGE + sub * (BN * BK) + (wave * B_INSTR + j) * (8 * BK);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)dst, 16, b_lane,
-                                                     sb_off + (unsigned)((sub * BN + j * 8) * BK * 4), 0, 0);
+                                                     sb_off + (unsigned)((sub * BN + j * 8) * BK * 4), 0, 0);   // (U non-temporal too: 3955 vs 4048 frames/s -- every XCD's four tile rows share it)
         }
     };
 
@@ -709,6 +709,7 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
         case 2: e = wino4_launch_variant<2, 3, 4>(a, stream); break;
         case 3: e = sub4 ? wino4_launch_variant<4, 2, 8>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream); break;
         case 4: e = wino4_launch_variant<2, 4, 4>(a, stream); break;
+        case 6: e = sub4 ? wino4_launch_variant<4, 2, 8, 40>(a, stream) : wino4_launch_variant<2, 2, 4>(a, stream); break;   // variant 3 with non-temporal V loads (the default since round 5: 4034 -> 4048 frames/s)
         case 5: e = sub4 ? wino4_launch_variant<4, 2, 4, 20>(a, stream) : wino4_launch_variant<2, 2, 4, 20>(a, stream); break;
         default: break;
     }

@@ -155,6 +155,27 @@ def test_three_chains_by_knob(monkeypatch):
     assert knobs["EAMM_PASS_CHAINS"] == {"value": 3, "set": 1}
 
 
+def test_gemm_cache_policy_variants_are_bit_identical(monkeypatch):
+    """EAMM_WINO4_VARIANT 3 vs 6 (the default): the same bottleneck GEMM, variant 6 loads the transformed-input stream with the
+    non-temporal cache policy.  A cache hint must not change a bit, on the 16-frame plan `value` is quoted on and on the
+    64-frame four-chain plan."""
+    st = state()
+    kd, ks = cuda(st["kp_d"]), cuda(st["kp_s"])
+    ref64 = st["e64"].forward_frames(kd, ks, outputs=KEYS)
+    ref64 = {k: v.clone() for k, v in ref64.items()}
+    assert st["e64"].describe_plan(64)["wino4_variant"] == 6
+    monkeypatch.setenv("EAMM_WINO4_VARIANT", "3")
+    _, e3 = fresh_engine(64)
+    assert e3.describe_plan(64)["wino4_variant"] == 3
+    out = e3.forward_frames(kd, ks, outputs=KEYS)
+    for k in KEYS:
+        assert torch.equal(out[k], ref64[k]), k
+    _, e3s = fresh_engine(16)
+    part = e3s.forward_frames({k: v[16:32] for k, v in kd.items()}, ks, outputs=KEYS)
+    for k in KEYS:
+        assert torch.equal(part[k], st["ref16"][k][16:32]), k
+
+
 def test_two_handles_on_two_caller_streams_share_the_pool():
     """Two handles driven alternately from ONE host thread on two caller streams: their chains interleave on the pool's
     three side streams (shared order, separate fork / join events) -- the frames must be the serial run's, bit for bit."""
