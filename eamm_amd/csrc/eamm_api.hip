@@ -314,6 +314,7 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->warp_joint = env_int("EAMM_WARP_JOINT", c->warp_joint);
     c->enc_cus_pct = std::max(1, env_int("EAMM_ENC_CUS_PCT", c->enc_cus_pct));
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
+    c->wino4_variant_pinned = getenv("EAMM_WINO4_VARIANT") != nullptr;   // an explicit choice holds for every call size
 #ifdef EAMM_EXPERIMENTS
     c->epi_v = env_int("EAMM_WINO4_EPI_V", c->epi_v);
 #else
@@ -788,6 +789,17 @@ static int wino4_groups(const eamm_ctx* c, int n) {
     return env_int("EAMM_WINO4_GROUPS", w4g);
 }
 
+// GEMM variant 6 (= 3 with the V stream loaded non-temporally) pays only while all the GEMM workgroups of a call are co-resident,
+// one per CU: the four cout workgroups of a tile row then pull a V line through the L2 together.  16 frames at 256x256 (two chains
+// of 128 workgroups): + 0.3 %; 128 frames (four chains of 512): - 2 % (profiles/r05_experiments.txt 13) -- those keep variant 3.
+static int wino4_variant_for(const eamm_ctx* c, int call_frames) {
+    if (c->wino4_variant != 6 || c->wino4_variant_pinned) return c->wino4_variant;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    const size_t wgs = (((size_t)call_frames * (c->hf / 4) * (c->wf / 4) + 63) / 64) * ((c->Cb + 63) / 64);
+    return wgs <= (size_t)cus ? 6 : 3;
+}
+
 // Chains: the frames of a call are independent, so the F(4x4) bottleneck can run as K groups of frames on K streams.
 // Each chain alternates an HBM-bound input transform with an MFMA-bound GEMM that fills 1/K of the chip; while one
 // chain's transform streams through HBM the other chains' GEMMs own the matrix pipes, and a chain's transform moves only
@@ -1058,6 +1070,7 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
     //  neutral, 3917 vs 3958 frames/s: the input transform is latency-bound and does not shrink with the frames per launch;
     //  profiles/r05_experiments.txt section 2, git 9500c6c)
     const int chains = chained ? 1 : bottleneck_chains(c, n);
+    const int w4var = wino4_variant_for(c, chained ? c->cur_call_frames : n);
     auto split_stream = [&](int k) { return c->side_streams[k - 1]; };
     hipEvent_t split_fork = c->ev_fork;
     auto split_join = [&](int k) { return c->ev_join[k - 1]; };
@@ -1080,11 +1093,11 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
                 if (k == 0) SUB_MARK();
                 HIP_TRY(c, wino4_transform_launch(xk, c->pre_s[i], c->pre_t[i], nk, hf, wf, c->Cb, vk, sk));
                 if (k == 0) SUB_MARK();
-                HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], vk, nk, hf, wf, ACT_RELU, nullptr, tk, sk, c->wino4_variant, 1, nullptr));
+                HIP_TRY(c, wino4_gemm_launch(c->w4res1[i], vk, nk, hf, wf, ACT_RELU, nullptr, tk, sk, w4var, 1, nullptr));
                 if (k == 0) SUB_MARK();
                 HIP_TRY(c, wino4_transform_launch(tk, nullptr, nullptr, nk, hf, wf, c->Cb, vk, sk));
                 if (k == 0) SUB_MARK();
-                HIP_TRY(c, wino4_gemm_launch(c->w4res2[i], vk, nk, hf, wf, ACT_NONE, xk, xnk, sk, c->wino4_variant, 1, nullptr));
+                HIP_TRY(c, wino4_gemm_launch(c->w4res2[i], vk, nk, hf, wf, ACT_NONE, xk, xnk, sk, w4var, 1, nullptr));
             }
             std::swap(x, xn);
         }
@@ -1104,7 +1117,7 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
             // V: realistic operand values), and the GEMMs' epilogues write V-sized extra output instead (variant 50)
             const bool epi = c->epi_v && c->epi_scratch && w4g == 1;
             float* escr = epi ? c->epi_scratch + (size_t)3 * (v.xa - c->xa) : v.wino_z;
-            const int wvar = epi ? 50 : c->wino4_variant;
+            const int wvar = epi ? 50 : w4var;
             if (!epi || i == 0) HIP_TRY(c, wino4_transform_launch(x, c->pre_s[i], c->pre_t[i], n, hf, wf, c->Cb, v.wino_v, s));
             if (stagger && chain_idx == 0) HIP_TRY(c, hipEventRecord(c->ev_stagger, s));
             SUB_MARK();
@@ -1250,6 +1263,7 @@ int eamm_forward_frames(eamm_ctx* c, int n, const float* kd_val, const float* kd
     hipEvent_t* cev = nullptr; // bottleneck window of every whole-pass chain
     const int chains = pass_chains(c, n);
     c->cur_pass_chains = chains;
+    c->cur_call_frames = n;
     if (c->profiling && c->prof_used < eamm_ctx::PROF_CALLS) {
         ev = c->prof_events.data() + (size_t)c->prof_used * (eamm_ctx::NMARK + 1 + eamm_ctx::NSUB);
         cev = c->prof_chain_ev.data() + (size_t)c->prof_used * eamm_ctx::MAXCHAIN * 2;
@@ -1513,7 +1527,7 @@ int eamm_describe_plan(const eamm_ctx* c, int n, char* buf, int cap) {
                              "{\"frames\": %d, \"pass_chains\": %d, \"frames_per_chain\": %d, \"bottleneck_form\": %d, \"bottleneck_chains\": %d, "
                              "\"wino4_groups\": %d, \"wino4_variant\": %d, \"hg_encoder\": %s, \"final\": \"%s\", \"warp_joint\": %d, "
                              "\"bneck_stagger\": %d, \"side_streams\": %d, \"experiments_build\": %d}",
-                             n, pc, nk, form, bc, (form == 4 && pc == 1 && bc == 1) ? wino4_groups(c, n) : 1, c->wino4_variant, enc.c_str(),
+                             n, pc, nk, form, bc, (form == 4 && pc == 1 && bc == 1) ? wino4_groups(c, n) : 1, wino4_variant_for(c, n), enc.c_str(),
                              fused ? "col7q fused" : "col7 + shift-sum", c->warp_joint, c->bneck_stagger, (int)c->pool_streams.size(),
                              eamm_build_experiments());
     if (buf && cap > 0) {

@@ -73,9 +73,12 @@ struct eamm_ctx : eamm::CtxBase {
                                            // chains' HBM-bound input transforms run beside the other chain's GEMM instead of beside each other
     std::vector<hipEvent_t> ev_join;
     int cur_pass_chains = 1;               // whole-pass chains of the call being enqueued
+    int cur_call_frames = 0;               // ... and its frames (all chains)
     int wino_tile = 4;                     // preferred output tile (EAMM_WINO_TILE): 4 -> F(4x4) where it applies, 2 -> F(2x2)
     int wino4_variant = 6;                 // wino4_gemm_kernel pipeline variant (3: one DMA piece per 8 MFMAs; 2.062 -> 2.047 ms per step vs one per 4;
-                                           // 6 = 3 with the V stream loaded non-temporally: + 0.35 % frames/s, round 5)
+                                           // 6 = 3 with the V stream loaded non-temporally where every GEMM workgroup of the call has a CU
+                                           // of its own, 3 for larger calls: wino4_variant_for, eamm_api.hip)
+    bool wino4_variant_pinned = false;     // EAMM_WINO4_VARIANT set: that variant for every call size
     float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] (F(2x2)) or [36][F*hf*wf/16][Cb] transformed activations
     float* wino_z = nullptr;               // [24][F*hf*wf/16][Cb] x-folded products of the split F(4x4) form (few tiles)
     int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd F(2x2) form

@@ -156,22 +156,25 @@ def test_three_chains_by_knob(monkeypatch):
 
 
 def test_gemm_cache_policy_variants_are_bit_identical(monkeypatch):
-    """EAMM_WINO4_VARIANT 3 vs 6 (the default): the same bottleneck GEMM, variant 6 loads the transformed-input stream with the
-    non-temporal cache policy.  A cache hint must not change a bit, on the 16-frame plan `value` is quoted on and on the
-    64-frame four-chain plan."""
+    """The bottleneck GEMM's variant 6 = variant 3 with the transformed-input stream loaded non-temporally.  The library picks 6
+    while every GEMM workgroup of a call has a CU of its own (16 frames at 256x256: + 0.3 %) and 3 for larger calls (128 frames:
+    6 costs 2 %; eamm_api.hip wino4_variant_for); EAMM_WINO4_VARIANT pins one for every call size.  A cache hint must not change a
+    bit: each plan under the other variant against the default's frames."""
     st = state()
     kd, ks = cuda(st["kp_d"]), cuda(st["kp_s"])
-    ref64 = st["e64"].forward_frames(kd, ks, outputs=KEYS)
-    ref64 = {k: v.clone() for k, v in ref64.items()}
-    assert st["e64"].describe_plan(64)["wino4_variant"] == 6
-    monkeypatch.setenv("EAMM_WINO4_VARIANT", "3")
-    _, e3 = fresh_engine(64)
-    assert e3.describe_plan(64)["wino4_variant"] == 3
-    out = e3.forward_frames(kd, ks, outputs=KEYS)
+    assert st["e16"].describe_plan(16)["wino4_variant"] == 6 and st["e64"].describe_plan(16)["wino4_variant"] == 6
+    assert st["e64"].describe_plan(17)["wino4_variant"] == 3 and st["e64"].describe_plan(64)["wino4_variant"] == 3
+    ref64 = {k: v.clone() for k, v in st["e64"].forward_frames(kd, ks, outputs=KEYS).items()}
+    monkeypatch.setenv("EAMM_WINO4_VARIANT", "6")
+    _, e6 = fresh_engine(64)
+    assert e6.describe_plan(64)["wino4_variant"] == 6
+    out = e6.forward_frames(kd, ks, outputs=KEYS)
     for k in KEYS:
         assert torch.equal(out[k], ref64[k]), k
-    _, e3s = fresh_engine(16)
-    part = e3s.forward_frames({k: v[16:32] for k, v in kd.items()}, ks, outputs=KEYS)
+    monkeypatch.setenv("EAMM_WINO4_VARIANT", "3")
+    _, e3 = fresh_engine(16)
+    assert e3.describe_plan(16)["wino4_variant"] == 3
+    part = e3.forward_frames({k: v[16:32] for k, v in kd.items()}, ks, outputs=KEYS)
     for k in KEYS:
         assert torch.equal(part[k], st["ref16"][k][16:32]), k
 
