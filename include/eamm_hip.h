@@ -167,6 +167,9 @@ int eamm_describe_plan(const eamm_ctx* ctx, int n, char* buf, int cap);
  *   EAMM_WGRAD_WINO4, EAMM_WGRAD_ROW, EAMM_CONV_DEV_WINO4   (0 | 1) forms of the training operators
  *   EAMM_PRIVATE_STREAMS (0 | 1)           never use the shared side-stream pool
  *   EAMM_WARP_JOINT, EAMM_BNECK_STAGGER    scheduling variants measured in round 4 (off)
+ *   EAMM_WINO4_VARIANT (0-6)               software pipeline of the F(4x4) bottleneck GEMM, pinned for every call size; unset: 6 (variant 3 with
+ *                                          the transformed input loaded non-temporally) while the call's GEMM workgroups number at most the CUs,
+ *                                          3 above (bit-identical results)
  * TUNING aids (tile-size thresholds, pipeline variants, split sizes: everything else the sources read) are honoured only together
  * with EAMM_TUNING=1; without it they are ignored and reported with "set": 2.
  * Knobs that compute WRONG results (timing experiments: EAMM_WINO4_EPI_V, EAMM_COL7_DBG, EAMM_WINO4_VARIANT 10/16/17/50) exist
