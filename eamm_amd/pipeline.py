@@ -168,6 +168,7 @@ def _animate_streaming(backend, kp_detector_a, deconv_tail, src, feats, kp_sourc
     main.wait_stream(front)
     if not return_keypoints:
         return frames, span
+    # (concatenated on the caller's stream: the results belong to its allocator pool, the front stream's chunks die here, after the join)
     cat = lambda parts: {k: torch.cat([p[k] for p in parts]) for k in ("value", "jacobian")}
     return frames, span, {"kp_source": kp_source, "kp_driving_raw": cat(keep["raw"]), "kp_driving_smoothed": cat(keep["smoothed"]), "kp_norm": norm}
 
