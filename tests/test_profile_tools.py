@@ -60,3 +60,23 @@ def test_bottleneck_timeline_union(tmp_path):
     out2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), str(db)], capture_output=True, text=True,
                           check=True).stdout
     assert "wino4_gemm_kernel<2, 4, 2, 4, 2, 8, 0>" in out2 and "total_ms" in out2
+
+
+def test_pmc_counter_split_by_launch_size(tmp_path):
+    """tools/pmc_by_grid.py: one kernel launched at two sizes (the contract line's 8-frame launches, the clip leg's 32-frame launches)
+    keeps two rows -- rocpd_summary's per-kernel table would average them (profiles/r05_experiments.txt 14)."""
+    db = tmp_path / "pmc_results.db"
+    con = sqlite3.connect(db)
+    con.execute("create table counters_collection (kernel_name text, grid_size integer, workgroup_size integer, counter_name text, "
+                "value real, start integer, end integer)")
+    rows = [(GEMM, 128 * 512, 512, "FETCH_SIZE", 82000.0 + i, 0, 164_000) for i in range(3)]
+    rows += [(GEMM, 512 * 512, 512, "FETCH_SIZE", 254000.0, 0, 336_000) for _ in range(5)]
+    rows += [(GEMM, 512 * 512, 512, "WRITE_SIZE", 1.0, 0, 1), (TR, 1024 * 256, 256, "FETCH_SIZE", 15000.0, 0, 20_000)]
+    con.executemany("insert into counters_collection values (?,?,?,?,?,?,?)", rows)
+    con.commit()
+    con.close()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_by_grid.py"), str(db), "FETCH_SIZE", "wino4_gemm_kernel"],
+                         capture_output=True, text=True, check=True).stdout.splitlines()
+    body = [l.split() for l in out[2:]]
+    assert len(body) == 2 and "input_transform" not in "".join(out)
+    assert body[0][-4:] == ["128", "3", "82001.0", "164.00"] and body[1][-4:] == ["512", "5", "254000.0", "336.00"]
