@@ -120,9 +120,11 @@ def _worker(rank, world, port, total, batch, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [5, 1])     # 1: the second rank's shard is EMPTY (more ranks than frames)
-def test_two_rank_clip_equals_single_process(tmp_path, total):
-    batch, world = 2, 2
+# (1, 2): the second rank's shard is EMPTY (more ranks than frames); (7, 4): four ranks, shards of 2 / 2 / 2 / 1 frames; (3, 8): the widest
+# job the driver launches, five of its eight shards empty
+@pytest.mark.parametrize("total,world", [(5, 2), (1, 2), (7, 4), (3, 8)])
+def test_n_rank_clip_equals_single_process(tmp_path, total, world):
+    batch = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -179,11 +181,11 @@ def _chain_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_two_rank_end_to_end_chain_shards_the_front_end_too(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])     # 8 ranks over 7 frames: one frame each, the last rank's shard empty
+def test_n_rank_end_to_end_chain_shards_the_front_end_too(tmp_path, world):
     """animate_from_features under a process group: both of the reference's loops shard by frames (demo.py:212-228 and :251-281);
     three collectives per clip; the result equals the single-process run."""
     from eamm_amd import animate_from_features
-    world = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
