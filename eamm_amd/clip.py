@@ -65,15 +65,25 @@ class EngineBackend:
 
     # -- device -> host delivery (the reference copies every frame to the host, demo.py:281) -----------------------------
     def host_buffer(self, frames: int, tail, dtype) -> torch.Tensor:
-        """A pinned host tensor [frames, *tail] (grow-only, reused from clip to clip: pinning 400 MB costs ~100 ms)."""
+        """A pinned host tensor [frames, *tail] out of a grow-only pool (pinning 400 MB costs ~100 ms, so buffers are reused
+        from clip to clip) -- but never one the caller still holds: a buffer goes back into circulation only when nothing outside
+        the pool references its storage (the tensor `animate_clip(..., to_host=True)` returned, a view of it, a numpy array made
+        from it), so a delivered clip stays valid for as long as the caller keeps it, as a fresh tensor would."""
         need = int(frames)
         for d in tail:
             need *= int(d)
         key = (dtype, tuple(tail))
-        buf = self._host.get(key)
-        if buf is None or buf.numel() < need:
+        pool = self._host.setdefault(key, [])
+        buf = None
+        for cand, idle_count in pool:
+            if cand.numel() >= need and _storage_use_count(cand) <= idle_count:
+                buf = cand
+                break
+        if buf is None:
+            # drop idle buffers that are too small before pinning a larger one (grow-only, but not a leak)
+            pool[:] = [(c, n) for c, n in pool if _storage_use_count(c) > n]
             buf = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
-            self._host[key] = buf
+            pool.append((buf, _storage_use_count(buf)))
         return buf[:need].view((frames,) + tuple(tail))
 
     def copy_stream(self):
@@ -102,6 +112,11 @@ def driving_keypoints(deconv_tail, kp_detector_a, lstm_features: torch.Tensor, b
             if k in kp:
                 parts.setdefault(k, []).append(kp[k])
     return {k: torch.cat(v, 0) for k, v in parts.items()}
+
+
+def _storage_use_count(t: torch.Tensor) -> int:
+    """References to the tensor's storage (views, numpy arrays and the tensor itself all count)."""
+    return int(torch._C._storage_Use_Count(t.untyped_storage()._cdata))
 
 
 def _staged(group, device) -> bool:

@@ -131,20 +131,10 @@ struct StreamLease {
             c->last_streams = 0;
             return;
         }
+        // (the private twins are created with the pool streams in eamm_finalize_weights, outside any capture)
         if (c->own_streams.size() < c->pool_streams.size()) {
-            // created on first need; inside a capture under the relaxed mode (stream creation is not a captured operation,
-            // but the global capture mode refuses API calls it cannot prove harmless)
-            hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
-            if (capturing) (void)hipThreadExchangeStreamCaptureMode(&mode);
-            while (c->own_streams.size() < c->pool_streams.size()) {
-                hipStream_t st = nullptr;
-                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-                    rc = fail(c, EAMM_ERR_HIP, "hipStreamCreate failed for a private chain stream");
-                    break;
-                }
-                c->own_streams.push_back(st);
-            }
-            if (capturing) (void)hipThreadExchangeStreamCaptureMode(&mode);
+            rc = fail(c, EAMM_ERR_STATE, "handle has no private chain streams (weights not finalized?)");
+            return;
         }
         c->side_streams = c->own_streams;
         c->last_streams = capturing ? 2 : 1;
@@ -228,7 +218,9 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     if (g.num_channels < 1 || g.num_channels > 6)
         return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 1 .. 6 (got %d): the motion kernels keep a pixel's image channels in "
                     "groups of three (one float4 beside its heat-map value per group), two groups at most", g.num_channels);
-    if (g.num_kp < 1 || g.num_kp + 2 > 32) return fail(nullptr, EAMM_ERR_ARG, "num_kp out of range");
+    if (g.num_kp < 1 || g.num_kp + 2 > 32)
+        return fail(nullptr, EAMM_ERR_ARG, "num_kp must be 1 .. 30 (got %d): the flow head keeps the K + 1 motions' softmax and the "
+                    "occlusion logit of a pixel in one 32-lane group", g.num_kp);
     // dm_num_blocks == 0: a generator without a motion network (dense_motion_params=None, generator.py:22-23)
     const bool has_dm = g.dm_num_blocks > 0;
     if (g.dm_num_blocks < 0) return fail(nullptr, EAMM_ERR_ARG, "dm_num_blocks < 0");
@@ -315,6 +307,14 @@ int eamm_create(const eamm_config* cfg, int device, eamm_ctx** out) {
     c->enc_cus_pct = std::max(1, env_int("EAMM_ENC_CUS_PCT", c->enc_cus_pct));
     c->wino4_variant = env_int("EAMM_WINO4_VARIANT", c->wino4_variant);
     c->wino4_variant_pinned = getenv("EAMM_WINO4_VARIANT") != nullptr;   // an explicit choice holds for every call size
+    // read ONCE here (both used to be looked up -- a getenv, the knob registry's mutex and map, a device query -- in every
+    // forward_view of the per-frame path)
+    c->wino4_groups_knob = env_int("EAMM_WINO4_GROUPS", 0);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
+        else (void)hipGetLastError();
+    }
 #ifdef EAMM_EXPERIMENTS
     c->epi_v = env_int("EAMM_WINO4_EPI_V", c->epi_v);
 #else
@@ -624,8 +624,7 @@ int eamm_finalize_weights(eamm_ctx* c) {
             upd1(c->first, f * HW);
             for (int i = 0; i < c->nd; ++i) upd(c->down[i], f * (HW >> (2 * i)));
         }
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+        const int cus = c->cus;
         auto upd_poly = [&](const LayerSet& S, size_t f, int Hin, int Win) {   // split polyphase launches: raw slabs of the output
             if (!S.has_patch || !S.patch.w_poly || Hin < 16 || Win < 16) return;
             const int sp = patch_poly_splits(S.patch, (int)f, Hin, Win, c->patch_split_max, cus);
@@ -748,8 +747,7 @@ int eamm_encode_source(eamm_ctx* c, const float* source, int ns, void* stream_) 
             288e-6 * tiles * c->w4down[i].Cin * c->w4down[i].Cout >= (double)c->enc_wino_min_mflop) {
             const WinoLayer& L = c->w4down[i];   // as the hourglass encoder levels (forward_view)
             const int nblk = ((tiles + 63) / 64) * L.ntiles;
-            int cus = 256, g = 2;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            int cus = c->cus, g = 2;
             for (int gsel : {6, 3})
                 if (nblk * gsel <= cus) {
                     g = gsel;
@@ -779,14 +777,10 @@ static int bottleneck_form(const eamm_ctx* c, int n) {
 // the largest split that still fits one round of the chip (64 x 64 blocks, one per CU)
 static int wino4_groups(const eamm_ctx* c, int n) {
     const int nb = ((n * (c->hf / 4) * (c->wf / 4) + 63) / 64) * ((c->Cb + 63) / 64);
-    int cus = 256, w4g = 1;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    if (c->wino4_groups_knob) return c->wino4_groups_knob;
     for (int gsel : {6, 3, 2})
-        if (nb * gsel <= cus) {
-            w4g = gsel;
-            break;
-        }
-    return env_int("EAMM_WINO4_GROUPS", w4g);
+        if (nb * gsel <= c->cus) return gsel;
+    return 1;
 }
 
 // GEMM variant 6 (= 3 with the V stream loaded non-temporally) pays only while all the GEMM workgroups of a call are co-resident,
@@ -794,10 +788,8 @@ static int wino4_groups(const eamm_ctx* c, int n) {
 // of 128 workgroups): + 0.3 %; 128 frames (four chains of 512): - 2 % (profiles/r05_experiments.txt 13) -- those keep variant 3.
 static int wino4_variant_for(const eamm_ctx* c, int call_frames) {
     if (c->wino4_variant != 6 || c->wino4_variant_pinned) return c->wino4_variant;
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const size_t wgs = (((size_t)call_frames * (c->hf / 4) * (c->wf / 4) + 63) / 64) * ((c->Cb + 63) / 64);
-    return wgs <= (size_t)cus ? 6 : 3;
+    return wgs <= (size_t)c->cus ? 6 : 3;
 }
 
 // Chains: the frames of a call are independent, so the F(4x4) bottleneck can run as K groups of frames on K streams.
@@ -966,8 +958,7 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
             // the output-transform kernel's) -- the largest split that still fits one round of the chip
             const WinoLayer& L = c->w4enc[i];
             const int nblk = ((tiles + 63) / 64) * L.ntiles;
-            int cus = 256, g = 2;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            int cus = c->cus, g = 2;
             cus = cus * c->enc_cus_pct / 100;   // EAMM_ENC_CUS_PCT (experiment): the CU count the split of the point rows is sized for
             for (int gsel : {6, 3})
                 if (nblk * gsel <= cus) {

@@ -79,6 +79,8 @@ struct eamm_ctx : eamm::CtxBase {
                                            // 6 = 3 with the V stream loaded non-temporally where every GEMM workgroup of the call has a CU
                                            // of its own, 3 for larger calls: wino4_variant_for, eamm_api.hip)
     bool wino4_variant_pinned = false;     // EAMM_WINO4_VARIANT set: that variant for every call size
+    int cus = 256;                         // the device's CU count, read ONCE in eamm_create (the per-call launch rules size their splits by it)
+    int wino4_groups_knob = 0;             // EAMM_WINO4_GROUPS read once in eamm_create (0: unset -> the rule in wino4_groups())
     float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] (F(2x2)) or [36][F*hf*wf/16][Cb] transformed activations
     float* wino_z = nullptr;               // [24][F*hf*wf/16][Cb] x-folded products of the split F(4x4) form (few tiles)
     int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd F(2x2) form

@@ -18,6 +18,7 @@ struct eamm_kp_ctx : eamm::CtxBase {
     std::vector<int> enc_c, dec_c;
     std::vector<LayerSet> hg_enc, hg_dec;
     ConvLayer head;               // kp (K) + jacobian (4*njm) stacked along Cout
+    int head_cs = 64;             // pixel stride of the logits = K + 4*njm rounded up to 64 (round 6: 128 / 192 for num_kp 13 .. 30)
     // KPDetector_a whose feature map is 32 m + 3 channels wide (the shipped 35 = block_expansion 32 + num_channels_a 3): the heads
     // run as a 7x7 MFMA convolution over the first 32 m channels (K = 49 x 32 m instead of 49 x the next multiple of 32: 45 % fewer
     // multiplies at 35) PLUS the thin-channel 7x7 kernel (conv7_thin.hip: K = (tap, channel) = 196) over the last three, added in
@@ -47,9 +48,9 @@ int run_head(eamm_kp_ctx* c, const float* in0, const float* in1, int B, const ea
     io.partial = c->partial;
     io.partial_cap = c->partial_elems;
     ConvLayer head = c->head;
-    head.Cout = 64;  // logits are written with a 64-float pixel stride; channels >= K + 4*njm have zero weights
+    head.Cout = c->head_cs;  // logits are written with a head_cs-float pixel stride; channels >= K + 4*njm have zero weights
     HIP_TRY(c, conv_launch(head, io, s));
-    HIP_TRY(c, kp_head_launch(c->logits, B, c->K, c->njm, c->h, c->w, 64, c->cfg.pad, c->cfg.temperature, o->value,
+    HIP_TRY(c, kp_head_launch(c->logits, B, c->K, c->njm, c->h, c->w, c->head_cs, c->cfg.pad, c->cfg.temperature, o->value,
                               o->jacobian, o->heatmap, s));
     return EAMM_OK;
 }
@@ -73,8 +74,9 @@ int eamm_kp_create(const eamm_kp_config* cfg, int device, eamm_kp_ctx** out) {
     *out = nullptr;
     const eamm_kp_config& g = *cfg;
     if (g.num_channels < 1 || g.num_channels > 8) return fail(nullptr, EAMM_ERR_ARG, "num_channels must be 1 .. 8 (got %d)", g.num_channels);
-    if (g.num_kp < 1 || g.num_kp * (g.estimate_jacobian ? (g.single_jacobian_map ? 1 : 5) : 1) + (g.single_jacobian_map ? 4 : 0) > 64)
-        return fail(nullptr, EAMM_ERR_ARG, "num_kp out of range for the 64-channel head");
+    // the generator takes 1 .. 30 key points (eamm_create); the detectors feed it, so the same range holds here (round 6: the heads'
+    // K + 4 K logits are no longer limited to one 64-float line)
+    if (g.num_kp < 1 || g.num_kp > 30) return fail(nullptr, EAMM_ERR_ARG, "num_kp must be 1 .. 30 (got %d)", g.num_kp);
     if (g.block_expansion % 32 || g.max_features % 32 || g.num_blocks < 1)
         return fail(nullptr, EAMM_ERR_ARG, "channel widths must be multiples of 32");
     if (g.inv_scale != 1 && g.inv_scale != 2 && g.inv_scale != 4) return fail(nullptr, EAMM_ERR_ARG, "1/scale_factor must be 1, 2 or 4");
@@ -99,6 +101,7 @@ int eamm_kp_create(const eamm_kp_config* cfg, int device, eamm_kp_ctx** out) {
     c->K = g.num_kp;
     c->nb = g.num_blocks;
     c->njm = g.estimate_jacobian ? (g.single_jacobian_map ? 1 : g.num_kp) : 0;
+    c->head_cs = (c->K + 4 * c->njm + 63) / 64 * 64;
     c->feat_c = g.block_expansion + g.in_features;
     for (int i = 0; i < c->nb; ++i) c->enc_c.push_back(std::min(g.max_features, g.block_expansion << (i + 1)));
     for (int i = c->nb - 1; i >= 0; --i) c->dec_c.push_back(std::min(g.max_features, g.block_expansion << i));
@@ -174,7 +177,7 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
         // KPDetector_a: the caller's feature map already is the hourglass output (feat_c channels)
         const int cp = (c->feat_c + 31) / 32 * 32;
         const int wide = c->feat_c - 3;
-        if (wide >= 32 && wide % 32 == 0 && env_int("EAMM_KPA_THIN", 1)) {
+        if (wide >= 32 && wide % 32 == 0 && c->head_cs == 64 && env_int("EAMM_KPA_THIN", 1)) {   // (the thin kernel's N is one 64-column tile)
             // slice every head's filter [co, feat_c, 7, 7] into its wide part (replaces the entry) and its last three input channels
             std::vector<float> thin((size_t)64 * 3 * 49, 0.f);
             int o0 = 0;
@@ -215,7 +218,7 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
         if ((rc = dev_alloc(c, &c->thin_y, F * hw * 64))) return rc;
         if ((rc = dev_alloc(c, &c->thin_ws, conv7_thin_workspace_floats((int)F, c->h, c->w, 64)))) return rc;
     }
-    if ((rc = dev_alloc(c, &c->logits, F * hw * 64))) return rc;
+    if ((rc = dev_alloc(c, &c->logits, F * hw * c->head_cs))) return rc;
     size_t need = 0;
     auto upd1 = [&](const ConvLayer& L, size_t M) { need = std::max(need, conv_plan(L, (int)M).partial_elems); };
     if (g.with_predictor) {

@@ -9,7 +9,7 @@
 //     s_t    = a_t * x_t + (1 - a_t) * s_{t-1}              (x_0 for t = 0),   a_t = alpha(mincutoff + beta * |edx_t|)
 //     alpha(c) = 1 / (1 + (1 / (2 pi c)) / te),  te = 1 / freq
 // with x = input * scale and output s / scale, every step in float32 in the reference's operation order (separate multiplies
-// and adds: no fused multiply-add, so the result follows the host filter to rounding).  A frame's 60 values are loaded
+// and adds, true divisions where ATen's CPU kernels divide: no fused multiply-add, so the result is the host filter's bit for bit).  A frame's 60 values are loaded
 // sixteen frames ahead of the dependent chain (the loads do not depend on it), so the walk costs the chain's ~40 dependent
 // float operations per frame (two correctly rounded reciprocals among them: ~380 cycles), not a memory round trip per frame:
 // 2048 frames in 0.32 ms (rocprofv3, profiles/r05_e2e_kernel_trace_stats.txt) where the host loop takes 600 ms.
@@ -24,15 +24,19 @@ constexpr int EURO_AHEAD = 16;
 // form) -- a clip filtered in chunks then differs from the clip filtered whole in the last bit (measured: cuts at odd frames), and
 // from the reference's separately rounded operations.  THIS FILE IS COMPILED WITH -ffp-contract=off (csrc/Makefile).
 
-static __device__ __forceinline__ float euro_alpha(float cutoff, float inv_te) {
-    // torch evaluates 1.0 / (2 * np.pi * cutoff) as reciprocal(cutoff * float(2 pi)) and tau / te as tau * (1 / te)
+static __device__ __forceinline__ float euro_alpha(float cutoff, float te) {
+    // The reference filters CPU tensors (demo.py:245 `.cpu() * 10`): ATen evaluates 1.0 / (2 * np.pi * cutoff) as
+    // reciprocal(cutoff * float(2 pi)) and `tau / te` as a TRUE float32 division by float(te) (its CPU kernel divides; only the CUDA
+    // kernel multiplies by the reciprocal -- round 5 followed that one and was 1-2 ulp off the reference filter)
     const float tau = __frcp_rn(__fmul_rn(cutoff, 6.283185307179586f));
-    return __frcp_rn(__fadd_rn(1.0f, __fmul_rn(tau, inv_te)));
+    return __frcp_rn(__fadd_rn(1.0f, __fdiv_rn(tau, te)));
 }
 
-__global__ __launch_bounds__(64) void one_euro_kernel(const float* __restrict__ x, int T, int E, float mincutoff, float beta,
-                                                     float a_d, float one_m_ad, float freq, float inv_te, float scale, float inv_scale,
-                                                     float* __restrict__ out, float* __restrict__ state, int resume) {
+// (x and out carry no __restrict__: include/eamm_hip.h allows out == x; a thread reads its element sixteen frames ahead into
+//  registers before it writes those frames, so the in-place form is well defined)
+__global__ __launch_bounds__(64) void one_euro_kernel(const float* x, int T, int E, float mincutoff, float beta,
+                                                     float a_d, float one_m_ad, float freq, float te, float scale,
+                                                     float* out, float* __restrict__ state, int resume) {
     // state (optional, [3][E]): the filter's memory -- previous scaled input, previous filtered value, previous filtered
     // derivative -- written at the end; with `resume` it is read first and frame 0 of this call continues the sequence (a clip
     // filtered in chunks gives the bits of the clip filtered whole)
@@ -60,13 +64,13 @@ __global__ __launch_bounds__(64) void one_euro_kernel(const float* __restrict__ 
             } else {
                 const float dx = __fmul_rn(__fsub_rn(xv, prev_x), freq);
                 edx = __fadd_rn(__fmul_rn(a_d, dx), __fmul_rn(one_m_ad, prev_edx));
-                const float a = euro_alpha(__fadd_rn(mincutoff, __fmul_rn(beta, fabsf(edx))), inv_te);
+                const float a = euro_alpha(__fadd_rn(mincutoff, __fmul_rn(beta, fabsf(edx))), te);
                 s = __fadd_rn(__fmul_rn(a, xv), __fmul_rn(__fsub_rn(1.0f, a), prev_s));
             }
             prev_x = xv;
             prev_s = s;
             prev_edx = edx;
-            out[(size_t)t * E + e] = __fmul_rn(s, inv_scale);   // `/ scale` by a Python scalar: torch multiplies by float(1 / scale)
+            out[(size_t)t * E + e] = __fdiv_rn(s, scale);   // `/ scale` on a CPU tensor: a true float32 division by float(scale)
         }
     }
     if (state != nullptr) {
@@ -85,9 +89,9 @@ hipError_t one_euro_launch(const float* x, int T, int E, float mincutoff, float 
     const double tau_d = 1.0 / (2.0 * 3.14159265358979323846 * (double)dcutoff);
     const double a_dd = 1.0 / (1.0 + tau_d / te);
     const float a_d = (float)a_dd, one_m_ad = (float)(1.0 - a_dd);   // `(1.0 - a_d)` is a double subtraction there too
-    const float inv_te = 1.0f / (float)te;      // tensor / Python-scalar: torch multiplies by the reciprocal of the scalar cast to float
-    hipLaunchKernelGGL(one_euro_kernel, dim3((E + 63) / 64), dim3(64), 0, stream, x, T, E, mincutoff, beta, a_d, one_m_ad, freq, inv_te, scale,
-                       1.0f / scale, out, state, resume);
+    // tensor / Python-scalar on the CPU: a division by the scalar cast to float
+    hipLaunchKernelGGL(one_euro_kernel, dim3((E + 63) / 64), dim3(64), 0, stream, x, T, E, mincutoff, beta, a_d, one_m_ad, freq, (float)te, scale,
+                       out, state, resume);
     return hipGetLastError();
 }
 

@@ -87,6 +87,40 @@ class _Tracked:
         self._bump()
         super().add_module(name, module)
 
+    def _apply(self, fn, *args, **kwargs):
+        # `.cuda()` / `.double()` / `.half()` on a SUB-module (`gen.first.double()`): `param.data = fn(param.data)` changes neither
+        # the tensor's identity nor its version counter, so without the bump the engine would keep the old weights
+        self._bump()
+        return super()._apply(fn, *args, **kwargs)
+
+
+class _TrackedContainer(_Tracked):
+    """nn.ModuleList / nn.Sequential mutators that write ``self._modules`` directly (no registration call to intercept)."""
+
+    def insert(self, index, module):
+        self._bump()
+        return super().insert(index, module)
+
+    def pop(self, key):
+        self._bump()
+        return super().pop(key)
+
+    def extend(self, modules):
+        self._bump()
+        return super().extend(modules)
+
+    def append(self, module):
+        self._bump()
+        return super().append(module)
+
+    def __setitem__(self, idx, module):
+        self._bump()
+        return super().__setitem__(idx, module)
+
+    def __delitem__(self, idx):
+        self._bump()
+        return super().__delitem__(idx)
+
 
 class _Conv2d(_Tracked, nn.Conv2d):
     pass
@@ -96,11 +130,11 @@ class _BatchNorm2d(_Tracked, nn.BatchNorm2d):
     pass
 
 
-class _ModuleList(_Tracked, nn.ModuleList):
+class _ModuleList(_TrackedContainer, nn.ModuleList):
     pass
 
 
-class _Sequential(_Tracked, nn.Sequential):
+class _Sequential(_TrackedContainer, nn.Sequential):
     pass
 
 
@@ -411,8 +445,9 @@ class OcclusionAwareGenerator(_Tracked, nn.Module):
 
     # -- the reference contract -----------------------------------------------------------------------
     def _any_parameter_requires_grad(self) -> bool:
-        """``any(p.requires_grad ...)`` cached under the structure epoch + the flags themselves (``requires_grad_()`` changes
-        neither a version counter nor the structure: the flags are re-read, which is a tuple compare of ~200 booleans)."""
+        """``any(p.requires_grad ...)`` over the cached slot list (the list is rebuilt only when the structure epoch moves; the
+        FLAGS are re-read on every call -- ``requires_grad_()`` changes neither a version counter nor the structure, so they
+        cannot be cached -- which costs a walk over ~200 parameters, only when gradients are enabled)."""
         ps = [t for t in (store[key] for store, key, _ in self._tensor_slots()) if isinstance(t, nn.Parameter)]
         return any(p.requires_grad for p in ps)
 

@@ -124,12 +124,18 @@ def one_euro_smooth(seq: torch.Tensor, mincutoff: float = 1.0, beta: float = 0.0
     if state is not None or resume:
         raise RuntimeError("one_euro_smooth: the resumable form is the device path's (a CPU tensor is filtered whole)")
     f32 = np.float32
-    x_all = seq.detach().to(torch.float32).numpy().reshape(seq.shape[0], -1) * f32(scale)
+    if seq.shape[0] == 0:                       # an empty sequence (an empty shard): nothing to filter
+        return torch.empty(seq.shape, dtype=torch.float32)
+    per_frame = seq[0].numel()
+    x_all = seq.detach().to(torch.float32).contiguous().numpy().reshape(seq.shape[0], per_frame) * f32(scale)
     out = np.empty_like(x_all)
+    # The reference filters CPU tensors (demo.py:245 `.cpu() * 10 ... / 10`): ATen's float32 CPU kernels DIVIDE (`tau / te`,
+    # `/ scale` are true divisions by the scalar cast to float32; `1.0 / tensor` is reciprocal(tensor)), unlike the CUDA kernels,
+    # which multiply by the scalar's reciprocal.  Same operations here -> bit-equal to the reference filter's outputs.
     te = 1.0 / freq
     a_dd = 1.0 / (1.0 + (1.0 / (2 * np.pi * dcutoff)) / te)
     a_d, one_m_ad = f32(a_dd), f32(1.0 - a_dd)
-    two_pi, inv_te, one, fq, mc, bt = f32(2 * np.pi), f32(1.0) / f32(te), f32(1.0), f32(freq), f32(mincutoff), f32(beta)
+    two_pi, te32, one, fq, mc, bt, sc = f32(2 * np.pi), f32(te), f32(1.0), f32(freq), f32(mincutoff), f32(beta), f32(scale)
     prev_x = prev_s = prev_edx = None
     for t in range(x_all.shape[0]):
         x = x_all[t]
@@ -140,11 +146,11 @@ def one_euro_smooth(seq: torch.Tensor, mincutoff: float = 1.0, beta: float = 0.0
             dx = (x - prev_x) * fq
             edx = a_d * dx + one_m_ad * prev_edx
             tau = one / ((mc + bt * np.abs(edx)) * two_pi)
-            a = one / (one + tau * inv_te)
+            a = one / (one + tau / te32)
             s = a * x + (one - a) * prev_s
         prev_x, prev_s, prev_edx = x, s, edx
         out[t] = s
-    return torch.from_numpy(out * (f32(1.0) / f32(scale))).reshape(seq.shape)
+    return torch.from_numpy(out / sc).reshape(seq.shape)
 
 
 def smooth_keypoints(kp_seq: Dict[str, torch.Tensor], mincutoff: float = 0.05, beta: float = 8.0, dcutoff: float = 1.0,
@@ -156,5 +162,7 @@ def smooth_keypoints(kp_seq: Dict[str, torch.Tensor], mincutoff: float = 0.05, b
         for k, v in kp_seq.items():
             if k in ("value", "jacobian") and k not in state:
                 state[k] = torch.zeros(3, v.numel() // max(1, v.shape[0]), dtype=torch.float32, device=v.device)
-    return {k: one_euro_smooth(v, mincutoff, beta, dcutoff, freq, scale, None if state is None else state[k], resume)
-            for k, v in kp_seq.items() if k in ("value", "jacobian")}
+    # (keys other than 'value' / 'jacobian' -- the detectors' 'heatmap' -- are not filtered by the reference either, demo.py:244-248:
+    #  they are passed through untouched rather than dropped)
+    return {k: (one_euro_smooth(v, mincutoff, beta, dcutoff, freq, scale, None if state is None else state[k], resume)
+                if k in ("value", "jacobian") else v) for k, v in kp_seq.items()}

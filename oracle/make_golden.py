@@ -290,7 +290,16 @@ def kp_detector_cases(only=None):
                                    ("kpa_full", kp_detector_a_config(), 256, True),
                                    ("kp_tiny64_gray", {**tiny_kp_config(), "num_channels": 1}, 64, False),
                                    ("kp_tiny64_rgba", {**tiny_kp_config(), "num_channels": 4}, 64, False),
-                                   ("kp_tiny64_six_channels", {**tiny_kp_config(), "num_channels": 6}, 64, False)):
+                                   ("kp_tiny64_six_channels", {**tiny_kp_config(), "num_channels": 6}, 64, False),
+                                   # round 6: num_kp != 10 (keypoint_detector.py:24-41 accepts any)
+                                   ("kp_tiny64_k1", {**tiny_kp_config(), "num_kp": 1}, 64, False),
+                                   ("kp_tiny64_k5", {**tiny_kp_config(), "num_kp": 5}, 64, False),
+                                   ("kp_tiny64_k15", {**tiny_kp_config(), "num_kp": 15}, 64, False),
+                                   ("kp_tiny64_k30", {**tiny_kp_config(), "num_kp": 30}, 64, False),
+                                   ("kpa_tiny_k1", {**tiny_kp_config(audio=True), "num_kp": 1}, 64, True),
+                                   ("kpa_tiny_k5", {**tiny_kp_config(audio=True), "num_kp": 5}, 64, True),
+                                   ("kpa_tiny_k15", {**tiny_kp_config(audio=True), "num_kp": 15}, 64, True),
+                                   ("kpa_tiny_k30", {**tiny_kp_config(audio=True), "num_kp": 30}, 64, True)):
         if only and name not in only:
             continue
         sd = synthetic_state_dict(cfg, seed=77, spec=kp_state_dict_spec(cfg))
@@ -694,6 +703,19 @@ def train_backward_case(OAG, name="tiny64_train_backward", cfg=None, size=64, n=
     print(name + ": wrote", len(blob), "arrays,", os.path.getsize(os.path.join(GOLDEN, name + ".npz")) >> 10, "KiB")
 
 
+# num_kp != 10: (fixture, config, size, frames, sample stride, with driving jacobians).  K enters the 4(K+1)-channel hourglass input
+# line, the softmax width of the flow head, its 7*(K+2)-column padding and the K + 2 <= 32 guard (eamm_api.hip): 1 = the smallest,
+# 5 / 15 = below / above the shipped 10 (15: 4(K+1) = 64 fills the padded line exactly), 30 = the largest the library accepts
+# (128 input channels, 7*32 = 224 flow-head columns); one case at the shipped 256x256 configuration, one without jacobians.
+NUM_KP_CASES = (("tiny64_kp1", {**tiny_config(), "num_kp": 1}, 64, 2, 1, True),
+                ("tiny64_kp5", {**tiny_config(), "num_kp": 5}, 64, 2, 1, True),
+                ("tiny64_kp15", {**tiny_config(), "num_kp": 15}, 64, 2, 1, True),
+                ("tiny64_kp30", {**tiny_config(), "num_kp": 30}, 64, 2, 1, True),
+                ("tiny64_kp30_nojac", {**tiny_config(), "num_kp": 30}, 64, 2, 1, False),
+                ("full256_kp15", {**hot_path_config(), "num_kp": 15}, 256, 2, 4, True),
+                ("full256_kp5", {**hot_path_config(), "num_kp": 5}, 256, 1, 4, True))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "train_backward":
         os.makedirs(GOLDEN, exist_ok=True)
@@ -738,6 +760,22 @@ def main():
             summary["cases"][name] = rep
             with open(path, "w") as f:
                 json.dump(summary, f, indent=1, sort_keys=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "num_kp":   # num_kp != 10 (dense_motion.py:15-18, generator.py:14 accept any)
+        torch.set_num_threads(os.cpu_count() or 1)
+        OAG = import_reference()
+        path = os.path.join(GOLDEN, "summary.json")
+        summary = json.load(open(path))
+        which = sys.argv[2:]
+        for name, cfg, size, n, stride, jac in NUM_KP_CASES:
+            if which and name not in which:
+                continue
+            rep = case(OAG, name, cfg, size, n, 1234, stride, with_jacobian=jac)
+            summary["cases"][name] = rep
+            print(name, {k: (f"{r['oracle_vs_reference']:.1e}", f"{r['fp32_vs_fp64_floor']:.1e}") for k, r in rep.items()})
+        with open(path, "w") as f:
+            json.dump(summary, f, indent=1, sort_keys=True)
+        kp_detector_cases(only=[f"{a}_k{k}" for a in ("kp_tiny64", "kpa_tiny") for k in (1, 5, 15, 30)])
         return
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         os.makedirs(GOLDEN, exist_ok=True)
@@ -787,6 +825,8 @@ def main():
     summary["tiny64_six_channels"] = case(OAG, "tiny64_six_channels", {**tiny, "num_channels": 6}, 64, 2, 1234, 1, per_frame_source=True)
     summary["tiny64_adversarial"] = adversarial_case(OAG, "tiny64_adversarial", tiny, 64, 3, 1)
     summary["full256_adversarial"] = adversarial_case(OAG, "full256_adversarial", full, 256, 2, 4)
+    for name, cfg, size, n, stride, jac in NUM_KP_CASES:
+        summary[name] = case(OAG, name, cfg, size, n, 1234, stride, with_jacobian=jac)
     no_motion_case(OAG)
     normalize_kp_case()
     emotion_case()

@@ -63,6 +63,19 @@ def test_bench_single_gpu_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0
     assert len(c["passes"]) >= 5 and min(c["passes"]) <= c["value"] <= max(c["passes"])   # median of >= 5 passes
+    # round 6: the box's physical cores, its logical CPUs and the threads the timed passes used are three separate fields
+    assert c["threads_used"] == c["cores"] and 1 <= c["threads_used"] <= c["logical_cpus"] == os.cpu_count()
+    assert c["physical_cores"] is None or 1 <= c["physical_cores"] <= c["logical_cpus"]
+    # round 6: the FULL five-key forward timed beside the contract's prediction-only step ...
+    a = d["all_outputs"]
+    assert a["outputs"] == ["prediction", "mask", "sparse_deformed", "occlusion_map", "deformed"] and a["steps"] == 10
+    assert abs(a["frames_per_s"] - 16 * 1e3 / a["ms_per_step"]) / a["frames_per_s"] < 0.01
+    assert 0.75 * d["value"] <= a["frames_per_s"] <= 1.02 * d["value"] and a["prediction_max_abs_err_vs_fixture"] <= 1e-4
+    # ... and ONE frame per call (BASELINE configs[1]): latency, executed-flop fraction, parity through that plan
+    b1 = d["latency_b1"]
+    assert 0.1 < b1["ms_per_frame"] < 2.0 and abs(b1["frames_per_s"] - 1e3 / b1["ms_per_frame"]) < 1.0
+    assert 15.0 < b1["executed_gflop_per_frame"] < 40.0 and 0.0 < b1["frac_chip_executed"] < 1.0
+    assert b1["parity_max_abs_err_vs_fixture"] <= 1e-4 and b1["plan"]["frames"] == 1
     assert d["value"] > 30 * c["value"]        # north_star target: >= 30x the CPU reference path
     # roofline.traffic: a committed PMC measurement of THIS kernel source at THIS (size, batch), or null with the reason
     assert (r["traffic"] is None or r["traffic"] > 0) and r["traffic_source"]

@@ -131,6 +131,34 @@ def test_module_forward_survives_clip_use_of_the_same_engine():
     assert float((gen_b[0] - clip_b[0]).abs().max()) <= 1e-6
 
 
+def test_host_delivery_of_one_backend_never_overwrites_a_clip_the_caller_still_holds():
+    """`to_host=True` hands out pinned buffers from the backend's pool.  A delivered clip must stay intact for as long as
+    the caller keeps it (two clips in a row on ONE backend used to share storage, the second silently overwriting the first), and a
+    buffer the caller has dropped must be reused instead of pinned again."""
+    cfg = tiny_config()
+    gen = make_generator(cfg)
+    be = EngineBackend(gen, batch=4)
+    src = synthetic_source(64, seed=1).to(DEV)
+    kp_s = synthetic_keypoints(1, 10, seed=0)
+    kp_a, kp_b = synthetic_keypoints(6, 10, seed=2), synthetic_keypoints(6, 10, seed=30)
+    first, _ = animate_clip(be, src, kp_s, kp_a, 64, 64, to_host=True)
+    assert first.is_pinned()
+    keep = first.clone()
+    as_numpy = first.numpy()                       # a numpy view keeps the buffer out of circulation as well
+    second, _ = animate_clip(be, src, kp_s, kp_b, 64, 64, to_host=True)
+    assert second.data_ptr() != first.data_ptr()
+    assert torch.equal(first, keep) and not torch.equal(first, second)
+    ptr_first = first.data_ptr()
+    del first
+    third, _ = animate_clip(be, src, kp_s, kp_b, 64, 64, to_host=True)       # the numpy view still holds the first buffer
+    assert third.data_ptr() not in (ptr_first, second.data_ptr()) and np.array_equal(as_numpy, keep.numpy())
+    assert torch.equal(third, second)
+    del as_numpy, third
+    fourth, _ = animate_clip(be, src, kp_s, kp_a, 64, 64, to_host=True)      # dropped buffers come back: no new pinning
+    assert fourth.data_ptr() in (ptr_first, ) or len(be._host[(torch.float32, (3, 64, 64))]) <= 3
+    assert torch.equal(fourth, keep)
+
+
 def _rank_worker(rank, world, port, total, batch, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -9,8 +9,8 @@ from conftest import TOL
 from eamm_amd import EngineBackend, OcclusionAwareGenerator, animate_clip, hot_path_config, tiny_config
 from eamm_amd.weights import synthetic_keypoints, synthetic_source, synthetic_state_dict
 from oracle import eamm_oracle as orc
-from test_oracle_golden import (gray_config, inputs_from_fixture, load_case, rgba_config, sample, six_channel_config,
-                                two_channel_config)
+from test_oracle_golden import (NUM_KP_CASES, gray_config, inputs_from_fixture, load_case, num_kp_config, rgba_config, sample,
+                                six_channel_config, two_channel_config)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -49,7 +49,7 @@ def report(tag, errs):
                                          ("tiny64_nojac", tiny_config), ("full256_clip2", hot_path_config),
                                          ("full512_clip1", hot_path_config),
                                          ("tiny64_gray", gray_config), ("tiny64_two_channels", two_channel_config),
-                                         ("tiny64_rgba", rgba_config), ("tiny64_six_channels", six_channel_config)])
+                                         ("tiny64_rgba", rgba_config), ("tiny64_six_channels", six_channel_config)] + NUM_KP_CASES)
 def test_module_forward_matches_reference_fixture(name, cfg_fn):
     """Reference contract forward(source, kp_driving, kp_source) -> dict, against reference outputs.  The last two: one and two
     image channels (num_channels; generator.py:14 accepts any) -- [n,C,H,W] in and out, run as the zero-extended RGB network -- and
@@ -272,6 +272,24 @@ def test_edge_cases_and_errors():
     with torch.no_grad():
         ref = orc.generator_forward(synthetic_state_dict(cfg, seed=99), cfg, src, kp_d, kp_s)["prediction"]
     assert float((b.cpu() - ref).abs().max()) <= TOL["prediction"]
+
+
+def test_num_kp_range_is_1_to_30_and_other_values_are_refused_with_the_documented_error():
+    """num_kp enters the 4(K+1)-channel hourglass input line, the softmax width of the flow head and its 7(K+2)-column padding; the
+    library accepts 1 .. 30 (reference fixtures at 1 / 5 / 15 / 30 above) and refuses the rest by name instead of computing garbage
+    (the reference, dense_motion.py:15-18, accepts any K: a documented limit)."""
+    src = synthetic_source(64, seed=1).to(DEV)
+    for k in (31, 40):
+        cfg = num_kp_config(k)()
+        gen = OcclusionAwareGenerator(**cfg)
+        gen.load_state_dict(synthetic_state_dict(cfg, seed=1234), strict=True)      # the holders take any K ...
+        gen = gen.to(DEV).eval()
+        with pytest.raises(RuntimeError, match=r"num_kp must be 1 \.\. 30 \(got %d\)" % k):    # ... the engine refuses it at its first use
+            gen(src, kp_source=cuda(synthetic_keypoints(1, k, seed=0)), kp_driving=cuda(synthetic_keypoints(1, k, seed=2)))
+    # a K that differs between the module and the key points it is fed: the reference fails inside its tensor algebra; here by name
+    gen = generator(tiny_config)
+    with pytest.raises(RuntimeError):
+        gen(src, kp_source=cuda(synthetic_keypoints(1, 10, seed=0)), kp_driving=cuda(synthetic_keypoints(1, 9, seed=2)))
 
 
 VARIANTS = {

@@ -18,6 +18,10 @@ CASES = [("kp_tiny64", lambda: tiny_kp_config(), False), ("kp_full256", kp_detec
          ("kp_tiny64_gray", lambda: {**tiny_kp_config(), "num_channels": 1}, False),   # one image channel (keypoint_detector.py:17-21)
          ("kp_tiny64_rgba", lambda: {**tiny_kp_config(), "num_channels": 4}, False),   # four / six: four channels per float4 slot
          ("kp_tiny64_six_channels", lambda: {**tiny_kp_config(), "num_channels": 6}, False)]
+# round 6: num_kp != 10 (reference keypoint_detector.py:24-41 sizes the heat-map and jacobian heads by it)
+for _k in (1, 5, 15, 30):
+    CASES.append((f"kp_tiny64_k{_k}", (lambda k=_k: {**tiny_kp_config(), "num_kp": k}), False))
+    CASES.append((f"kpa_tiny_k{_k}", (lambda k=_k: {**tiny_kp_config(audio=True), "num_kp": k}), True))
 
 
 def load(name, cfg, audio):

@@ -31,10 +31,22 @@ def six_channel_config():
     return {**tiny_config(), "num_channels": 6}
 
 
+def num_kp_config(k, full=False):
+    """num_kp != 10 (reference dense_motion.py:15-18, generator.py:14 accept any; round 6)."""
+    def make():
+        return {**(hot_path_config() if full else tiny_config()), "num_kp": k}
+    make.__name__ = f"{'full' if full else 'tiny'}_kp{k}_config"
+    return make
+
+
+NUM_KP_CASES = [("tiny64_kp1", num_kp_config(1)), ("tiny64_kp5", num_kp_config(5)), ("tiny64_kp15", num_kp_config(15)),
+                ("tiny64_kp30", num_kp_config(30)), ("tiny64_kp30_nojac", num_kp_config(30)),
+                ("full256_kp15", num_kp_config(15, full=True)), ("full256_kp5", num_kp_config(5, full=True))]
+
 CASES = [("tiny64_clip3", tiny_config), ("tiny64_batch2", tiny_config), ("tiny64_nojac", tiny_config),
          ("full256_clip2", hot_path_config), ("full512_clip1", hot_path_config),
          ("tiny64_gray", gray_config), ("tiny64_two_channels", two_channel_config),
-         ("tiny64_rgba", rgba_config), ("tiny64_six_channels", six_channel_config)]
+         ("tiny64_rgba", rgba_config), ("tiny64_six_channels", six_channel_config)] + NUM_KP_CASES
 
 
 def load_case(name):

@@ -56,6 +56,15 @@ def test_bottleneck_timeline_union(tmp_path):
     avg = [l for l in out.splitlines() if l.startswith("average over the timed calls")][0]
     assert f"union {window + 0.040:.4f} ms" in avg and f"sum of windows {2 * window:.4f} ms" in avg
     assert "trace / events = 1.0000" in out
+    # --per-launch-frac (round 6): roofline.frac from the trace's per-kernel AVERAGES alone -- 2 chains x 9.664 GFLOP
+    # per launch / (170 us GEMM + 30 us transform) / 157.3 TFLOP/s; the hourglass-level GEMM (fewer dispatches) must not be picked
+    line["roofline"]["per_launch"] = {"executed_gflop": 9.664, "avg_launch_ms": 0.170, "frames": 8}
+    (tmp_path / "line.json").write_text(json.dumps(line))
+    out3 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), "--per-launch-frac",
+                           str(tmp_path / "line.json"), str(db), str(tmp_path / "line.json")], capture_output=True, text=True, check=True).stdout
+    want = 2 * 9.664 / ((G + T) * 1e-9) / 1e3 / 157.3     # GFLOP / s -> TFLOP/s -> fraction of the peak
+    assert f"= {want:.4f}" in out3 and "wino4_gemm_kernel<2, 4, 2, 4, 2, 8, 0>" in out3 and "avg 170.00 us" in out3 and "avg 30.00 us" in out3
+    assert f"derived / reported = {want / 0.59:.3f}" in out3 and "trace GEMM avg / HIP-event GEMM avg = 1.000" in out3
     # the plain summary mode still works on the same database
     out2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), str(db)], capture_output=True, text=True,
                           check=True).stdout

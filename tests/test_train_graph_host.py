@@ -108,6 +108,47 @@ def test_tensor_slots_follow_structural_changes():
     assert not ids & set(gen._weights_version()[:len(v2) // 2])      # the copy reads ITS tensors, not the original's
 
 
+def test_epoch_sees_container_mutators_and_submodule_apply():
+    """(1) ``ModuleList.insert`` / ``Sequential.insert`` / ``pop`` / ``append`` write ``_modules`` directly -- no registration
+    call -- and (2) ``_apply`` on a SUB-module (``gen.first.double()``) changes neither a tensor's identity nor its version counter: both
+    must move the generator's structure epoch, or ``_weights_unchanged()`` keeps an engine with stale weights."""
+    from eamm_amd import OcclusionAwareGenerator, tiny_config
+    gen = OcclusionAwareGenerator(**tiny_config())
+    gen._tensor_slots()
+    gen._remember_weights()
+    assert gen._weights_unchanged()
+    n_slots = len(gen._tensor_slots())
+    blk = type(gen.down_blocks[0])(32, 32, 3)
+    gen.down_blocks.insert(0, blk)                                   # (structurally nonsense; the point is that it is SEEN)
+    assert not gen._weights_unchanged()
+    assert len(gen._tensor_slots()) > n_slots
+    gen._remember_weights()
+    assert gen._weights_unchanged()
+    gen.down_blocks.pop(0)
+    assert not gen._weights_unchanged() and len(gen._tensor_slots()) == n_slots
+    gen._remember_weights()
+    from eamm_amd.generator import _Sequential
+    res = type(gen.bottleneck[0])
+    gen.extra = _Sequential(res(128), res(128))                      # (the bottleneck itself has NAMED entries r0..r5, which
+    gen._remember_weights()                                          #  torch's own Sequential.insert cannot renumber)
+    assert gen._weights_unchanged()
+    gen.extra.insert(0, res(128))                                    # nn.Sequential.insert
+    assert not gen._weights_unchanged()
+    gen._remember_weights()
+    del gen.extra[0]
+    assert not gen._weights_unchanged()
+    del gen.extra
+    gen._remember_weights()
+    assert gen._weights_unchanged()
+    before = gen.first.conv.weight
+    gen.first.double()                                               # _apply on a sub-module: same Parameter object, same version
+    assert gen.first.conv.weight is before and before.dtype == torch.float64
+    assert not gen._weights_unchanged()
+    gen._remember_weights()
+    gen.dense_motion_network.hourglass.float()
+    assert not gen._weights_unchanged()
+
+
 def test_clip_interface_refuses_inputs_that_require_grad():
     """encode_source / forward_frames are the graph-free inference path; an input that asks for a gradient is refused
     (forward() is the differentiable entry) instead of being detached silently."""

@@ -5,7 +5,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 SIZE=${1:-256}; BATCH=${2:-16}; TAG=${3:-${SIZE}_b${BATCH}}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
@@ -17,6 +17,8 @@ grep '^{' $O/kt_bench.log > $O/bench_under_kernel_trace.json
 # the bottleneck stage's union window re-derived from the trace's kernel timestamps (vs bench.py's HIP events, same run)
 $BENCH > $O/bench_unprofiled.log 2>&1; grep '^{' $O/bench_unprofiled.log > $O/bench_unprofiled.json   # the same command without the profiler
 python tools/rocpd_summary.py --bneck-timeline $O/bench_under_kernel_trace.json $O/kt/kt_results.db $O/bench_unprofiled.json > $O/bneck_timeline.txt 2>&1
+# roofline.frac re-derived from the trace's per-kernel averages alone (the chains drift apart under the profiler; durations do not)
+python tools/rocpd_summary.py --per-launch-frac $O/bench_under_kernel_trace.json $O/kt/kt_results.db $O/bench_unprofiled.json > $O/per_launch_frac.txt 2>&1
 pmc() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o $name -- $BENCH > $O/$name.log 2>&1; python tools/rocpd_summary.py $O/$name/${name}_results.db | grep -v rocclr > $O/pmc_$name.txt; }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE

@@ -143,9 +143,53 @@ def timeline_report(bench_json, db):
     return u_avg, ev
 
 
+def per_launch_frac(bench_json, db):
+    """`roofline.frac` of the contract line RE-DERIVED from tracked per-kernel averages alone: under rocprofv3 the
+    two chains of a 16-frame step drift apart (every dispatch costs the host ~10 us, eager and graph replay alike), so the trace's own
+    union of the chains' windows is a different experiment; the per-kernel DURATIONS are not affected by that drift.  Per chain
+    (stream) the bottleneck stage is `nres` x (input transform, GEMM) back to back, and the chains run side by side, so
+
+        frac = chains x (executed GFLOP of one GEMM launch) / (avg GEMM duration + avg transform duration) / chip fp32 matrix peak
+
+    with every number taken from the kernel trace (durations) and from the launch geometry the bench line records (FLOP per launch)."""
+    line = json.load(open(bench_json))
+    roof = line["roofline"]
+    chains = int(roof.get("pass_chains", roof.get("chains", 2)))
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, count(*), avg(duration), min(duration), max(duration) from kernels group by name").fetchall()
+    gemms = [r for r in rows if "wino4_gemm_kernel" in r[0]]
+    trans = [r for r in rows if "wino4_input_transform_kernel" in r[0]]
+    if not gemms or not trans:
+        raise SystemExit("no wino4 GEMM / input-transform dispatches in the trace")
+    g = max(gemms, key=lambda r: r[1])
+    t = max(trans, key=lambda r: r[1])
+    steps_traced = g[1] / (chains * 12.0)
+    gflop_launch = roof["per_launch"]["executed_gflop"]
+    g_us, t_us = g[2] / 1e3, t[2] / 1e3
+    frac_pair = chains * gflop_launch / ((g_us + t_us) * 1e-6) / 1e3 / FP32_MFMA_PEAK_TFLOPS
+    frac_gemm = gflop_launch / (g_us * 1e-6) / 1e3 / FP32_MFMA_PEAK_TFLOPS
+    print(f"== roofline.frac of the contract line from per-kernel averages of {db}")
+    print(f"GEMM       {short(g[0])}: {g[1]} launches (= {steps_traced:.1f} steps x {chains} chains x 12), avg {g_us:.2f} us (min {g[3] / 1e3:.2f}, max {g[4] / 1e3:.2f})")
+    print(f"transform  {short(t[0])}: {t[1]} launches, avg {t_us:.2f} us (min {t[3] / 1e3:.2f}, max {t[4] / 1e3:.2f})")
+    print(f"executed GFLOP per GEMM launch (bench line, launch geometry): {gflop_launch:.3f}  ({roof['per_launch'].get('frames', '?')} frames per launch)")
+    print(f"one launch alone:        {gflop_launch:.3f} GFLOP / {g_us:.2f} us / {FP32_MFMA_PEAK_TFLOPS} TFLOP/s = {frac_gemm:.4f} of the chip "
+          f"(a launch occupies 1/{chains} of the CUs: {frac_gemm * chains:.4f} of those)")
+    print(f"stage, {chains} chains side by side: {chains} x {gflop_launch:.3f} GFLOP / ({g_us:.2f} + {t_us:.2f}) us / {FP32_MFMA_PEAK_TFLOPS} = {frac_pair:.4f}")
+    print(f"bench.py line of the same run (HIP-event union of the chains' windows): frac {roof['frac']:.4f}"
+          f" -> derived / reported = {frac_pair / roof['frac']:.3f}")
+    if len(sys.argv) > 4:
+        ref = json.load(open(sys.argv[4]))["roofline"]
+        print(f"unprofiled bench.py line: frac {ref['frac']:.4f}, per_launch.avg_launch_ms {ref['per_launch']['avg_launch_ms']:.4f}"
+              f" -> derived / unprofiled = {frac_pair / ref['frac']:.3f}; trace GEMM avg / HIP-event GEMM avg = "
+              f"{g_us / (ref['per_launch']['avg_launch_ms'] * 1e3):.3f}")
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--bneck-timeline":
         timeline_report(sys.argv[2], sys.argv[3])
+        return
+    if len(sys.argv) >= 4 and sys.argv[1] == "--per-launch-frac":
+        per_launch_frac(sys.argv[2], sys.argv[3])
         return
     for path in sys.argv[1:]:
         con = sqlite3.connect(path)
