@@ -10,10 +10,10 @@ from .clip import EngineBackend, animate_clip, driving_keypoints, shard_bounds  
 from .keypoints import apply_emotion_offsets, normalize_kp, one_euro_smooth, smooth_keypoints  # noqa: F401
 from .pipeline import animate_from_features  # noqa: F401
 from .keypoint_detector import KPDetector, KPDetector_a  # noqa: F401
-from .deconv_tail import DeconvTail  # noqa: F401
+from .deconv_tail import DeconvTail, SplitFeatureMap  # noqa: F401
 from .sync_batchnorm import SynchronizedBatchNorm2d  # noqa: F401
 from .data_parallel import all_reduce_gradients  # noqa: F401
 from .config import kp_detector_config, kp_detector_a_config, tiny_kp_config  # noqa: F401
 
-__all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "animate_from_features", "driving_keypoints", "shard_bounds", "normalize_kp", "apply_emotion_offsets", "smooth_keypoints", "one_euro_smooth", "KPDetector", "KPDetector_a", "DeconvTail", "SynchronizedBatchNorm2d",
+__all__ = ["OcclusionAwareGenerator", "Engine", "EngineBackend", "animate_clip", "animate_from_features", "driving_keypoints", "shard_bounds", "normalize_kp", "apply_emotion_offsets", "smooth_keypoints", "one_euro_smooth", "KPDetector", "KPDetector_a", "DeconvTail", "SplitFeatureMap", "SynchronizedBatchNorm2d",
            "all_reduce_gradients", "hot_path_config", "tiny_config"]

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeamm_hip.so")
 
-ABI_VERSION = 4   # round 5: record entries (plan, knobs, stream set, flops total), eamm_op_one_euro with state / resume
+ABI_VERSION = 5   # round 6: split NHWC hand-over DeconvTail -> KPDetector_a (eamm_deconv_forward_split, eamm_kp_detect_features_split)
 
 EAMM_OK = 0
 ERR_ARG, ERR_STATE, ERR_KEY, ERR_HIP, ERR_NUMERIC = -1, -2, -3, -4, -5
@@ -93,12 +93,16 @@ SIGNATURES = {
     "eamm_kp_finalize_weights": (C.c_int, [C.c_void_p]),
     "eamm_kp_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(EammKpOutputs), C.c_void_p]),
     "eamm_kp_detect_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(EammKpOutputs), C.c_void_p]),
+    "eamm_kp_split_channels": (C.c_int, [C.c_void_p]),
+    "eamm_kp_detect_features_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(EammKpOutputs), C.c_void_p]),
     "eamm_deconv_create": (C.c_int, [C.POINTER(EammDeconvConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "eamm_deconv_destroy": (None, [C.c_void_p]),
     "eamm_deconv_last_error": (C.c_char_p, [C.c_void_p]),
     "eamm_deconv_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "eamm_deconv_finalize_weights": (C.c_int, [C.c_void_p]),
     "eamm_deconv_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "eamm_deconv_split_channels": (C.c_int, [C.c_void_p]),
+    "eamm_deconv_forward_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eamm_bn_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "eamm_bn_local_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eamm_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

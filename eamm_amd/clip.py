@@ -106,8 +106,14 @@ def driving_keypoints(deconv_tail, kp_detector_a, lstm_features: torch.Tensor, b
     if lstm_features.dim() != 2:
         raise RuntimeError(f"expected [T,C] LSTM features, got {tuple(lstm_features.shape)}")
     parts: Dict[str, List[torch.Tensor]] = {}
+    # round 6: both ends of `deco_out[:, t]` live in the library -- when the tail's output is 32 m + 3 channels wide (the shipped 35) it
+    # is handed to the heads in the layout they read (NHWC wide part + one float4 per pixel) instead of the reference's NCHW tensor
+    split = getattr(deconv_tail, "forward_split", None) if getattr(deconv_tail, "split_channels", lambda: 0)() else None
     for t0 in range(0, lstm_features.shape[0], batch):
-        kp = kp_detector_a(deconv_tail(lstm_features[t0:t0 + batch].contiguous()))
+        x = lstm_features[t0:t0 + batch].contiguous()
+        fm = split(x) if split is not None else deconv_tail(x)
+        detect = getattr(kp_detector_a, "detect", None)         # (stand-in detectors of the CPU tests have no such method)
+        kp = detect(fm, heatmap=False) if detect is not None else kp_detector_a(fm)
         for k in ("value", "jacobian"):
             if k in kp:
                 parts.setdefault(k, []).append(kp[k])

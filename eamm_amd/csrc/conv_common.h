@@ -85,6 +85,12 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, int phase, int
         OW = 2 * p.W;
     }
     const size_t pix = (size_t)(b * OH + oy) * OW + ox;
+    if (p.split_n > 0) {   // wide channels NHWC [.., split_n] + the last few as one float4 per pixel (no residual / second output here)
+        v = apply_act(v, p.act);
+        if (n < p.split_n) p.out[pix * p.split_n + n] = v;
+        else p.out2[pix * 4 + (n - p.split_n)] = v;
+        return;
+    }
     if (p.resid != nullptr) v += p.resid[pix * p.Cout + n];
     v = apply_act(v, p.act);
     if (p.nchw)
@@ -135,6 +141,14 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, Acc& acc, f
                 if (p.nphase == 4) {
                     y = 2 * y + (phase >> 1);
                     x = 2 * x + (phase & 1);
+                }
+                if (p.split_n > 0) {   // split NHWC hand-over (epilogue_store): wide channels with a split_n stride, the last float4 apart
+                    const size_t pix = (size_t)(b * OH + y) * OW + x;
+                    v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+                    v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+                    if (n < p.split_n) *reinterpret_cast<float4*>(p.out + pix * p.split_n + n) = v;
+                    else *reinterpret_cast<float4*>(p.out2 + pix * 4) = v;
+                    continue;
                 }
                 const size_t o = ((size_t)(b * OH + y) * OW + x) * p.Cout + n;
                 if (p.resid != nullptr) {
@@ -187,7 +201,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, Acc& acc, int m
             const bool nok = n < p.Cout;
             const float bias = p.bias[n];
             float s2 = 0.f, t2 = 0.f;
-            if (p.out2 != nullptr && nok) {
+            if (p.out2 != nullptr && nok && p.split_n == 0) {
                 s2 = p.s2[n];
                 t2 = p.t2[n];
             }

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs p, in
             int b, y, x;
             pix_decode(p, r, b, y, x);
             float s2 = 0.f, t2 = 0.f;
-            if (p.out2 != nullptr) {
+            if (p.out2 != nullptr && p.split_n == 0) {
                 s2 = p.s2[n];
                 t2 = p.t2[n];
             }
@@ -471,6 +471,9 @@ hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream,
     a.out2 = io.out2;
     a.s2 = io.s2;
     a.t2 = io.t2;
+    a.split_n = io.split_n;
+    if (io.split_n > 0 && (io.out2 == nullptr || io.resid != nullptr || io.pool || io.nchw || L.Cout > io.split_n + 4 || L.Cout <= io.split_n))
+        return hipErrorInvalidValue;
     a.linear = ((a.H | a.W) & 1) ? 1 : 0;                   // odd side: raster order (2x2 quads need even sides)
     if (a.linear && io.pool) return hipErrorInvalidValue;   // AvgPool2d(2) windows are the quads
     if (pl.splits > 1 && io.partial == nullptr) return hipErrorInvalidValue;

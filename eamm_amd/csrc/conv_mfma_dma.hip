@@ -18,6 +18,8 @@
 // Zero padding and the M tail are buffer-descriptor range misses (the DMA then writes zeros).
 #include "conv_common.h"
 
+#include <type_traits>
+
 namespace eamm {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -66,7 +68,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_dma_kernel(const ConvAr
     // stream then carries one v_add (the chunk's wave-uniform tap / channel displacement), one bit test and
     // one select (zero padding and the M tail = an offset the buffer descriptor rejects) -- the first version
     // redid the 2-D bounds test and the pixel address arithmetic per piece.
-    unsigned abase0[A_INSTR], abase1[A_INSTR], tapmask[A_INSTR];
+    // (7x7 has 49 taps: a 64-bit mask there, round 6 -- the key-point heads' 7x7 convolution on this kernel)
+    typedef typename std::conditional<(T > 32), unsigned long long, unsigned>::type tapmask_t;
+    unsigned abase0[A_INSTR], abase1[A_INSTR];
+    tapmask_t tapmask[A_INSTR];
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
         const int row = (wave * A_INSTR + j) * 8 + (lane >> 3);
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_dma_kernel(const ConvAr
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int yy = y + t / KW + oy, xx = x + t % KW + ox;
-                if (((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W)) tapmask[j] |= 1u << t;
+                if (((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W)) tapmask[j] |= (tapmask_t)1 << t;
             }
         }
     }
@@ -99,7 +104,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_dma_kernel(const ConvAr
     constexpr int NPIECE = A_INSTR + B_INSTR;
     // wave-uniform description of the chunk being fetched (set by chunk_src, read by dma_piece)
     int n_first = 1, n_st = 0;
-    unsigned n_delta = 0, n_tapbit = 0, n_woff = 0;
+    unsigned n_delta = 0, n_woff = 0;
+    tapmask_t n_tapbit = 0;
     auto chunk_src = [&](int ci, int st) {
         const int cc = ci / T, tap = ci - cc * T;
         const int dy = tap / KW + oy, dx = tap % KW + ox;
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_dma_kernel(const ConvAr
         const int C = n_first ? p.C0 : p.C1;
         const int coff = n_first ? c0 : c0 - p.C0;
         n_delta = (unsigned)(((dy * p.W + dx) * C + coff) * 4);   // two's complement: the lane's add wraps to the right offset
-        n_tapbit = 1u << tap;
+        n_tapbit = (tapmask_t)1 << tap;
         n_st = st;
         n_woff = (unsigned)((wtile + ci) * (BN * BK) + wave * (B_INSTR * 8 * BK)) * 4u;
     };
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_dma_kernel(const ConvAr
     }
 
     // ---- epilogue
-    if (p.partial == nullptr && !p.pool && !p.nchw && (p.Cout & 3) == 0)
+    if (p.partial == nullptr && !p.pool && !p.nchw && (p.Cout & 3) == 0 && (p.split_n & 3) == 0)
         conv_epilogue_lds<MT, NT, WM, WN>(p, acc, smem, mbase, ntile, wm, wn, l31, half, phase, tid);
     else
         conv_epilogue<MT, NT, BN>(p, acc, mbase, ntile, wm, wn, l31, half, phase, split);
@@ -212,6 +218,11 @@ static hipError_t launch_dma_cfg(const ConvArgs& a, int blocks, hipStream_t stre
 
 template <int KH, int KW, bool PHASE>
 static hipError_t launch_dma_tile(int BM, int BN, const ConvArgs& a, int blocks, hipStream_t stream) {
+    if constexpr (KH == 7) {   // the key-point heads (K + 4 K logits: N = 64 or 128 per tile): two tiles are instantiated
+        if (BM == 512 && BN == 64) return launch_dma_cfg<KH, KW, 2, 2, 8, 1, PHASE>(a, blocks, stream);
+        if (BM == 256 && BN == 128) return launch_dma_cfg<KH, KW, 2, 2, 4, 2, PHASE>(a, blocks, stream);
+        return hipErrorInvalidValue;
+    }
     if (BM == 256 && BN == 256) return launch_dma_cfg<KH, KW, 2, 4, 4, 2, PHASE>(a, blocks, stream);
     if (BM == 256 && BN == 128) return launch_dma_cfg<KH, KW, 2, 2, 4, 2, PHASE>(a, blocks, stream);
     if (BM == 512 && BN == 64) return launch_dma_cfg<KH, KW, 2, 2, 8, 1, PHASE>(a, blocks, stream);
@@ -223,6 +234,7 @@ static hipError_t launch_dma_tile(int BM, int BN, const ConvArgs& a, int blocks,
 hipError_t conv_dma_launch_kernel(const ConvLayer& L, const ConvArgs& a, int blocks, hipStream_t stream) {
     if (L.phase) return launch_dma_tile<2, 2, true>(L.BM, L.BN, a, blocks, stream);
     if (L.kh == 3 && L.kw == 3) return launch_dma_tile<3, 3, false>(L.BM, L.BN, a, blocks, stream);
+    if (L.kh == 7 && L.kw == 7) return launch_dma_tile<7, 7, false>(L.BM, L.BN, a, blocks, stream);
     return hipErrorInvalidValue;
 }
 

@@ -174,8 +174,10 @@ struct Wino4Args {
     int act;
     const float* resid;    // NHWC [B,H,W,Cout]
     float* out;            // NHWC [B,H,W,Cout]
-    int groups;            // > 1: the six rows of transform points are split over `groups` workgroups per tile (small M)
-    float* zout;           // groups > 1: [24][Mq][Cout] x-folded products Z[i][q], finished by wino4_output_transform_kernel
+    int groups;            // > 1: the 36 transform points are split over `groups` workgroups per tile (small M): 2 / 3 / 6 = whole rows of six,
+                           // 12 = HALF rows (round 6: one frame per call = 16 blocks of 64 x 64 -> 192 workgroups of the eight-wave kernel)
+    float* zout;           // groups > 1: [24][Mq][Cout] x-folded products Z[i][q] (groups == 12: [48]: slot 2 i + half holds the partial x fold
+                           // of its three points), finished by wino4_output_transform_kernel
     float* epi_scratch;    // DBG 30 (timing experiment, EAMM_WINO4_EPI_V): the epilogue also writes 2.25 x the output here
 };
 
@@ -211,12 +213,13 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int ntile = L % p.ntiles;
     const int mtile = (L / p.ntiles) % p.mtiles;
-    const int grp = L / (p.ntiles * p.mtiles);          // which rows of transform points (0 when groups == 1)
-    const int rows_per = 6 / p.groups;
+    const int grp = L / (p.ntiles * p.mtiles);          // which transform points (0 when groups == 1)
+    const int xis_per = 36 / p.groups;                   // 36, 18, 12, 6: whole rows; 3 (groups == 12): half a row
+    const int xi0 = grp * xis_per;                       // first transform point of this workgroup
     const int mbase = mtile * BM;
     const int cchunks = p.C / BK;                         // channel chunks per transform point
-    const int ci_base = grp * rows_per * 6 * cchunks;     // first chunk of this workgroup's transform points
-    const int nsuper = rows_per * 6 * cchunks / SUB;      // barrier intervals
+    const int ci_base = xi0 * cchunks;                    // first chunk of this workgroup's transform points
+    const int nsuper = xis_per * cchunks / SUB;           // barrier intervals
 
     // DMA addressing.  Every piece is ONE buffer_load ... lds whose address splits into a per-lane VGPR part that never
     // changes (the lane's row and 16-byte slot) and a wave-uniform SGPR part that advances by a constant per interval
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     const unsigned a_wrap = plane_bytes - (unsigned)(cchunks * BK * 4);   // from the last chunks of xi to the first of xi + 1
 
     // uniform state of the interval whose pieces are issued next
-    unsigned sa_off = (unsigned)(grp * rows_per * 6) * plane_bytes;                                // (xi, cc) in V
+    unsigned sa_off = (unsigned)xi0 * plane_bytes;                                                 // (xi, cc) in V
     unsigned sb_off = (unsigned)((ntile * 36 * cchunks + ci_base) * BN * BK) * 4u +               // chunk ci in U
                       (unsigned)(wave * B_INSTR * 8 * BK) * 4u;                                    // + this wave's rows
     int dma_cc = 0, n_st = 0;
@@ -405,7 +408,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
     }
     __syncthreads();
     int st = 0;
-    int xi_left = per_xi, xj = 0, xrow = grp * rows_per;
+    int xi_left = per_xi, xj = xi0 % 6, xrow = xi0 / 6;
+    const bool half_rows = p.groups == 12;   // a workgroup's three points are half of row xrow: its Z is a partial x fold, slot = grp
     for (int sc = 0; sc < nsuper; ++sc) {
         const bool more = sc + D < nsuper;
         long long ts0 = 0, ts1 = 0, ts2 = 0;
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
             if (++xj == 6) {
                 xj = 0;
                 if (p.zout != nullptr)
-                    store_z(xrow++);
+                    store_z(half_rows ? grp : xrow++);
                 else
                     fold_y(xrow++);
             }
@@ -440,7 +444,10 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
         st = st + 1 == NST ? 0 : st + 1;
     }
 
-    if (p.zout != nullptr) return;
+    if (p.zout != nullptr) {
+        if (half_rows && xj != 0) store_z(grp);   // the first half of a row ends at j = 2: its partial fold has not left yet
+        return;
+    }
     // ---- epilogue: one output row py (four pixels) per round, staged through LDS, 16-byte row accesses.
     // A thread keeps the same (channel group, px) and walks BM / PER tiles; their output offsets are decoded once
     // (py only adds a row stride) and out-of-range tiles / channels get an offset the buffer descriptor rejects,
@@ -511,7 +518,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wino4_gemm_kernel(const Wino4Args
 
 // y fold of the split form: Y[p][q] = sum_i A^T[p][i] Z[i][q] (+ bias, residual, activation) -> the 4x4 output pixels;
 // POOL: followed by the 2x2 average of DownBlock2d (reference modules/util.py:903-921) -> 2x2 pixels of [B,H/2,W/2,Cout]
-template <bool POOL, bool RESID>
+// HALVES = 2 (groups == 12): row i arrives as two partial x folds, slots 2 i and 2 i + 1, added first (always in that order).
+template <bool POOL, bool RESID, int HALVES = 1>
 __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Z, const float* __restrict__ bias,
                                                                      const float* __restrict__ resid, int Mq, int Cout, int H,
                                                                      int W, int act, float* __restrict__ out) {
@@ -531,8 +539,19 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4_t zi[6];
+            if constexpr (HALVES == 2) {
+                f32x4_t za[6], zb[6];      // all twelve loads in flight before the first add
 #pragma unroll
-            for (int i = 0; i < 6; ++i) zi[i] = z[(size_t)(i * 4 + q) * plane];
+                for (int i = 0; i < 6; ++i) {
+                    za[i] = z[(size_t)((2 * i) * 4 + q) * plane];
+                    zb[i] = z[(size_t)((2 * i + 1) * 4 + q) * plane];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) zi[i] = za[i] + zb[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) zi[i] = z[(size_t)(i * 4 + q) * plane];
+            }
             const f32x4_t s12 = zi[1] + zi[2], d12 = zi[1] - zi[2], s34 = zi[3] + zi[4], d34 = zi[3] - zi[4];
             f32x4_t y[4];
             y[0] = zi[0] + s12 + s34;
@@ -677,7 +696,8 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     a.act = act;
     a.resid = resid;
     a.out = out;
-    if (groups != 1 && groups != 2 && groups != 3 && groups != 6) return hipErrorInvalidValue;
+    if (groups != 1 && groups != 2 && groups != 3 && groups != 6 && groups != 12) return hipErrorInvalidValue;
+    if (groups == 12 && (pool || (L.Cin / CONV_BK) * 3 % 4 != 0)) return hipErrorInvalidValue;   // half rows: three points x Cin / 32 chunks, four per interval
     if (groups > 1 && zbuf == nullptr) return hipErrorInvalidValue;
     a.groups = groups;
     a.zout = groups > 1 ? zbuf : nullptr;
@@ -716,7 +736,14 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     if (e != hipSuccess || groups == 1) return e;
     const size_t total = (size_t)a.Mq * (L.Cout / 4);
     const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)1 << 20);
-    if (pool)
+    if (groups == 12) {
+        if (resid != nullptr)
+            hipLaunchKernelGGL((wino4_output_transform_kernel<false, true, 2>), dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid,
+                               a.Mq, L.Cout, H, W, act, out);
+        else
+            hipLaunchKernelGGL((wino4_output_transform_kernel<false, false, 2>), dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid,
+                               a.Mq, L.Cout, H, W, act, out);
+    } else if (pool)
         hipLaunchKernelGGL((wino4_output_transform_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, zbuf, L.bias, resid,
                            a.Mq, L.Cout, H, W, act, out);
     else if (resid != nullptr)

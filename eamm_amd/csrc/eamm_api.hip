@@ -581,6 +581,11 @@ int eamm_finalize_weights(eamm_ctx* c) {
             z_elems = std::max(z_elems, 24 * tiles * c->w4down[i].Cout);
         }
     if (!c->wres1.empty() && (rc = dev_alloc(c, &c->wino_v, v_elems))) return rc;
+    {   // the half-row split of one- / few-frame calls (wino4_groups() == 12) leaves 48 planes of partial x folds instead of 24
+        const size_t tiles12 = std::min<size_t>((size_t)(c->cus / 12 / std::max(1, (c->Cb + 63) / 64)) * 64, (F * hwf + 15) / 16);
+        z_elems = std::max(z_elems, 48 * tiles12 * c->Cb);
+    }
+    c->wino_z_elems = z_elems;
     if (!c->w4res1.empty() && (rc = dev_alloc(c, &c->wino_z, z_elems))) return rc;
     if (c->epi_v && !c->w4res1.empty() && (rc = dev_alloc(c, &c->epi_scratch, (size_t)3 * c->cfg.max_frames * c->hf * c->wf * c->Cb))) return rc;
     c->up_buf.resize(c->nd);
@@ -777,7 +782,16 @@ static int bottleneck_form(const eamm_ctx* c, int n) {
 // the largest split that still fits one round of the chip (64 x 64 blocks, one per CU)
 static int wino4_groups(const eamm_ctx* c, int n) {
     const int nb = ((n * (c->hf / 4) * (c->wf / 4) + 63) / 64) * ((c->Cb + 63) / 64);
-    if (c->wino4_groups_knob) return c->wino4_groups_knob;
+    if (c->wino4_groups_knob == 12) {   // the half-row split needs Cb % 128 == 0 and 48 planes of workspace: else the rule below
+        if (c->Cb % (4 * CONV_BK) == 0 && (size_t)48 * n * (c->hf / 4) * (c->wf / 4) * c->Cb <= c->wino_z_elems) return 12;
+    } else if (c->wino4_groups_knob) {
+        return c->wino4_groups_knob;
+    }
+    // round 6: 12 = HALF rows of transform points.  One 256x256 frame is 16 blocks of 64 x 64: split 6 gave 96 workgroups (run as 192
+    // narrow 32-tile four-wave blocks, one wave per SIMD, 21.5 us per launch); split 12 gives 192 workgroups of the eight-wave kernel
+    // (two waves per SIMD, twice the flops per operand byte) at the price of 48 instead of 24 planes of x-folded products
+    // MEASURED (profiles/r06_experiments.txt): 21.3 us per launch against the narrow plan's 21.5 and an output transform of 6.6 instead of 5.4 us --
+    // one frame 0.808 vs 0.811 ms: no gain, so the rule keeps 6; 12 stays a tested option (EAMM_WINO4_GROUPS=12, eamm_op_conv tile 2162)
     for (int gsel : {6, 3, 2})
         if (nb * gsel <= c->cus) return gsel;
     return 1;
@@ -1056,7 +1070,9 @@ static int forward_view(eamm_ctx* c, const FrameView& v, hipStream_t s, hipEvent
         if (sub) HIP_TRY(c, hipEventRecord(sub[nsub++], s));     \
     } while (0)
     const bool wino4 = form == 4;
-    const int w4g = (wino4 && !chained) ? wino4_groups(c, n) : 1;   // a chained view shares the chip: never split the point rows
+    int w4g_sel = (wino4 && !chained) ? wino4_groups(c, n) : 1;   // a chained view shares the chip: never split the point rows
+    if (w4g_sel == 12 && v.wino_z != c->wino_z) w4g_sel = 6;      // (the 48-plane form is sized for a call's first frames only)
+    const int w4g = w4g_sel;
     // (round 5: splitting a whole-pass chain's bottleneck once more -- 2 x 2 sub-chains of 4 frames -- was built and measured
     //  neutral, 3917 vs 3958 frames/s: the input transform is latency-bound and does not shrink with the frames per launch;
     //  profiles/r05_experiments.txt section 2, git 9500c6c)
@@ -1697,7 +1713,7 @@ int eamm_op_conv(int device, const float* in0, int C0, const float* in1, int C1,
         if (!done(hipMalloc((void**)&W.u, packed.size() * sizeof(float)), "hipMalloc") &&
             !done(hipMalloc((void**)&W.bias, bias.size() * sizeof(float)), "hipMalloc") &&
             !done(hipMalloc((void**)&V, vel * sizeof(float)), "hipMalloc") &&
-            !done(hipMalloc((void**)&Zb, (size_t)24 * B * ((Hin + 3) / 4) * ((Win + 3) / 4) * Cout * sizeof(float) + 16), "hipMalloc") &&
+            !done(hipMalloc((void**)&Zb, (size_t)(w4_groups == 12 ? 48 : 24) * B * ((Hin + 3) / 4) * ((Win + 3) / 4) * Cout * sizeof(float) + 16), "hipMalloc") &&
             !done(hipMemcpy(W.u, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") &&
             !done(hipMemcpy(W.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy")) {
             // timing-mode knob: EAMM_OP_WINO_PART = 1 times the input transform alone, 2 the GEMM alone

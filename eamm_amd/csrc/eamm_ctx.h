@@ -82,7 +82,8 @@ struct eamm_ctx : eamm::CtxBase {
     int cus = 256;                         // the device's CU count, read ONCE in eamm_create (the per-call launch rules size their splits by it)
     int wino4_groups_knob = 0;             // EAMM_WINO4_GROUPS read once in eamm_create (0: unset -> the rule in wino4_groups())
     float* wino_v = nullptr;               // [16][F*hf*wf/4][Cb] (F(2x2)) or [36][F*hf*wf/16][Cb] transformed activations
-    float* wino_z = nullptr;               // [24][F*hf*wf/16][Cb] x-folded products of the split F(4x4) form (few tiles)
+    float* wino_z = nullptr;               // [24][F*hf*wf/16][Cb] x-folded products of the split F(4x4) form (few tiles; [48] for the half-row split)
+    size_t wino_z_elems = 0;               // its size in floats
     int wino_min_m = 49152;                // smallest pixel count for which the bottleneck runs in Winograd F(2x2) form
     int wino4_min_m = 0;                   // ... in F(4x4) form: with the transform-point rows split over workgroups it wins from one frame up
     int wino_variant = 0;                  // wino_gemm_kernel pipeline variant (see wino_gemm_launch); in-pipeline all are within noise

@@ -20,6 +20,8 @@ struct eamm_deconv_ctx : eamm::CtxBase {
     eamm_deconv_config cfg{};
     int nl = 0;
     std::vector<ConvLayer> layers;
+    ConvLayer last_dma;           // round 6: the last layer's filters packed for the LDS-DMA 512 x 64 tile (batched calls: the clip harness's
+    bool has_last_dma = false;    // 64-frame front-end batches ran it at 0.29 of the fp32 matrix peak on the register-staged 128 x 64 tile)
     std::vector<float*> bufs;     // NHWC output of layer i (all but the last)
     float* partial = nullptr;
     size_t partial_elems = 0;
@@ -52,7 +54,7 @@ int fold_norm(eamm_deconv_ctx* c, const std::string& conv, const std::string& no
 }
 
 int finish_layer(eamm_deconv_ctx* c, ConvLayer* L, int kh, int kw, bool phase, int Cin, int Cout,
-                 const std::vector<float>& wf, const std::vector<float>& bf) {
+                 const std::vector<float>& wf, const std::vector<float>& bf, int dma_cfg = 0) {
     L->kh = kh;
     L->kw = kw;
     L->phase = phase;
@@ -61,15 +63,16 @@ int finish_layer(eamm_deconv_ctx* c, ConvLayer* L, int kh, int kw, bool phase, i
     L->Cout = Cout;
     L->BM = 128;
     L->BN = conv_tile_n(Cout);
-    L->dma_cfg = 0;
+    L->dma_cfg = dma_cfg;
+    if (dma_cfg > 0 && !conv_dma_tile(dma_cfg, &L->BM, &L->BN)) return fail(c, EAMM_ERR_ARG, "unknown dma tile %d", dma_cfg);
     L->ntiles = (Cout + L->BN - 1) / L->BN;
     const int taps = phase ? 4 : kh * kw;
     L->nchunks = taps * (Cin / CONV_BK);
     std::vector<float> packed(conv_packed_elems(taps, Cin, Cout, L->BN, phase ? 4 : 1));
     if (phase)
-        conv_pack_phases_host(wf.data(), Cout, Cin, nullptr, Cin, L->BN, false, packed.data());
+        conv_pack_phases_host(wf.data(), Cout, Cin, nullptr, Cin, L->BN, dma_cfg > 0, packed.data());
     else
-        conv_pack_host(wf.data(), Cout, Cin, kh, kw, nullptr, Cin, L->BN, false, false, packed.data());
+        conv_pack_host(wf.data(), Cout, Cin, kh, kw, nullptr, Cin, L->BN, false, dma_cfg > 0, packed.data());
     std::vector<float> bias_pad((size_t)L->ntiles * L->BN, 0.f);
     std::copy(bf.begin(), bf.end(), bias_pad.begin());
     if (int rc = upload(c, &L->w, packed)) return rc;
@@ -169,6 +172,10 @@ int eamm_deconv_finalize_weights(eamm_deconv_ctx* c) {
                                     (float)(W(ci, o, 3 - py - 2 * ty, 3 - px - 2 * tx) * sc[o]);
             }
             if ((rc = finish_layer(c, &c->layers[i], 2, 2, true, Cin, Cout, wf, bf))) return rc;
+            if (i + 1 == c->nl && Cout + 1 <= 64 && c->dma_min_m >= 0) {   // (+ 1: the split hand-over's zero column)
+                if ((rc = finish_layer(c, &c->last_dma, 2, 2, true, Cin, Cout, wf, bf, 3))) return rc;
+                c->has_last_dma = true;
+            }
         }
     }
     const size_t F = g.max_batch;
@@ -180,6 +187,7 @@ int eamm_deconv_finalize_weights(eamm_deconv_ctx* c) {
         for (int i = 0; i < c->nl; ++i) {
             const size_t M = i == 0 ? f : f * side_of(i - 1) * side_of(i - 1);
             need = std::max(need, conv_plan(c->layers[i], (int)M).partial_elems);
+            if (i + 1 == c->nl && c->has_last_dma) need = std::max(need, conv_plan(c->last_dma, (int)M).partial_elems);
         }
     c->partial_elems = need;
     if ((rc = dev_alloc(c, &c->partial, need))) return rc;
@@ -189,8 +197,30 @@ int eamm_deconv_finalize_weights(eamm_deconv_ctx* c) {
     return EAMM_OK;
 }
 
+// The private hand-over to KPDetector_a (round 6): the last layer's C_last = 32 m + 3 channels leave as NHWC [B,S,S,32 m] (`wide`, the
+// operand the heads' 7x7 MFMA convolution reads) + one float4 per pixel (`thin`: the last three channels and a zero, what the thin
+// 7x7 kernel reads) -- no NCHW tensor in between, no layout kernels on the other side.  0 when the channel count has no such split.
+int eamm_deconv_split_channels(const eamm_deconv_ctx* c) {
+    if (!c) return 0;
+    const int wide = c->cfg.channels[c->nl] - 3;
+    return (wide >= 32 && wide % 32 == 0) ? wide : 0;
+}
+
+static int deconv_run(eamm_deconv_ctx* c, const float* x, int B, float* out, float* thin, void* stream_);
+
+int eamm_deconv_forward_split(eamm_deconv_ctx* c, const float* x, int B, float* wide, float* thin, void* stream_) {
+    if (!c || !x || !wide || !thin) return fail(c, EAMM_ERR_ARG, "null argument");
+    if (eamm_deconv_split_channels(c) == 0)
+        return fail(c, EAMM_ERR_ARG, "the last layer's %d channels are not 32 m + 3: no split hand-over", c->cfg.channels[c->nl]);
+    return deconv_run(c, x, B, wide, thin, stream_);
+}
+
 int eamm_deconv_forward(eamm_deconv_ctx* c, const float* x, int B, float* out, void* stream_) {
     if (!c || !x || !out) return fail(c, EAMM_ERR_ARG, "null argument");
+    return deconv_run(c, x, B, out, nullptr, stream_);
+}
+
+static int deconv_run(eamm_deconv_ctx* c, const float* x, int B, float* out, float* thin, void* stream_) {
     if (!c->finalized) return fail(c, EAMM_ERR_STATE, "call eamm_deconv_finalize_weights first");
     if (B < 1 || B > c->cfg.max_batch) return fail(c, EAMM_ERR_ARG, "batch %d outside [1,%d]", B, c->cfg.max_batch);
     DeviceGuard guard(c->device);
@@ -203,11 +233,20 @@ int eamm_deconv_forward(eamm_deconv_ctx* c, const float* x, int B, float* out, v
         io.B = B;
         io.Hin = io.Win = i == 0 ? 1 : side_of(i - 1);
         io.act = last ? ACT_NONE : ACT_RELU;     // util.py:559-574: BatchNorm2d + ReLU after every layer but the last
-        io.nchw = last ? 1 : 0;
+        io.nchw = (last && !thin) ? 1 : 0;
         io.out = last ? out : c->bufs[i];
         io.partial = c->partial;
         io.partial_cap = c->partial_elems;
-        HIP_TRY(c, conv_launch(c->layers[i], io, s));
+        const bool dma = last && c->has_last_dma && (long long)B * io.Hin * io.Win >= c->dma_min_m;
+        if (last && thin) {   // split hand-over: column C_last (zero weights, zero bias) fills the float4's fourth slot
+            ConvLayer L = dma ? c->last_dma : c->layers[i];
+            io.split_n = L.Cout - 3;
+            io.out2 = thin;
+            L.Cout += 1;
+            HIP_TRY(c, conv_launch(L, io, s));
+            continue;
+        }
+        HIP_TRY(c, conv_launch(dma ? c->last_dma : c->layers[i], io, s));
     }
     return EAMM_OK;
 }

@@ -18,6 +18,9 @@ struct eamm_kp_ctx : eamm::CtxBase {
     std::vector<int> enc_c, dec_c;
     std::vector<LayerSet> hg_enc, hg_dec;
     ConvLayer head;               // kp (K) + jacobian (4*njm) stacked along Cout
+    ConvLayer head_dma;           // the same filters packed for the LDS-DMA tile (512 x 64 / 256 x 128), batched calls (round 6: the wide 7x7
+    bool has_head_dma = false;    // head is 73 % of KPDetector_a's per-frame time; 0.38 -> of the fp32 matrix peak on the register-staged tile)
+    int head_dma_min_m = 16384;   // smallest B*h*w for which it is used (EAMM_KP_HEAD_DMA_MIN_M; < 0: never)
     int head_cs = 64;             // pixel stride of the logits = K + 4*njm rounded up to 64 (round 6: 128 / 192 for num_kp 13 .. 30)
     // KPDetector_a whose feature map is 32 m + 3 channels wide (the shipped 35 = block_expansion 32 + num_channels_a 3): the heads
     // run as a 7x7 MFMA convolution over the first 32 m channels (K = 49 x 32 m instead of 49 x the next multiple of 32: 45 % fewer
@@ -27,6 +30,7 @@ struct eamm_kp_ctx : eamm::CtxBase {
     float *thin_w = nullptr, *thin_x = nullptr, *thin_y = nullptr, *thin_ws = nullptr;   // [64,3,7,7] filter, [B,h,w,4] input, [B,h,w,64] output, workspace
     float* aa_w = nullptr;
     float* img_stage = nullptr;   // num_channels 1 / 2: the image zero-extended to the three planes the anti-alias kernel reads
+    float* head_ws = nullptr;     // kp_head_launch's workspace (pixel-sliced reductions of batched calls)
     float *x_in = nullptr, *logits = nullptr, *partial = nullptr;
     size_t partial_elems = 0;
     std::vector<float*> e_buf, u_buf;
@@ -47,11 +51,11 @@ int run_head(eamm_kp_ctx* c, const float* in0, const float* in1, int B, const ea
     io.out = c->logits;
     io.partial = c->partial;
     io.partial_cap = c->partial_elems;
-    ConvLayer head = c->head;
+    ConvLayer head = (c->has_head_dma && c->head_dma_min_m >= 0 && (long long)B * c->h * c->w >= c->head_dma_min_m) ? c->head_dma : c->head;
     head.Cout = c->head_cs;  // logits are written with a head_cs-float pixel stride; channels >= K + 4*njm have zero weights
     HIP_TRY(c, conv_launch(head, io, s));
     HIP_TRY(c, kp_head_launch(c->logits, B, c->K, c->njm, c->h, c->w, c->head_cs, c->cfg.pad, c->cfg.temperature, o->value,
-                              o->jacobian, o->heatmap, s));
+                              o->jacobian, o->heatmap, s, c->head_ws));
     return EAMM_OK;
 }
 
@@ -144,6 +148,10 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
     c->Cin_pad = (cin + 31) / 32 * 32;
     std::vector<FoldSpec> parts = {{"kp", ""}};
     if (c->njm) parts.push_back({"jacobian", ""});
+    // LDS-DMA twin of the heads' 7x7 convolution: N = K + 4 K logits in one 64-column tile -> 512 x 64 (id 3), up to 128 -> 256 x 128 (id 2)
+    c->head_dma_min_m = env_int("EAMM_KP_HEAD_DMA_MIN_M", c->head_dma_min_m);
+    const int head_dma_cfg = c->head_dma_min_m < 0 ? 0 : (c->head_cs == 64 ? 3 : (c->head_cs == 128 ? 2 : 0));
+    c->has_head_dma = head_dma_cfg != 0;
     if (g.with_predictor) {
         c->hg_enc.resize(c->nb);
         c->hg_dec.resize(c->nb);
@@ -160,6 +168,7 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
         }
         // head input = cat[last up output (block_expansion), hourglass input (cin, stored padded)]  util.py:981-987
         if ((rc = build_layer(c, parts, 7, c->dec_c.back(), c->dec_c.back(), cin, c->Cin_pad, &c->head))) return rc;
+        if (head_dma_cfg && (rc = build_layer(c, parts, 7, c->dec_c.back(), c->dec_c.back(), cin, c->Cin_pad, &c->head_dma, MODE_PLAIN, nullptr, head_dma_cfg))) return rc;
         std::vector<float> aa((size_t)std::max(3, g.num_channels) * 169, 0.f);
         if (g.inv_scale != 1) {
             const HostTensor* t = find(c, "down.weight");
@@ -202,10 +211,12 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
                 o0 += co;
             }
             if ((rc = build_layer(c, parts, 7, wide, wide, 0, 0, &c->head))) return rc;
+            if (head_dma_cfg && (rc = build_layer(c, parts, 7, wide, wide, 0, 0, &c->head_dma, MODE_PLAIN, nullptr, head_dma_cfg))) return rc;
             if ((rc = upload(c, &c->thin_w, thin))) return rc;
             c->thin_wide = wide;
-        } else if ((rc = build_layer(c, parts, 7, c->feat_c, cp, 0, 0, &c->head))) {
-            return rc;
+        } else {
+            if ((rc = build_layer(c, parts, 7, c->feat_c, cp, 0, 0, &c->head))) return rc;
+            if (head_dma_cfg && (rc = build_layer(c, parts, 7, c->feat_c, cp, 0, 0, &c->head_dma, MODE_PLAIN, nullptr, head_dma_cfg))) return rc;
         }
     }
     if (c->head.Cout != c->K + 4 * c->njm) return fail(c, EAMM_ERR_KEY, "kp / jacobian heads have the wrong channel count");
@@ -219,6 +230,7 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
         if ((rc = dev_alloc(c, &c->thin_ws, conv7_thin_workspace_floats((int)F, c->h, c->w, 64)))) return rc;
     }
     if ((rc = dev_alloc(c, &c->logits, F * hw * c->head_cs))) return rc;
+    if ((rc = dev_alloc(c, &c->head_ws, kp_head_workspace_floats((int)F, c->K)))) return rc;
     size_t need = 0;
     auto upd1 = [&](const ConvLayer& L, size_t M) { need = std::max(need, conv_plan(L, (int)M).partial_elems); };
     if (g.with_predictor) {
@@ -241,7 +253,10 @@ int eamm_kp_finalize_weights(eamm_kp_ctx* c) {
                     }
                 }
     }
-    for (size_t f = 1; f <= F; ++f) upd1(c->head, f * hw);
+    for (size_t f = 1; f <= F; ++f) {
+        upd1(c->head, f * hw);
+        if (c->has_head_dma) upd1(c->head_dma, f * hw);
+    }
     c->partial_elems = need;
     if ((rc = dev_alloc(c, &c->partial, need))) return rc;
     c->sd.clear();
@@ -315,6 +330,22 @@ int eamm_kp_detect_features(eamm_kp_ctx* c, const float* feature_map, int B, con
     const int cp = (c->feat_c + 31) / 32 * 32;
     HIP_TRY(c, nchw_to_nhwc_pad_launch(feature_map, B, c->feat_c, c->h, c->w, cp, c->x_in, s));
     return run_head(c, c->x_in, nullptr, B, o, s);               // keypoint_detector.py:180-203
+}
+
+// Round 6: the feature map as DeconvTail hands it over privately (eamm_deconv_forward_split): `wide` NHWC [B,h,w,32 m] + `thin` one
+// float4 per pixel -- the two operands the heads read, so no layout kernel runs here.  eamm_kp_split_channels: 32 m, or 0 when this
+// handle's heads do not run in the wide + thin form.
+int eamm_kp_split_channels(const eamm_kp_ctx* c) { return (c && c->finalized && !c->cfg.with_predictor) ? c->thin_wide : 0; }
+
+int eamm_kp_detect_features_split(eamm_kp_ctx* c, const float* wide, const float* thin, int B, const eamm_kp_outputs* o, void* stream_) {
+    if (int rc = check_call(c, wide, B, o)) return rc;
+    if (!thin) return fail(c, EAMM_ERR_ARG, "null argument");
+    if (c->cfg.with_predictor || !c->thin_wide) return fail(c, EAMM_ERR_STATE, "this handle's heads do not take the split feature map");
+    DeviceGuard guard(c->device);
+    if (guard.status != hipSuccess) return fail(c, EAMM_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(c, conv7_thin_in_launch(thin, c->thin_w, nullptr, B, c->h, c->w, 64, 0, c->thin_y, c->thin_ws, s));
+    return run_head(c, wide, nullptr, B, o, s, c->thin_y);   // keypoint_detector.py:180-203
 }
 
 }  // extern "C"

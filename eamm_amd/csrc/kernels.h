@@ -52,6 +52,8 @@ struct ConvArgs {
     float* out2;           // optional second output relu(out*s2 + t2): the next res-block's pre-activation
     const float* s2;
     const float* t2;
+    int split_n;           // > 0 (round 6, the private DeconvTail -> KPDetector_a hand-over): channels n < split_n go to `out` as NHWC with
+                           // a split_n-float pixel stride, channels split_n <= n < Cout to `out2` as one float4 per pixel (Cout <= split_n + 4)
 };
 
 // Packed convolution weights resident on the device.
@@ -93,6 +95,7 @@ struct ConvIO {
     float* out; float* out2; const float* s2; const float* t2;
     float* partial;         // split-K workspace
     size_t partial_cap;     // its capacity in floats (the slice count is clamped to fit)
+    int split_n;            // ConvArgs::split_n
 };
 hipError_t conv_launch(const ConvLayer& L, const ConvIO& io, hipStream_t stream, int force_splits = 0);
 
@@ -197,7 +200,10 @@ hipError_t nchw_to_nhwc_pad_launch(const float* src /*[B,planes,H,W]*/, int B, i
                                    float* dst /*[B,H,W,Cpad]*/, hipStream_t s, int planes = 0 /*0: = C; else the first C of them*/);
 hipError_t kp_head_launch(const float* logits /*[B,h,w,Cs]*/, int B, int K, int njm, int h, int w, int Cs, int pad,
                           float temperature, float* value /*[B,K,2]*/, float* jacobian /*[B,K,2,2] or null*/,
-                          float* heatmap /*[B,K,h-6+2pad,w-6+2pad] or null*/, hipStream_t s);
+                          float* heatmap /*[B,K,h-6+2pad,w-6+2pad] or null*/, hipStream_t s,
+                          float* ws = nullptr /* kp_head_workspace_floats(B, K) floats: batched calls run the pixel-sliced form */);
+constexpr int KP_HEAD_SLICES = 8;
+size_t kp_head_workspace_floats(int B, int K);
 // ---- training-mode BatchNorm forward (batchnorm.hip; SURVEY.md 8f row N4, first slice)
 size_t bn_workspace_floats(int N, int C, int HW);
 hipError_t bn_local_sums_launch(const float* x /*[N,C,HW]*/, int N, int C, int HW, float* sums /*[6C+2]*/, float* workspace,

@@ -729,16 +729,159 @@ __global__ __launch_bounds__(256) void kp_head_kernel(const float* __restrict__ 
     }
 }
 
+// Round 6, batched calls: the reductions split over PIXEL SLICES so that the whole chip streams the logits, each line read by one block.
+// The per-(image, key point) kernel above runs K x B blocks that each read one float of every 256-byte logit line three times over;
+// with one block per image (a first version of this round, 109 us per 64-frame batch against 116) the 67 MB of a batch hang on 64 CUs
+// at ~30 GB/s each.  Here block (b, slice) owns n / S pixels and ALL key points of a group of KG: pass 1 its slice's maxima, pass 2 the
+// sums relative to them (the slice's lines come out of the L2 the second time) -> `part` [B][K][S][8] = (max, s, vx, vy, j0..j3).
+// kp_head_combine_kernel folds the slices in slice order: M = max m_s, total = sum_s exp(m_s - M) * part_s (deterministic; the
+// rescaling rounds once more than the one-block form: <= 2e-7 of the value), writes value / jacobian and (M, S) for the optional
+// heat-map pass kp_head_heatmap_kernel.
+template <int KG>
+__global__ __launch_bounds__(256) void kp_head_slice_kernel(const float* __restrict__ logits, int K, int njm, int h, int w, int Cs,
+                                                            int off, int oh, int ow, float temperature, int S,
+                                                            float* __restrict__ part) {
+    constexpr int NV = 7;                       // s, vx, vy, j0..j3
+    __shared__ float red[4][KG * NV];           // one row per wave
+    __shared__ float fin[KG];
+    const int b = blockIdx.x, sl = blockIdx.y, k0 = blockIdx.z * KG;
+    const int kn = min(KG, K - k0);
+    const int n = oh * ow;
+    const int i0 = (int)((long long)n * sl / S), i1 = (int)((long long)n * (sl + 1) / S);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* base = logits + (size_t)b * h * w * Cs;
+    float m[KG];
+#pragma unroll
+    for (int k = 0; k < KG; ++k) m[k] = -INFINITY;
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const float* px = base + (size_t)((i / ow + off) * w + i % ow + off) * Cs + k0;
+#pragma unroll
+        for (int k = 0; k < KG; ++k)
+            if (k < kn) m[k] = fmaxf(m[k], px[k] / temperature);
+    }
+#pragma unroll
+    for (int k = 0; k < KG; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], o));
+        if (lane == 0) red[wave][k] = m[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < KG) fin[threadIdx.x] = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KG; ++k) m[k] = fin[k];
+    __syncthreads();
+    float acc[KG][NV];
+#pragma unroll
+    for (int k = 0; k < KG; ++k)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[k][v] = 0.f;
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const int yy = i / ow, xx = i % ow;
+        const float* px = base + (size_t)((yy + off) * w + xx + off) * Cs;
+        const float gx = grid_coord(xx, ow), gy = grid_coord(yy, oh);
+#pragma unroll
+        for (int k = 0; k < KG; ++k) {
+            if (k < kn) {
+                const float e = expf(px[k0 + k] / temperature - m[k]);
+                acc[k][0] += e;
+                acc[k][1] = fmaf(e, gx, acc[k][1]);
+                acc[k][2] = fmaf(e, gy, acc[k][2]);
+                if (njm > 0) {
+                    const float* pj = px + K + 4 * (njm == 1 ? 0 : k0 + k);
+                    acc[k][3] = fmaf(e, pj[0], acc[k][3]);
+                    acc[k][4] = fmaf(e, pj[1], acc[k][4]);
+                    acc[k][5] = fmaf(e, pj[2], acc[k][5]);
+                    acc[k][6] = fmaf(e, pj[3], acc[k][6]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KG; ++k)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float x = acc[k][v];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            if (lane == 0) red[wave][k * NV + v] = x;
+        }
+    __syncthreads();
+    if (threadIdx.x < kn * 8) {
+        const int k = threadIdx.x >> 3, v = threadIdx.x & 7;
+        float r = v == 0 ? fin[k] : ((red[0][k * NV + v - 1] + red[1][k * NV + v - 1]) + red[2][k * NV + v - 1]) + red[3][k * NV + v - 1];
+        part[(((size_t)b * K + k0 + k) * S + sl) * 8 + v] = r;
+    }
+}
+
+__global__ __launch_bounds__(64) void kp_head_combine_kernel(const float* __restrict__ part, int K, int njm, int S,
+                                                            float* __restrict__ value, float* __restrict__ jacobian,
+                                                            float* __restrict__ stats) {
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float* p = part + ((size_t)b * K + k) * S * 8;
+        float M = -INFINITY;
+        for (int sl = 0; sl < S; ++sl) M = fmaxf(M, p[sl * 8]);
+        float t[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < S; ++sl) {
+            const float sc = expf(p[sl * 8] - M);        // (an empty slice has max -inf: scale 0, sums 0)
+#pragma unroll
+            for (int v = 0; v < 7; ++v) t[v] = fmaf(sc, p[sl * 8 + 1 + v], t[v]);
+        }
+        value[((size_t)b * K + k) * 2 + 0] = t[1] / t[0];
+        value[((size_t)b * K + k) * 2 + 1] = t[2] / t[0];
+        if (njm > 0 && jacobian) {
+            float* jo = jacobian + ((size_t)b * K + k) * 4;
+            jo[0] = t[3] / t[0]; jo[1] = t[4] / t[0]; jo[2] = t[5] / t[0]; jo[3] = t[6] / t[0];
+        }
+        stats[((size_t)b * K + k) * 2 + 0] = M;
+        stats[((size_t)b * K + k) * 2 + 1] = t[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void kp_head_heatmap_kernel(const float* __restrict__ logits, const float* __restrict__ stats, int K, int h,
+                                                             int w, int Cs, int off, int oh, int ow, float temperature, int S,
+                                                             float* __restrict__ heatmap) {
+    const int b = blockIdx.x, sl = blockIdx.y;
+    const int n = oh * ow;
+    const int i0 = (int)((long long)n * sl / S), i1 = (int)((long long)n * (sl + 1) / S);
+    const float* base = logits + (size_t)b * h * w * Cs;
+    const float* st = stats + (size_t)b * K * 2;
+    for (int k = 0; k < K; ++k) {      // (k outer: a wave's stores of one key point are contiguous)
+        const float M = st[2 * k], Sd = st[2 * k + 1];
+        float* ho = heatmap + ((size_t)b * K + k) * n;
+        for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x)
+            ho[i] = expf(base[(size_t)((i / ow + off) * w + i % ow + off) * Cs + k] / temperature - M) / Sd;
+    }
+}
+
 hipError_t nchw_to_nhwc_pad_launch(const float* src, int B, int C, int H, int W, int Cpad, float* dst, hipStream_t s, int planes) {
     const size_t total = (size_t)B * H * W * Cpad;
     hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, B, C, H * W, Cpad, dst, planes > 0 ? planes : C);
     return hipGetLastError();
 }
 
+size_t kp_head_workspace_floats(int B, int K) { return (size_t)B * K * (KP_HEAD_SLICES * 8 + 2); }
+
 hipError_t kp_head_launch(const float* logits, int B, int K, int njm, int h, int w, int Cs, int pad, float temperature,
-                          float* value, float* jacobian, float* heatmap, hipStream_t s) {
+                          float* value, float* jacobian, float* heatmap, hipStream_t s, float* ws) {
     const int off = 3 - pad, oh = h - 2 * off, ow = w - 2 * off;
     if (off < 0 || oh < 1 || ow < 1) return hipErrorInvalidValue;
+    // batched calls with a workspace: pixel slices over the whole chip + a combine step (round 6, kp_head_slice_kernel above).  Few images
+    // (or no workspace): one block per (image, key point).  EAMM_KP_HEAD_SLICE_MIN_B (tuning aid): < 0 never
+    static const int slice_min_b = (int)knob_int("EAMM_KP_HEAD_SLICE_MIN_B", 8);
+    if (ws != nullptr && slice_min_b >= 0 && B >= slice_min_b) {
+        constexpr int KG = 10;
+        const int S = KP_HEAD_SLICES;
+        float* part = ws;
+        float* stats = ws + (size_t)B * K * S * 8;
+        hipLaunchKernelGGL(kp_head_slice_kernel<KG>, dim3(B, S, (K + KG - 1) / KG), dim3(256), 0, s, logits, K, njm, h, w, Cs, off, oh, ow,
+                           temperature, S, part);
+        hipLaunchKernelGGL(kp_head_combine_kernel, dim3(B), dim3(64), 0, s, part, K, njm, S, value, jacobian, stats);
+        if (heatmap)
+            hipLaunchKernelGGL(kp_head_heatmap_kernel, dim3(B, S), dim3(256), 0, s, logits, stats, K, h, w, Cs, off, oh, ow, temperature, S, heatmap);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(kp_head_kernel, dim3(K, B), dim3(256), 0, s, logits, K, njm, h, w, Cs, off, oh, ow, temperature,
                        value, jacobian, heatmap);
     return hipGetLastError();

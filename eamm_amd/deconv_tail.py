@@ -21,6 +21,31 @@ from .keypoint_detector import _refuse_silent_detach
 from .weights import DECONV_CHANNELS
 
 
+class SplitFeatureMap:
+    """A [B, 32 m + 3, S, S] feature map in the layout ``KPDetector_a``'s heads read: ``wide`` NHWC [B,S,S,32 m] and ``thin``
+    [B,S,S,4] (channels 32 m .. 32 m + 2 and a zero).  Produced by ``DeconvTail.forward_split``, accepted by ``KPDetector_a``."""
+    __slots__ = ("wide", "thin")
+
+    def __init__(self, wide: torch.Tensor, thin: torch.Tensor):
+        if (wide.dim() != 4 or thin.dim() != 4 or thin.shape[-1] != 4 or wide.shape[:3] != thin.shape[:3] or wide.dtype != torch.float32
+                or thin.dtype != torch.float32 or wide.device != thin.device):
+            raise RuntimeError(f"SplitFeatureMap: wide {tuple(wide.shape)} / thin {tuple(thin.shape)} do not belong together")
+        self.wide, self.thin = wide, thin
+
+    @property
+    def shape(self):
+        b, h, w, c = self.wide.shape
+        return (b, c + 3, h, w)
+
+    @property
+    def device(self):
+        return self.wide.device
+
+    def to_nchw(self) -> torch.Tensor:
+        """The reference's tensor (util.py:604-607 `deco_out[:, t]`): [B, 32 m + 3, S, S]."""
+        return torch.cat([self.wide, self.thin[..., :3]], dim=-1).permute(0, 3, 1, 2).contiguous()
+
+
 class DeconvTail(nn.Sequential):
     """MI355X-native stand-in for reference modules/util.py:559-576 (``AT_net2.decon``)."""
 
@@ -93,7 +118,22 @@ class DeconvTail(nn.Sequential):
         with torch.no_grad():
             return self._forward(x)
 
-    def _forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward_split(self, x: torch.Tensor) -> "SplitFeatureMap":
+        """The same layers, the result in the PRIVATE layout ``KPDetector_a``'s heads read (round 6): ``wide`` NHWC
+        [B,S,S,C_last - 3] + ``thin`` [B,S,S,4] (the last three channels and a zero) instead of the reference's NCHW
+        [B,C_last,S,S] (util.py:604-607) -- both ends of that tensor live in this library, so the clip harness
+        (``driving_keypoints``) skips the NCHW round trip.  Only when C_last = 32 m + 3 (the shipped 35); the values are
+        those of ``forward`` bit for bit (``SplitFeatureMap.to_nchw()`` gives the reference's tensor back)."""
+        _refuse_silent_detach(self, x)
+        with torch.no_grad():
+            return self._forward(x, split=True)
+
+    def split_channels(self) -> int:
+        """``wide`` channel count of ``forward_split`` (0: this tail's output has no 32 m + 3 split)."""
+        wide = self.channels[-1] - 3
+        return wide if wide >= 32 and wide % 32 == 0 else 0
+
+    def _forward(self, x: torch.Tensor, split: bool = False):
         if x.dim() == 4 and x.shape[2:] == (1, 1):
             x = x.flatten(1)
         if x.dim() != 2 or x.shape[1] != self.channels[0] or x.dtype != torch.float32:
@@ -102,8 +142,18 @@ class DeconvTail(nn.Sequential):
         self._ensure(b)
         x = x.contiguous()
         side = 4 << (len(self.channels) - 2)
-        out = torch.empty(b, self.channels[-1], side, side, device=x.device)
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        if split:
+            wide_c = self.split_channels()
+            if not wide_c:
+                raise RuntimeError(f"forward_split needs 32 m + 3 output channels, this tail has {self.channels[-1]}")
+            wide = torch.empty(b, side, side, wide_c, device=x.device)
+            thin = torch.empty(b, side, side, 4, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().eamm_deconv_forward_split(self._ctx, C.c_void_p(x.data_ptr()), b, C.c_void_p(wide.data_ptr()),
+                                                                C.c_void_p(thin.data_ptr()), stream), self._ctx, deconv=True)
+            return SplitFeatureMap(wide, thin)
+        out = torch.empty(b, self.channels[-1], side, side, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().eamm_deconv_forward(self._ctx, C.c_void_p(x.data_ptr()), b, C.c_void_p(out.data_ptr()),
                                                       stream), self._ctx, deconv=True)

@@ -115,10 +115,24 @@ class _KPBase(nn.Module):
             _lib.check(L.eamm_kp_finalize_weights(ctx), ctx, kp=True)
         self._key = key
 
+    _want_heatmap = True      # detect(..., heatmap=False) clears it for one call: the clip harness never reads the heat-maps (demo.py:219-281)
+
+    def detect(self, x, heatmap: bool = True) -> Dict[str, torch.Tensor]:
+        """``forward`` with the heat-maps optional: ``heatmap=False`` returns {'value', 'jacobian'} only and skips the heat-map pass
+        (K x 58 x 58 floats per frame written for nobody: ``demo.py`` never reads them; ``driving_keypoints`` calls this)."""
+        self._want_heatmap = bool(heatmap)
+        try:
+            return self(x)
+        finally:
+            self._want_heatmap = True
+
     def _run(self, x: torch.Tensor, fn_name: str, hm_h: int, hm_w: int) -> Dict[str, torch.Tensor]:
         dev, b, k = x.device, x.shape[0], self._cfg["num_kp"]
-        out = {"value": torch.empty(b, k, 2, device=dev), "heatmap": torch.empty(b, k, hm_h, hm_w, device=dev)}
-        o = _lib.EammKpOutputs(value=out["value"].data_ptr(), heatmap=out["heatmap"].data_ptr())
+        out = {"value": torch.empty(b, k, 2, device=dev)}
+        o = _lib.EammKpOutputs(value=out["value"].data_ptr())
+        if self._want_heatmap:
+            out["heatmap"] = torch.empty(b, k, hm_h, hm_w, device=dev)
+            o.heatmap = out["heatmap"].data_ptr()
         if self.jacobian is not None:
             out["jacobian"] = torch.empty(b, k, 2, 2, device=dev)
             o.jacobian = out["jacobian"].data_ptr()
@@ -164,12 +178,23 @@ class KPDetector_a(_KPBase):
         super().__init__(block_expansion, num_kp, num_channels, max_features, num_blocks, temperature,
                          estimate_jacobian, scale_factor, single_jacobian_map, pad, num_channels_a, max_batch)
 
-    def forward(self, feature_map: torch.Tensor) -> Dict[str, torch.Tensor]:
-        _refuse_silent_detach(self, feature_map)
+    def forward(self, feature_map) -> Dict[str, torch.Tensor]:
+        """``feature_map``: the reference's float32 [B, C, h, w] tensor, or (round 6) the ``SplitFeatureMap`` ``DeconvTail.forward_split``
+        hands over (same values, the layout the heads read)."""
+        _refuse_silent_detach(self, feature_map if torch.is_tensor(feature_map) else feature_map.wide)
         with torch.no_grad():
             return self._forward(feature_map)
 
-    def _forward(self, feature_map: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def accepts_split(self, height: int, width: int, batch: int = 1) -> int:
+        """``wide`` channel count of the split feature map these heads read directly (``DeconvTail.forward_split``), 0 if they do
+        not run in the wide + thin form (round 6: the private NHWC hand-over).  Builds the handle for (height, width) maps."""
+        inv = self._cfg["inv_scale"]
+        self._ensure(height * inv, width * inv, batch)
+        return int(_lib.lib().eamm_kp_split_channels(self._ctx))
+
+    def _forward(self, feature_map) -> Dict[str, torch.Tensor]:
+        if not torch.is_tensor(feature_map) and hasattr(feature_map, "wide") and hasattr(feature_map, "thin"):
+            return self._forward_split(feature_map)
         if feature_map.dim() != 4 or feature_map.shape[1] != self.out_filters or feature_map.dtype != torch.float32:
             raise RuntimeError(f"expected a float32 [B,{self.out_filters},h,w] feature map, got "
                                f"{tuple(feature_map.shape)} {feature_map.dtype}")
@@ -177,3 +202,27 @@ class KPDetector_a(_KPBase):
         inv, pad = self._cfg["inv_scale"], self._cfg["pad"]
         self._ensure(h * inv, w * inv, b)
         return self._run(feature_map.contiguous(), "eamm_kp_detect_features", h - 6 + 2 * pad, w - 6 + 2 * pad)
+
+    def _forward_split(self, fm) -> Dict[str, torch.Tensor]:
+        b, c, h, w = fm.shape
+        if c != self.out_filters:
+            raise RuntimeError(f"expected a split [B,{self.out_filters},h,w] feature map, got {tuple(fm.shape)}")
+        inv, pad = self._cfg["inv_scale"], self._cfg["pad"]
+        self._ensure(h * inv, w * inv, b)
+        if int(_lib.lib().eamm_kp_split_channels(self._ctx)) != c - 3:
+            return self._forward(fm.to_nchw())          # heads not in the wide + thin form: the reference's tensor
+        wide, thin = fm.wide.contiguous(), fm.thin.contiguous()
+        dev, k = wide.device, self._cfg["num_kp"]
+        out = {"value": torch.empty(b, k, 2, device=dev)}
+        o = _lib.EammKpOutputs(value=out["value"].data_ptr())
+        if self._want_heatmap:
+            out["heatmap"] = torch.empty(b, k, h - 6 + 2 * pad, w - 6 + 2 * pad, device=dev)
+            o.heatmap = out["heatmap"].data_ptr()
+        if self.jacobian is not None:
+            out["jacobian"] = torch.empty(b, k, 2, 2, device=dev)
+            o.jacobian = out["jacobian"].data_ptr()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().eamm_kp_detect_features_split(self._ctx, C.c_void_p(wide.data_ptr()), C.c_void_p(thin.data_ptr()), b,
+                                                               C.byref(o), stream), self._ctx, kp=True)
+        return out

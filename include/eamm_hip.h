@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EAMM_ABI_VERSION 4
+#define EAMM_ABI_VERSION 5
 
 typedef enum eamm_status {
     EAMM_OK = 0,
@@ -223,6 +223,14 @@ int eamm_kp_load_tensor(eamm_kp_ctx* ctx, const char* key, const float* host_dat
 int eamm_kp_finalize_weights(eamm_kp_ctx* ctx);
 int eamm_kp_detect(eamm_kp_ctx* ctx, const float* image /*[B,3,H,W]*/, int B, const eamm_kp_outputs* out, void* stream);
 int eamm_kp_detect_features(eamm_kp_ctx* ctx, const float* feature_map, int B, const eamm_kp_outputs* out, void* stream);
+/* Round 6 -- the private hand-over between the deconvolution tail and KPDetector_a (reference: util.py:604-607 produces
+ * deco_out[:, t], keypoint_detector.py:180-205 consumes it; both sides live in this library, so the [B,35,64,64] NCHW tensor the
+ * reference materialises between them is optional).  eamm_kp_split_channels: the `wide` channel count 32 m this handle's heads
+ * read (feature map = 32 m + 3 channels, heads in the wide + thin form), or 0.  eamm_kp_detect_features_split: `wide` NHWC
+ * [B,h,w,32 m] float32 + `thin` [B,h,w,4] (the last three channels and a zero), both caller-owned device memory, as written by
+ * eamm_deconv_forward_split; same outputs as eamm_kp_detect_features on the equivalent NCHW map, bit for bit. */
+int eamm_kp_split_channels(const eamm_kp_ctx* ctx);
+int eamm_kp_detect_features_split(eamm_kp_ctx* ctx, const float* wide, const float* thin, int B, const eamm_kp_outputs* out, void* stream);
 
 /*
  * ---- N3: audio-to-feature deconvolution tail ------------------------------------------------------------
@@ -249,6 +257,11 @@ int eamm_deconv_load_tensor(eamm_deconv_ctx* ctx, const char* key, const float* 
 int eamm_deconv_finalize_weights(eamm_deconv_ctx* ctx);
 /* x: [B, channels[0]] (= the reference's [B,C,1,1]) device fp32; out: [B, channels[L], S, S] NCHW, S = 4 << (L-1). */
 int eamm_deconv_forward(eamm_deconv_ctx* ctx, const float* x, int B, float* out, void* stream);
+/* Round 6: the same layers with the last one writing the split NHWC form KPDetector_a's heads read (above) instead of NCHW:
+ * wide [B,S,S,C_last - 3], thin [B,S,S,4].  eamm_deconv_split_channels: C_last - 3 when that is a positive multiple of 32, else 0
+ * (eamm_deconv_forward_split then fails with EAMM_ERR_ARG). */
+int eamm_deconv_split_channels(const eamm_deconv_ctx* ctx);
+int eamm_deconv_forward_split(eamm_deconv_ctx* ctx, const float* x, int B, float* wide, float* thin, void* stream);
 
 /*
  * ---- N4: training-mode BatchNorm, forward (round 2) and backward (round 3) --------------------------------------

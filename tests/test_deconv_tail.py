@@ -114,3 +114,42 @@ def test_driving_keypoints_chain_matches_oracle():
     assert tuple(kp["value"].shape) == (11, 10, 2) and tuple(kp["jacobian"].shape) == (11, 10, 2, 2)
     assert float((kp["value"].cpu() - ref["value"]).abs().max()) <= 5e-5
     assert float((kp["jacobian"].cpu() - ref["jacobian"]).abs().max()) <= 2e-4
+
+
+@pytest.mark.gpu
+def test_split_hand_over_to_kp_detector_a_is_the_nchw_path_bit_for_bit():
+    """Round 6: DeconvTail.forward_split writes the 35 channels in the layout KPDetector_a's heads read -- NHWC wide
+    [B,64,64,32] + one float4 per pixel -- instead of the reference's NCHW [B,35,64,64] (util.py:604-607 -> keypoint_detector.py:180-205).
+    The values are forward()'s, the key points are those of the NCHW path, bit for bit, at one frame and at a clip-harness batch."""
+    from eamm_amd import KPDetector_a, SplitFeatureMap, driving_keypoints, kp_detector_a_config
+    from eamm_amd.weights import synthetic_lstm_features, trained_like_kp_state_dict
+    tail = DeconvTail()
+    tail.load_state_dict(synthetic_state_dict(None, seed=3, spec=deconv_state_dict_spec()), strict=True)
+    ca = kp_detector_a_config()
+    kpa = KPDetector_a(**ca)
+    kpa.load_state_dict(trained_like_kp_state_dict(ca, 77), strict=True)
+    tail, kpa = tail.cuda().eval(), kpa.cuda().eval()
+    assert tail.split_channels() == 32 and kpa.accepts_split(64, 64) == 32
+    feats = synthetic_lstm_features(70, seed=5).cuda()
+    with torch.no_grad():
+        for b in (1, 3, 70):
+            x = feats[:b].contiguous()
+            nchw = tail(x)
+            sp = tail.forward_split(x)
+            assert isinstance(sp, SplitFeatureMap) and sp.shape == (b, 35, 64, 64)
+            assert torch.equal(sp.to_nchw(), nchw)                      # same values, other layout
+            assert float(sp.thin[..., 3].abs().max()) == 0.0             # the float4's fourth slot
+            a, s = kpa(nchw), kpa(sp)
+            for k in ("value", "jacobian", "heatmap"):
+                assert torch.equal(a[k], s[k]), (b, k)
+
+        class Plain:                                                     # hides forward_split: the reference's hand-over
+            def __call__(self, t):
+                return tail(t)
+        ref, got = driving_keypoints(Plain(), kpa, feats, batch=16), driving_keypoints(tail, kpa, feats, batch=16)
+        assert all(torch.equal(ref[k], got[k]) for k in ref)
+    # a tail whose output is not 32 m + 3 channels wide has no split form
+    other = DeconvTail(channels=(64, 64, 32)).cuda().eval()
+    assert other.split_channels() == 0
+    with pytest.raises(RuntimeError, match="32 m \\+ 3"):
+        other.forward_split(torch.zeros(1, 64, device="cuda"))

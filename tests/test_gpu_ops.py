@@ -151,6 +151,11 @@ CASES = {
     "wino4_pool_enc3":   dict(B=3, H=8, W=8, C0=512, C1=0, Cout=1024, ks=3, act=1, pool=1, tile_n=2156),
     # one frame of the bottleneck: 32-tile four-wave blocks, six transform-point rows per tile, residual in the output transform
     "wino4_one_frame_narrow": dict(B=1, H=64, W=64, C0=256, C1=0, Cout=256, ks=3, resid=True, tile_n=2156),
+    # round 6: the HALF-row split (12 workgroups per 64 x 64 block, 48 planes of partial x folds summed by the output transform) --
+    # the one-frame plan of the bottleneck (192 eight-wave workgroups), with and without residual, ragged M / Cout tails
+    "wino4_half_rows_one_frame": dict(B=1, H=64, W=64, C0=256, C1=0, Cout=256, ks=3, resid=True, tile_n=2162),
+    "wino4_half_rows_relu":      dict(B=1, H=64, W=64, C0=256, C1=0, Cout=256, ks=3, act=1, tile_n=2162),
+    "wino4_half_rows_ragged":    dict(B=3, H=12, W=20, C0=128, C1=0, Cout=72, ks=3, resid=True, tile_n=2162),
     "wino4_pool_ragged": dict(B=1, H=12, W=20, C0=64, C1=0, Cout=72, ks=3, act=1, pool=1, tile_n=2156),
     "wino4_interleaved": dict(B=3, H=16, W=20, C0=128, C1=0, Cout=96, ks=3, resid=True, tile_n=2105),
     "7x1_rowsplit":      dict(B=2, H=16, W=16, C0=64, C1=0, Cout=21, ks=7, kw=1),

@@ -126,3 +126,33 @@ def test_kp_detector_feeds_generator_contract():
         ref = orc.generator_forward(sd_g, gcfg, src.cpu(), {k: v.cpu() for k, v in kp_driving.items() if k != "heatmap"},
                                     {k: v.cpu() for k, v in kp_source.items() if k != "heatmap"})
     assert float((out["prediction"].cpu() - ref["prediction"]).abs().max()) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("audio,k", [(True, 10), (False, 10), (True, 15)])
+def test_batched_heads_on_the_lds_dma_tile_match_the_oracle_and_the_small_call(audio, k):
+    """Round 6: from B*h*w >= 16384 pixels (4 frames at 256x256) the heads' 7x7 convolution runs on the LDS-DMA tile (512 x 64 columns;
+    256 x 128 when K + 4 K > 64) instead of the register-staged 128 x 64 one -- the clip harness's 64-frame front-end batches.  Eight
+    frames (DMA tile) against the oracle, and their first two against a two-frame call (register-staged tile) of the same module."""
+    cfg = {**(kp_detector_a_config() if audio else kp_detector_config()), "num_kp": k}
+    sd = synthetic_state_dict(cfg, seed=77, spec=kp_state_dict_spec(cfg))
+    mod = (KPDetector_a if audio else KPDetector)(**cfg)
+    mod.load_state_dict(sd, strict=True)
+    mod = mod.to("cuda:0").eval()
+    if audio:
+        rs = np.random.RandomState(11)
+        x = torch.from_numpy(rs.standard_normal((8, cfg["block_expansion"] + cfg["num_channels_a"], 64, 64)).astype(np.float32))
+    else:
+        x = synthetic_source(256, seed=4, batch=8)
+    with torch.no_grad():
+        big = {n: v.cpu() for n, v in mod(x.to("cuda:0")).items()}
+        small = {n: v.cpu() for n, v in mod(x[:2].to("cuda:0")).items()}
+        ref = (orc.kp_detector_a_forward if audio else orc.kp_detector_forward)(sd, cfg, x)
+        lean = mod.detect(x.to("cuda:0"), heatmap=False)       # what the clip harness asks for: no heat-map pass
+    assert set(lean) == {"value", "jacobian"} and all(torch.equal(lean[n].cpu(), big[n]) for n in lean)
+    assert float((big["heatmap"].sum(dim=(2, 3)) - 1).abs().max()) <= 1e-5     # the sliced form's heat-maps are normalised by the combined sum
+    errs = {n: float((big[n] - ref[n]).abs().max()) for n in big}
+    print(f"\nbatched heads audio={audio} K={k}: " + "  ".join(f"{n}={e:.2e}" for n, e in errs.items()))
+    for n, e in errs.items():
+        assert e <= TOL_KP[n], (n, e)
+        assert float((big[n][:2] - small[n]).abs().max()) <= TOL_KP[n] / 2, n

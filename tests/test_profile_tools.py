@@ -89,3 +89,38 @@ def test_pmc_counter_split_by_launch_size(tmp_path):
     body = [l.split() for l in out[2:]]
     assert len(body) == 2 and "input_transform" not in "".join(out)
     assert body[0][-4:] == ["128", "3", "82001.0", "164.00"] and body[1][-4:] == ["512", "5", "254000.0", "336.00"]
+
+
+def test_train_step_timeline_by_stage(tmp_path):
+    """tools/rocpd_summary.py --train-timeline (round 6): a kernel trace of tools/train_step_bench.py reduced to kernel
+    time per stage in the forward and backward halves of a step + idle time; steps cut at the L1 loss's abs / sign kernels."""
+    db = tmp_path / "train.db"
+    con = sqlite3.connect(db)
+    con.execute("create table kernels (name text, start integer, end integer, duration integer)")
+    rows, t = [], [0]
+
+    def add(name, dur, gap=0):
+        t[0] += gap
+        rows.append((name, t[0], t[0] + dur, dur))
+        t[0] += dur
+    for step in range(4):
+        add("void eamm::kp_prepare_kernel(float const*)", 5_000, 100_000)
+        add(GEMM, 100_000)
+        add("void eamm::bn_nhwc_partial_kernel(float const*)", 20_000, 1_000)
+        add("void at::native::vectorized_elementwise_kernel<4, at::native::AbsFunctor<float>, std::array<char*, 2ul> >(int)", 5_000)
+        add("void at::native::reduce_kernel<512, 1, at::native::ReduceOp<float, at::native::MeanOps<float> > >(int)", 5_000)
+        add("void at::native::vectorized_elementwise_kernel<4, at::native::sign_kernel_cuda(at::TensorIteratorBase&)>(int)", 5_000)
+        add("void eamm::conv_wgrad_kernel<32>(eamm::WgradArgs)", 200_000)
+        add("void eamm::bn_nhwc_bwd_apply_kernel<false>(float const*)", 30_000, 2_000)
+    con.executemany("insert into kernels values (?,?,?,?)", rows)
+    con.commit()
+    con.close()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), "--train-timeline", str(db)], capture_output=True,
+                         text=True, check=True).stdout
+    assert "2 steps" in out
+    line = {l.split("  ")[0]: l.split() for l in out.splitlines()[2:]}
+    assert line["weight / bias gradients"][-6:] == ["0.000", "0.0", "0.200", "1.0", "0.200", "54.3%"]
+    assert line["convolutions: forward and data gradients"][-6:-1] == ["0.100", "1.0", "0.000", "0.0", "0.100"]
+    assert line["BatchNorm backward"][-4:-1] == ["0.030", "1.0", "0.030"] and line["BatchNorm statistics / apply"][-6:-4] == ["0.020", "1.0"]
+    idle = [l for l in out.splitlines() if l.startswith("idle")][0].split()
+    assert idle[-4:-1] == ["0.001", "0.002", "0.003"]

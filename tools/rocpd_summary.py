@@ -184,7 +184,80 @@ def per_launch_frac(bench_json, db):
               f"{g_us / (ref['per_launch']['avg_launch_ms'] * 1e3):.3f}")
 
 
+TRAIN_STAGES = (   # (stage, regex on the demangled kernel name) -- first match wins
+    ("BatchNorm statistics / apply", r"bn_(nhwc_)?(partial|combine|finalize|apply|local_stats)|bn_nhwc_apply|bn_finalize|bn_combine|bn_nhwc_partial"),
+    ("BatchNorm backward", r"bn_(nhwc_)?bwd|bn_bwd"),
+    ("weight / bias gradients", r"wgrad|bias_grad|wino4_dy_transform"),
+    ("filter packing (weights change every step)", r"pack_dev|conv7_thin_pack|col7_pack"),
+    ("convolutions: forward and data gradients", r"wino4_gemm|wino4_input_transform|wino4_output_transform|wino_gemm|wino_input|conv_mfma|conv_col7|"
+                                                 r"conv7_thin_in|conv_patch|patch_poly|splitk_reduce|conv_first7|final_shift_sum"),
+    ("motion / warp operators (forward + backward)", r"motion_|warp_|kp_prepare|kp_records|antialias|rec_partial|source_to_nhwc|to_u8"),
+    ("ATen glue (elementwise / reductions / copies / fills)", r"at::native|rocclr|Cijk_|elementwise|reduce_kernel"),
+)
+
+
+def train_timeline(db, steps_hint=None):
+    """A rocprofv3 kernel trace of tools/train_step_bench.py reduced to a per-stage table: kernel time per stage
+    in the FORWARD and in the BACKWARD half of a step, launches, and the time the device sits idle between kernels.  Steps are cut at the
+    L1 loss: its `abs` kernel ends a forward half, the `sign` kernel of its derivative starts the backward half (one each per step)."""
+    con = sqlite3.connect(db)
+    cols = [r[1] for r in con.execute("pragma table_info('kernels')")] or [d[0] for d in con.execute("select * from kernels limit 1").description]
+    t0c, t1c = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
+    rows = con.execute(f"select name, {t0c}, {t1c} from kernels order by {t0c}").fetchall()
+    cuts_f = [i for i, r in enumerate(rows) if "AbsFunctor" in r[0]]
+    cuts_b = [i for i, r in enumerate(rows) if "sign_kernel" in r[0]]
+    if not cuts_f or len(cuts_f) != len(cuts_b):
+        raise SystemExit(f"cannot find the L1 loss's abs / sign kernels in the trace ({len(cuts_f)} / {len(cuts_b)})")
+    # step k: forward = (end of step k-1's backward .. abs kernel], backward = [sign kernel .. last kernel before the next forward)
+    # the next forward starts at the first kernel after a gap in which the host zeroes the gradients: use the first kernel after the
+    # backward's last weight-gradient kernel -- simpler and robust: step k spans rows (bwd_end[k-1], bwd_end[k]] with bwd_end = the last
+    # row before the next step's first `kp_prepare` / `motion_front` kernel (the forward's first library kernel)
+    firsts = [i for i, r in enumerate(rows) if "kp_prepare" in r[0]]      # the forward's first library kernel
+    if len(firsts) < len(cuts_f):
+        raise SystemExit("fewer kp_prepare launches than steps in the trace")
+    steps = []
+    for k, (cf, cb) in enumerate(zip(cuts_f, cuts_b)):
+        st = max(i for i in firsts if i < cf)
+        nxt = [i for i in firsts if i > cb]
+        en = (nxt[0] - 1) if nxt else len(rows) - 1
+        steps.append((st, cf, cb, en))
+    # the first step pays allocator warm-up (tools/train_step_bench.py drops it too); the last one is followed by the tool's own
+    # gradient-norm reductions (ATen), which would count as its backward
+    if len(steps) > 2:
+        steps = steps[1:-1]
+    table = {}
+    wall_f = wall_b = idle_f = idle_b = 0.0
+    for st, cf, cb, en in steps:
+        for lo, hi, half in ((st, cf, "fwd"), (cb, en, "bwd")):
+            ivs = [(rows[i][1], rows[i][2]) for i in range(lo, hi + 1)]
+            wall = (max(b for _, b in ivs) - min(a for a, _ in ivs)) / 1e6
+            busy = union_ms(ivs)
+            if half == "fwd":
+                wall_f += wall; idle_f += wall - busy
+            else:
+                wall_b += wall; idle_b += wall - busy
+            for i in range(lo, hi + 1):
+                name = rows[i][0]
+                stage = next((s for s, rx in TRAIN_STAGES if re.search(rx, name)), "other")
+                e = table.setdefault(stage, {"fwd": [0.0, 0], "bwd": [0.0, 0]})
+                e[half][0] += (rows[i][2] - rows[i][1]) / 1e6
+                e[half][1] += 1
+    n = len(steps)
+    print(f"== training-step timeline from {db}: {n} steps (first and last of the trace dropped), per step")
+    print(f"{'stage':58s} {'fwd ms':>8s} {'launches':>9s} {'bwd ms':>8s} {'launches':>9s} {'step ms':>8s} {'share':>6s}")
+    tot = sum(v['fwd'][0] + v['bwd'][0] for v in table.values()) + idle_f + idle_b
+    for stage, v in sorted(table.items(), key=lambda kv: -(kv[1]['fwd'][0] + kv[1]['bwd'][0])):
+        f, b = v["fwd"], v["bwd"]
+        print(f"{stage:58s} {f[0] / n:8.3f} {f[1] / n:9.1f} {b[0] / n:8.3f} {b[1] / n:9.1f} {(f[0] + b[0]) / n:8.3f} {100 * (f[0] + b[0]) / tot:5.1f}%")
+    print(f"{'idle (no kernel running between first and last kernel)':58s} {idle_f / n:8.3f} {'':9s} {idle_b / n:8.3f} {'':9s} {(idle_f + idle_b) / n:8.3f} {100 * (idle_f + idle_b) / tot:5.1f}%")
+    print(f"{'wall clock of the half (first kernel start .. last end)':58s} {wall_f / n:8.3f} {'':9s} {wall_b / n:8.3f} {'':9s} {(wall_f + wall_b) / n:8.3f}")
+    return table
+
+
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--train-timeline":
+        train_timeline(sys.argv[2])
+        return
     if len(sys.argv) >= 4 and sys.argv[1] == "--bneck-timeline":
         timeline_report(sys.argv[2], sys.argv[3])
         return
