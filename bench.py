@@ -264,6 +264,9 @@ def main():
     ap.add_argument("--e2e-frames", type=int, default=2048,
                     help="frames of the end-to-end leg (make_animation_smooth: LSTM features -> uint8 frames in host memory; 0 = skip)")
     ap.add_argument("--train-pairs", type=int, default=8, help="pairs per step of the training-step leg (N = 1 only; 0 = skip)")
+    ap.add_argument("--latency-frames", type=int, default=64,
+                    help="frames per pass of the one-frame-per-call leg `latency_b1` (BASELINE configs[1]; N = 1, 256x256 only; 0 = skip)")
+    ap.add_argument("--no-all-outputs", action="store_true", help="skip the five-key `all_outputs` leg (profiling runs: the contract line's kernels only)")
     ap.add_argument("--graph", action="store_true",
                     help="after the contract's timed region: capture one step into a HIP graph and time `--steps` replays (extra key "
                          "`graph`).  Used by tools/gpu_profile.sh: under rocprofv3 the host's per-launch cost delays the second "
@@ -455,16 +458,18 @@ def main():
     def step_all():
         return eng.forward_frames(kp_d, kp_s, outputs=ALL_KEYS)
 
-    for _ in range(max(2, args.warmup)):
-        full = step_all()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full = step_all()
-    fence()
-    dt_all = max_over_ranks(time.perf_counter() - t0)
     all_outputs = None
-    if rank == 0:
+    full = None
+    if not args.no_all_outputs:
+        for _ in range(max(2, args.warmup)):
+            full = step_all()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            full = step_all()
+        fence()
+        dt_all = max_over_ranks(time.perf_counter() - t0)
+    if rank == 0 and full is not None:
         all_ok = all(k in full and bool(torch.isfinite(full[k]).all()) for k in ALL_KEYS)
         all_par = fixture_parity(full["prediction"], S)
         if not all_ok or (all_par["ok"] is False):
@@ -480,24 +485,25 @@ def main():
     # ---- ONE frame per call (BASELINE configs[1], the reference's own calling pattern demo.py:279): latency of the engine at
     # batch 1, source cached, key points resident, prediction left on the device; its own handle (max_frames = 1)
     latency_b1 = None
-    if world == 1 and S == 256:
+    if world == 1 and S == 256 and args.latency_frames > 0:
+        LF = args.latency_frames
         gen1 = OcclusionAwareGenerator(**cfg, max_frames=1)
         gen1.load_state_dict(sd, strict=True)
         gen1 = gen1.to(dev).eval()
         eng1 = gen1.encode_source(synthetic_source(S, seed=1).to(dev), max_frames=1)
-        kps1 = [{k: v.to(dev) for k, v in synthetic_keypoints(1, cfg["num_kp"], seed=2 + t).items()} for t in range(64)]
-        for t in range(16):
+        kps1 = [{k: v.to(dev) for k, v in synthetic_keypoints(1, cfg["num_kp"], seed=2 + t).items()} for t in range(LF)]
+        for t in range(min(16, LF)):
             eng1.forward_frames(kps1[t], kp_s, outputs=("prediction",))
         passes1 = []
         f0 = _eamm_lib.lib().eamm_total_mfma_flops()
         for _ in range(5):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for t in range(64):
+            for t in range(LF):
                 o1 = eng1.forward_frames(kps1[t], kp_s, outputs=("prediction",))
             torch.cuda.synchronize()
-            passes1.append((time.perf_counter() - t0) / 64 * 1e3)
-        gf1 = (_eamm_lib.lib().eamm_total_mfma_flops() - f0) * 1e-9 / (5 * 64)
+            passes1.append((time.perf_counter() - t0) / LF * 1e3)
+        gf1 = (_eamm_lib.lib().eamm_total_mfma_flops() - f0) * 1e-9 / (5 * LF)
         eng1.check_numeric()
         # parity THROUGH the one-frame plan: the fixture's two frames, one call each
         kp2 = synthetic_keypoints(2, cfg["num_kp"], seed=2)
@@ -510,7 +516,7 @@ def main():
                       "executed_gflop_per_frame": round(gf1, 3), "achieved_tflops": round(gf1 / ms1, 2),
                       "frac_chip_executed": round(gf1 / ms1 / FP32_MFMA_PEAK_TFLOPS, 4),
                       "parity_max_abs_err_vs_fixture": par1.get("max_abs_err"), "plan": eng1.describe_plan(1),
-                      "sample": "median of 5 passes x 64 calls of one frame each, back to back on one stream, no D2H (tools/module_latency.py "
+                      "sample": f"median of 5 passes x {LF} calls of one frame each, back to back on one stream, no D2H (tools/module_latency.py "
                                 "times the module wrapper incl. D2H)",
                       "workload": "256x256, 10 keypoints, batch=1 (BASELINE.json configs[1]; the reference's loop demo.py:251-281)"}
         del gen1, eng1, o1

@@ -89,6 +89,31 @@ def test_animate_clip_relative_adapt_matches_oracle():
     assert float((plain - frames).abs().max()) > 1e-3          # the normalisation really changed the key points
 
 
+@pytest.mark.parametrize("k", [5, 15, 30])
+def test_clip_interface_with_other_key_point_counts(k):
+    """Round 6: num_kp != 10 through the clip interface -- encode once, batches of ragged size (two whole-pass chains from 10 frames),
+    relative + adapt_movement_scale normalisation (normalize_kp is K-agnostic: the convex hull of K points), uint8 packing -- against the
+    oracle generator fed the oracle's own normalize_kp."""
+    cfg = {**tiny_config(), "num_kp": k}
+    sd = synthetic_state_dict(cfg, seed=1234)
+    gen = make_generator(cfg)
+    src = synthetic_source(64, seed=1)
+    kp_s, kp_d = synthetic_keypoints(1, k, seed=0), synthetic_keypoints(23, k, seed=2)
+    frames, span = animate_clip(EngineBackend(gen, batch=12), src, kp_s, kp_d, 64, 64)
+    assert span == (0, 23)
+    ref = np.stack(orc.animate_clip(sd, cfg, src, kp_s, kp_d))
+    assert np.abs(frames.cpu().numpy().transpose(0, 2, 3, 1) - ref).max() <= TOL["prediction"]
+    if k >= 3:   # adapt_movement_scale takes the convex hull's area: needs three points
+        kp_i = {kk: v[:1] for kk, v in kp_d.items()}
+        rel, _ = animate_clip(EngineBackend(gen, batch=12), src, kp_s, kp_d, 64, 64, kp_driving_initial=kp_i, relative=True,
+                              adapt_movement_scale=True)
+        per_frame = [orc.normalize_kp(kp_s, {kk: v[t:t + 1] for kk, v in kp_d.items()}, kp_i, adapt_movement_scale=True,
+                                      use_relative_movement=True, use_relative_jacobian=True) for t in range(23)]      # demo.py:276, frame by frame
+        norm = {kk: torch.cat([f[kk] for f in per_frame]) for kk in ("value", "jacobian")}
+        ref_rel = np.stack(orc.animate_clip(sd, cfg, src, kp_s, norm))
+        assert np.abs(rel.cpu().numpy().transpose(0, 2, 3, 1) - ref_rel).max() <= TOL["prediction"]
+
+
 def test_animate_clip_emotion_offsets_match_reference_loop():
     """`--add_emo` path of loop 2 (demo.py:263-276): emotion offsets, then normalize_kp, then the generator; expected
     frames = oracle on the key points the reference's own statements produced (fixture emotion_offsets.npz)."""

@@ -40,6 +40,14 @@ def test_bottleneck_timeline_union(tmp_path):
                 rows.append((TR, t, t + T, T, lane, lane))
                 rows.append((GEMM, t + T, t + T + G, G, lane, lane))
                 t += T + G
+    # one-frame launches of the narrow variants (bench.py's latency_b1 leg): more numerous than the contract line's, far less time
+    NARROW = "void eamm::wino4_gemm_kernel<2, 2, 2, 4, 2, 4, 0>(eamm::Wino4Args)"
+    TR1 = TR.replace("<4>", "<1>")
+    t = (calls + 10) * 5_000_000
+    for _ in range(400):
+        rows.append((TR1, t, t + 8_000, 8_000, 1, 1))
+        rows.append((NARROW, t + 8_000, t + 29_000, 21_000, 1, 1))
+        t += 40_000
     con.executemany("insert into kernels values (?,?,?,?,?,?,124,0,131072)", rows)
     con.commit()
     con.close()

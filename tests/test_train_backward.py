@@ -444,7 +444,7 @@ def test_two_replicas_gradients_add_up_to_the_whole_batch(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["no_jacobian", "no_motion_network", "odd_widths", "gray"])
+@pytest.mark.parametrize("variant", ["no_jacobian", "no_motion_network", "odd_widths", "gray", "kp5", "kp15"])
 def test_generator_backward_variants_against_oracle_autograd(variant):
     """Branches of the differentiable forward: key points without jacobians (dense_motion.py:55) and a generator built
     without a motion network (generator.py:22-23)."""
@@ -456,11 +456,13 @@ def test_generator_backward_variants_against_oracle_autograd(variant):
                    dense_motion_params=dict(cfg["dense_motion_params"], block_expansion=40, max_features=100))
     if variant == "gray":           # one image channel: the generic thin-layer / motion-stage routes of the operator composition
         cfg = dict(cfg, num_channels=1)
+    if variant.startswith("kp"):    # round 6: num_kp != 10 through the differentiable motion operators (24 / 64 hourglass input channels)
+        cfg = dict(cfg, num_kp=int(variant[2:]))
     n = 3
     sd = synthetic_state_dict(cfg, seed=77)
     src = synthetic_source(64, seed=3, batch=n, channels=cfg["num_channels"])
-    kp_s = synthetic_keypoints(n, 10, seed=4, jacobian=variant != "no_jacobian")
-    kp_d = synthetic_keypoints(n, 10, seed=5, jacobian=variant != "no_jacobian")
+    kp_s = synthetic_keypoints(n, cfg["num_kp"], seed=4, jacobian=variant != "no_jacobian")
+    kp_d = synthetic_keypoints(n, cfg["num_kp"], seed=5, jacobian=variant != "no_jacobian")
     gen = _make(cfg, 77).train()
     ks = {k: v.to(DEV).requires_grad_() for k, v in kp_s.items()}
     kd = {k: v.to(DEV).requires_grad_() for k, v in kp_d.items()}

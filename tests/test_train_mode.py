@@ -183,7 +183,7 @@ def test_gpu_two_ranks_unequal_shards_match_the_reference_replicas(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["no_jacobian", "no_motion_network", "one_pair_more_than_max_frames"])
+@pytest.mark.parametrize("variant", ["no_jacobian", "no_motion_network", "one_pair_more_than_max_frames", "kp5", "kp30"])
 def test_gpu_train_forward_variants_against_oracle(variant):
     """Branches of the forward in training mode against the oracle's training branch: key points without jacobians
     (dense_motion.py:55), a generator built without a motion network (generator.py:22-23), and a batch larger than the
@@ -194,10 +194,12 @@ def test_gpu_train_forward_variants_against_oracle(variant):
         cfg = dict(cfg, dense_motion_params=None, estimate_occlusion_map=False)
     if variant == "one_pair_more_than_max_frames":
         n = 5
+    if variant.startswith("kp"):    # round 6: num_kp != 10 in training mode (the resumable batch-statistics pass)
+        cfg = dict(cfg, num_kp=int(variant[2:]))
     sd = synthetic_state_dict(cfg, seed=77)
     src = synthetic_source(64, seed=3, batch=n)
-    kp_s = synthetic_keypoints(n, 10, seed=4, jacobian=variant != "no_jacobian")
-    kp_d = synthetic_keypoints(n, 10, seed=5, jacobian=variant != "no_jacobian")
+    kp_s = synthetic_keypoints(n, cfg["num_kp"], seed=4, jacobian=variant != "no_jacobian")
+    kp_d = synthetic_keypoints(n, cfg["num_kp"], seed=5, jacobian=variant != "no_jacobian")
     from eamm_amd import OcclusionAwareGenerator
     gen = OcclusionAwareGenerator(**cfg, max_frames=4)
     gen.load_state_dict(sd, strict=True)

@@ -10,7 +10,7 @@ SIZE=${1:-256}; BATCH=${2:-16}; TAG=${3:-${SIZE}_b${BATCH}}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd $R
-BENCH="python bench.py --size $SIZE --batch $BATCH --steps 10 --warmup 3 --cpu-frames 0 --clip-frames 0 --train-pairs 0 --e2e-frames 0"   # the contract line's kernels only
+BENCH="python bench.py --size $SIZE --batch $BATCH --steps 10 --warmup 3 --cpu-frames 0 --clip-frames 0 --train-pairs 0 --e2e-frames 0 --latency-frames 0 --no-all-outputs"   # the contract line's kernels only
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $BENCH --graph > $O/kt_bench.log 2>&1
 python tools/rocpd_summary.py $O/kt/kt_results.db > $O/kernel_trace_stats.txt 2>&1
 grep '^{' $O/kt_bench.log > $O/bench_under_kernel_trace.json

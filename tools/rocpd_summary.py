@@ -41,7 +41,7 @@ def union_ms(intervals):
 
 def bottleneck_timeline(con, nres=12, nchains=2):
     """-> list over forward calls of {"chains": [(start, end), ...], "gemm": [(start, end), ...]} (ns), in time order.
-    The bottleneck GEMM is the wino4_gemm_kernel instantiation with the most dispatches; a forward call is `nchains` x `nres`
+    The bottleneck GEMM is the wino4_gemm_kernel instantiation with the most kernel time; a forward call is `nchains` x `nres`
     (= 2 * num_bottleneck_blocks) consecutive dispatches of it in time order (calls never overlap: every call joins its chains
     before it returns); inside a call the chains are told apart by the stream / queue column (eager launches and graph replays
     run on different streams, so the lanes are looked up per call)."""
@@ -52,10 +52,10 @@ def bottleneck_timeline(con, nres=12, nchains=2):
     lane_cols = [c for c in ("stream_id", "queue_id", "queue") if c in cols]
     sel = ", ".join(["name", t0c, t1c] + lane_cols)
     rows = con.execute(f"select {sel} from kernels order by {t0c}").fetchall()
-    gemm_names = {}
+    gemm_names = {}   # by total TIME: one-frame launches of the narrow variants (bench.py's latency_b1 leg) are more numerous, far shorter
     for r in rows:
         if "wino4_gemm_kernel" in r[0]:
-            gemm_names[r[0]] = gemm_names.get(r[0], 0) + 1
+            gemm_names[r[0]] = gemm_names.get(r[0], 0) + (r[2] - r[1])
     if not gemm_names:
         raise SystemExit("no wino4_gemm_kernel dispatch in the trace (the bottleneck did not run in F(4x4) form)")
     bneck = max(gemm_names, key=gemm_names.get)
@@ -161,8 +161,10 @@ def per_launch_frac(bench_json, db):
     trans = [r for r in rows if "wino4_input_transform_kernel" in r[0]]
     if not gemms or not trans:
         raise SystemExit("no wino4 GEMM / input-transform dispatches in the trace")
-    g = max(gemms, key=lambda r: r[1])
-    t = max(trans, key=lambda r: r[1])
+    # the contract line's kernels = the instantiations with the most TIME (a trace may also hold one-frame launches of the narrow
+    # variants -- bench.py's latency_b1 leg -- which are more numerous but short)
+    g = max(gemms, key=lambda r: r[1] * r[2])
+    t = max(trans, key=lambda r: r[1] * r[2])
     steps_traced = g[1] / (chains * 12.0)
     gflop_launch = roof["per_launch"]["executed_gflop"]
     g_us, t_us = g[2] / 1e3, t[2] / 1e3
