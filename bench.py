@@ -263,6 +263,7 @@ def main():
     ap.add_argument("--clip-gather", action="store_true", help="clip leg: gather uint8 frames on rank 0 inside the timed region")
     ap.add_argument("--e2e-frames", type=int, default=2048,
                     help="frames of the end-to-end leg (make_animation_smooth: LSTM features -> uint8 frames in host memory; 0 = skip)")
+    ap.add_argument("--e2e-front-batch", type=int, default=None, help="frames per front-end call of the end-to-end leg (default: the harness's own default)")
     ap.add_argument("--train-pairs", type=int, default=8, help="pairs per step of the training-step leg (N = 1 only; 0 = skip)")
     ap.add_argument("--latency-frames", type=int, default=64,
                     help="frames per pass of the one-frame-per-call leg `latency_b1` (BASELINE configs[1]; N = 1, 256x256 only; 0 = skip)")
@@ -632,8 +633,9 @@ def main():
         e_feat = synthetic_lstm_features(T2, seed=5).to(dev) if rank == 0 else None
 
         def run_e2e(timings=None, keys=False):
+            extra = {} if args.e2e_front_batch is None else {"front_batch": args.e2e_front_batch}
             return animate_from_features(gen_e, m_kp, m_tail, m_kpa, e_src, e_feat, batch=CB2, uint8=True, to_host=True, backend=be2,
-                                         timings=timings, return_keypoints=keys, size=(S, S))
+                                         timings=timings, return_keypoints=keys, size=(S, S), **extra)
 
         run_e2e()                          # warm-up: engines, pinned buffer, allocator
         fence()

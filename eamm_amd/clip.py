@@ -73,6 +73,8 @@ class EngineBackend:
         for d in tail:
             need *= int(d)
         key = (dtype, tuple(tail))
+        if getattr(torch._C, "_storage_Use_Count", None) is None:      # no reference counter in this torch build: a fresh buffer per clip
+            return torch.empty(max(need, 1), dtype=dtype, pin_memory=True)[:need].view((frames,) + tuple(tail))
         pool = self._host.setdefault(key, [])
         buf = None
         for cand, idle_count in pool:

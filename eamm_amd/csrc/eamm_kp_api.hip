@@ -18,8 +18,8 @@ struct eamm_kp_ctx : eamm::CtxBase {
     std::vector<int> enc_c, dec_c;
     std::vector<LayerSet> hg_enc, hg_dec;
     ConvLayer head;               // kp (K) + jacobian (4*njm) stacked along Cout
-    ConvLayer head_dma;           // the same filters packed for the LDS-DMA tile (512 x 64 / 256 x 128), batched calls (round 6: the wide 7x7
-    bool has_head_dma = false;    // head is 73 % of KPDetector_a's per-frame time; 0.38 -> of the fp32 matrix peak on the register-staged tile)
+    ConvLayer head_dma;           // the same filters packed for the LDS-DMA tile (512 x 64 / 256 x 128), batched calls (round 6: the wide 7x7 head was
+    bool has_head_dma = false;    // 73 % of KPDetector_a's time per frame at 0.38 of the fp32 matrix peak on the register-staged tile; 0.75 here)
     int head_dma_min_m = 16384;   // smallest B*h*w for which it is used (EAMM_KP_HEAD_DMA_MIN_M; < 0: never)
     int head_cs = 64;             // pixel stride of the logits = K + 4*njm rounded up to 64 (round 6: 128 / 192 for num_kp 13 .. 30)
     // KPDetector_a whose feature map is 32 m + 3 channels wide (the shipped 35 = block_expansion 32 + num_channels_a 3): the heads

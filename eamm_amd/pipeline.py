@@ -45,7 +45,7 @@ def _kp_only(d: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 def animate_from_features(generator, kp_detector, deconv_tail, kp_detector_a, source_image: Optional[torch.Tensor],
                           lstm_features: Optional[torch.Tensor], emo_driving: Optional[Dict[str, torch.Tensor]] = None,
                           relative: bool = True, adapt_movement_scale: bool = True, smooth: bool = True, batch: int = 64,
-                          front_batch: int = 128, uint8: bool = True, to_host: bool = True, group=None,
+                          front_batch: int = 256, uint8: bool = True, to_host: bool = True, group=None,
                           backend: Optional[EngineBackend] = None, timings: Optional[Dict[str, float]] = None,
                           return_keypoints: bool = False, size: Optional[Tuple[int, int]] = None, stream: Optional[bool] = None):
     """make_animation_smooth (demo.py:194-282) for one clip.

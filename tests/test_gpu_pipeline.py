@@ -161,3 +161,40 @@ def test_one_euro_on_the_device_matches_the_reference_filter_and_is_fast():
     print(f"one-euro, 2048 frames, values + jacobians on the device: {best:.3f} ms (HIP events, best of 10)")
     assert best <= 2.0, best
     assert dev.is_cuda and one_euro_smooth(seq[:0].to(DEV), **kw).shape[0] == 0
+
+
+def test_whole_chain_with_15_key_points():
+    """Round 6: make_animation_smooth whole at num_kp = 15 -- the detectors' heads span 128 logit columns there, so KPDetector_a is NOT in
+    the wide + thin form and the tail's split hand-over falls back to the reference's NCHW tensor (SplitFeatureMap.to_nchw) inside
+    driving_keypoints -- key points and frames against the oracle's chain."""
+    cfg = {**hot_path_config(), "num_kp": 15}
+    sd = synthetic_state_dict(cfg, seed=1234)
+    gen = OcclusionAwareGenerator(**cfg)
+    gen.load_state_dict(sd, strict=True)
+    cfg_k, cfg_a = {**kp_detector_config(), "num_kp": 15}, {**kp_detector_a_config(), "num_kp": 15}
+    sd_k, sd_a = trained_like_kp_state_dict(cfg_k, 78), trained_like_kp_state_dict(cfg_a, 77)
+    sd_d = synthetic_state_dict(None, seed=3, spec=deconv_state_dict_spec())
+    kp, kpa, tail = KPDetector(**cfg_k), KPDetector_a(**cfg_a), DeconvTail()
+    kp.load_state_dict(sd_k, strict=True)
+    kpa.load_state_dict(sd_a, strict=True)
+    tail.load_state_dict(sd_d, strict=True)
+    gen, kp, tail, kpa = [m.to(DEV).eval() for m in (gen, kp, tail, kpa)]
+    T = 9
+    src, feats = synthetic_source(256, seed=1), synthetic_lstm_features(T, seed=5)
+    f32, span, kps = animate_from_features(gen, kp, tail, kpa, src, feats, batch=4, front_batch=5, uint8=False, to_host=True,
+                                           return_keypoints=True)
+    assert span == (0, T) and kpa.accepts_split(64, 64) == 0 and tail.split_channels() == 32
+    kp_s, norm, raw, smooth = orc.animation_keypoints(sd_k, cfg_k, sd_d, sd_a, cfg_a, src, feats)
+    nv, nj = torch.cat([n["value"] for n in norm]), torch.cat([n["jacobian"] for n in norm])
+    for name, got, want in (("raw", kps["kp_driving_raw"], raw), ("smoothed", kps["kp_driving_smoothed"], smooth),
+                            ("normalised", kps["kp_norm"], {"value": nv, "jacobian": nj})):
+        ev = float((got["value"].cpu() - want["value"]).abs().max())
+        ej = float((got["jacobian"].cpu() - want["jacobian"]).abs().max())
+        print(f"\nK = 15 {name:11s} value {ev:.2e}  jacobian {ej:.2e}")
+        assert ev <= 5e-5 and ej <= 2e-4, (name, ev, ej)
+    pick = [0, 4, 8]
+    srcb = src.expand(len(pick), -1, -1, -1).contiguous()
+    ksb = {k: v.cpu().expand(len(pick), *v.shape[1:]).contiguous() for k, v in kps["kp_source"].items()}
+    with torch.no_grad():
+        ref = orc.generator_forward(sd, cfg, srcb, {k: v.cpu()[pick] for k, v in kps["kp_norm"].items()}, ksb)["prediction"]
+    assert float((f32[pick] - ref).abs().max()) <= TOL["prediction"]

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r06"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 table = {}
 if os.path.exists(os.path.join(P, "pmc_traffic.json")):
@@ -20,6 +20,7 @@ for size_tag in ("256_b16", "512_b8"):
     for src, dst in (("kernel_trace_stats.txt", f"{rnd}_{size_tag}_rocprofv3_kernel_trace_stats.txt"),
                      ("bench_under_kernel_trace.json", f"{rnd}_{size_tag}_bench_under_kernel_trace.json"),
                      ("bneck_timeline.txt", f"{rnd}_{size_tag}_bneck_timeline.txt"),
+                     ("per_launch_frac.txt", f"{rnd}_{size_tag}_per_launch_frac.txt"),
                      ("pmc_fetch.txt", f"{rnd}_{size_tag}_pmc_fetch.txt"), ("pmc_write.txt", f"{rnd}_{size_tag}_pmc_write.txt"),
                      ("pmc_sq.txt", f"{rnd}_{size_tag}_pmc_sq.txt"), ("pmc_lds.txt", f"{rnd}_{size_tag}_pmc_lds.txt")):
         if os.path.exists(os.path.join(d, src)):

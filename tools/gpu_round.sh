@@ -4,7 +4,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-a}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 O=$R/gpurun_out/${ROUND}_$TAG
 mkdir -p $O
 cd $R
