@@ -156,7 +156,12 @@ def per_launch_frac(bench_json, db):
     roof = line["roofline"]
     chains = int(roof.get("pass_chains", roof.get("chains", 2)))
     con = sqlite3.connect(db)
-    rows = con.execute("select name, count(*), avg(duration), min(duration), max(duration) from kernels group by name").fetchall()
+    cols = [r[1] for r in con.execute("pragma table_info('kernels')")] or [d[0] for d in con.execute("select * from kernels limit 1").description]
+    # one instantiation may serve several launch sizes (at 512x512 the hourglass encoder's levels run the bottleneck's GEMM instantiation):
+    # group by (name, grid) when the trace has the grid, so that the averages are those of ONE launch geometry
+    gcols = [c for c in ("grid_size", "grid_size_x", "grid_x", "grid") if c in cols]
+    grp = "name" + (", " + gcols[0] if gcols else "")
+    rows = con.execute(f"select name, count(*), avg(duration), min(duration), max(duration) from kernels group by {grp}").fetchall()
     gemms = [r for r in rows if "wino4_gemm_kernel" in r[0]]
     trans = [r for r in rows if "wino4_input_transform_kernel" in r[0]]
     if not gemms or not trans:
