@@ -181,6 +181,13 @@ def per_launch_frac(bench_json, db):
     print(f"executed GFLOP per GEMM launch (bench line, launch geometry): {gflop_launch:.3f}  ({roof['per_launch'].get('frames', '?')} frames per launch)")
     print(f"one launch alone:        {gflop_launch:.3f} GFLOP / {g_us:.2f} us / {FP32_MFMA_PEAK_TFLOPS} TFLOP/s = {frac_gemm:.4f} of the chip "
           f"(a launch occupies 1/{chains} of the CUs: {frac_gemm * chains:.4f} of those)")
+    blocks, cus = roof["per_launch"].get("launch_blocks"), roof.get("cus", 256)
+    if blocks and blocks * chains > cus:
+        # e.g. 512x512 x 8: a 4-frame launch is 256 workgroups -- the chains' launches TIME-share the CUs, so a launch's duration depends on
+        # what the other chain runs beside it (min / max above) and "launches side by side on disjoint CUs" does not describe the stage
+        print(f"a launch is {blocks} workgroups, the {chains} chains' launches together exceed the {cus} CUs: they time-share the chip and the "
+              f"side-by-side derivation below does NOT apply at this size -- the trace's own union of the chains' windows does "
+              f"(--bneck-timeline: the profiler's per-dispatch cost is small against this step)")
     print(f"stage, {chains} chains side by side: {chains} x {gflop_launch:.3f} GFLOP / ({g_us:.2f} + {t_us:.2f}) us / {FP32_MFMA_PEAK_TFLOPS} = {frac_pair:.4f}")
     print(f"bench.py line of the same run (HIP-event union of the chains' windows): frac {roof['frac']:.4f}"
           f" -> derived / reported = {frac_pair / roof['frac']:.3f}")
