@@ -156,3 +156,27 @@ def test_batched_heads_on_the_lds_dma_tile_match_the_oracle_and_the_small_call(a
     for n, e in errs.items():
         assert e <= TOL_KP[n], (n, e)
         assert float((big[n][:2] - small[n]).abs().max()) <= TOL_KP[n] / 2, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("audio", [False, True])
+def test_sliced_head_reductions_on_small_maps(audio):
+    """The pixel-sliced reductions (B >= 8) where a slice holds a dozen pixels: the tiny detectors' 10 x 10 heat-map windows, nine images,
+    against the oracle and against the per-(image, key point) kernel's results for the same images (calls of two)."""
+    cfg = tiny_kp_config(audio=audio)
+    sd = synthetic_state_dict(cfg, seed=77, spec=kp_state_dict_spec(cfg))
+    mod = (KPDetector_a if audio else KPDetector)(**cfg)
+    mod.load_state_dict(sd, strict=True)
+    mod = mod.to("cuda:0").eval()
+    if audio:
+        x = torch.from_numpy(np.random.RandomState(12).standard_normal((9, cfg["block_expansion"] + cfg["num_channels_a"], 16, 16)).astype(np.float32))
+    else:
+        x = synthetic_source(64, seed=6, batch=9)
+    with torch.no_grad():
+        big = {n: v.cpu() for n, v in mod(x.to("cuda:0")).items()}
+        pairs = [mod(x[i:i + 2].to("cuda:0")) for i in (0, 2, 4, 6)]
+        ref = (orc.kp_detector_a_forward if audio else orc.kp_detector_forward)(sd, cfg, x)
+    for n in ("value", "jacobian", "heatmap"):
+        assert float((big[n] - ref[n]).abs().max()) <= TOL_KP[n], n
+        small = torch.cat([p[n].cpu() for p in pairs])
+        assert float((big[n][:8] - small).abs().max()) <= TOL_KP[n] / 2, n
