@@ -715,6 +715,8 @@ hipError_t wino4_gemm_launch(const WinoLayer& L, const float* V, int B, int H, i
     a.u_bytes = (unsigned)ub;
     const bool sub4 = L.Cin % (4 * CONV_BK) == 0;
     hipError_t e = hipErrorInvalidValue;
+    // (round 6: a three-stage ring for the narrow launches -- two intervals of operands in flight -- measured 21.8 us per launch against 21.5:
+    //  the one-frame launch is not DMA-latency bound; its 12 intervals cost what the steady-state kernel's cost, 1.2 us each, + ~7 us fixed)
     if (narrow) variant = 30;
     switch (variant) {   // (chunks per barrier, ring depth, MFMAs per DMA piece)
         case 30: e = wino4_launch_variant<4, 2, 4, 0, 2>(a, stream); break;
